@@ -1,0 +1,64 @@
+"""Deterministic synthetic NeRF scene shared by the ray-marching tests (numpy only).
+
+Occupancy = solid sphere of radius `radius` inside the [-bound,bound]^3 cube, stored the way the
+reference stores it: a Morton-ordered density grid [C, H^3] packed 8 cells per byte
+(lib/models/autoencoders/base_nerf.py:208-216, base_volume_renderer.py:105-177).
+Cameras: pinhole, looking at the origin from `dist` (lib/apis/adapter3d.py:991-996: distance 3.7,
+fov 30 deg).
+"""
+import numpy as np
+
+
+def morton_np(x, y, z):
+    def spread(v):
+        v = v.astype(np.uint32)
+        v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+        v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+        v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+        v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+        return v
+    return spread(x) | (spread(y) << np.uint32(1)) | (spread(z) << np.uint32(2))
+
+
+def sphere_density_grid(H=128, C=1, bound=1.0, radius=0.5, seed=0):
+    """-> density grid f32 [C, H^3] in Morton order; value 1+noise inside the sphere, noise*0.005 outside."""
+    rng = np.random.default_rng(seed)
+    g = np.arange(H)
+    X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
+    idx = morton_np(X.ravel(), Y.ravel(), Z.ravel())
+    grid = np.zeros((C, H ** 3), np.float32)
+    for c in range(C):
+        b = min(2.0 ** c, bound)
+        px = ((X.ravel() + 0.5) / H * 2 - 1) * b
+        py = ((Y.ravel() + 0.5) / H * 2 - 1) * b
+        pz = ((Z.ravel() + 0.5) / H * 2 - 1) * b
+        inside = (px * px + py * py + pz * pz) < radius * radius
+        vals = np.where(inside, 1.0 + rng.random(H ** 3), 0.005 * rng.random(H ** 3)).astype(np.float32)
+        grid[c, idx] = vals
+    return grid
+
+
+def camera_rays(n_views=2, S=32, dist=3.7, fov_deg=30.0, seed=0, jitter=True):
+    """-> rays_o, rays_d  f32 [n_views*S*S, 3] (unit directions)."""
+    rng = np.random.default_rng(seed)
+    f = S / (2 * np.tan(np.deg2rad(fov_deg) / 2))
+    os_, ds_ = [], []
+    for v in range(n_views):
+        az = 2 * np.pi * v / n_views + 0.1
+        el = -0.3 + 0.9 * (v / max(n_views - 1, 1))
+        eye = dist * np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+        fwd = -eye / np.linalg.norm(eye)
+        right = np.cross(fwd, np.array([0, 0, 1.0]))
+        right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        j, i = np.meshgrid(np.arange(S), np.arange(S), indexing='ij')
+        u = (i + 0.5 - S / 2) / f
+        w = (j + 0.5 - S / 2) / f
+        if jitter:
+            u = u + rng.normal(0, 1e-3, u.shape)
+        d = fwd[None, None] + u[..., None] * right[None, None] - w[..., None] * up[None, None]
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        os_.append(np.broadcast_to(eye, d.shape).reshape(-1, 3))
+        ds_.append(d.reshape(-1, 3))
+    return (np.ascontiguousarray(np.concatenate(os_), dtype=np.float32),
+            np.ascontiguousarray(np.concatenate(ds_), dtype=np.float32))
