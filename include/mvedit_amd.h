@@ -128,6 +128,73 @@ MVE_API int mve_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh
 MVE_API int mve_compact_alive(const int32_t* d_rays_alive, uint32_t n_alive, int32_t* d_out, int32_t* d_n_out,
                               void* d_scratch, void* stream);
 
+/* =========================================================================
+ * 2. UNet primitives (activations are NHWC = [B*H*W, C] row-major, 16-bit
+ *    storage `dtype` in {MVE_F16, MVE_BF16}, fp32 accumulation everywhere).
+ *    They replace the third-party arithmetic (diffusers==0.27.2 on cuDNN /
+ *    cuBLAS / SDPA) that the reference drives from
+ *    lib/models/architecture/diffusers.py:57-164 (unet_enc/unet_dec) and
+ *    lib/models/architecture/ip_adapter/attention_processor.py:198-270.
+ * ========================================================================= */
+
+#define MVE_GEMM_GEGLU   1   /* W rows interleaved (value,gate): out[m][i] = v[2i]*gelu(v[2i+1]), out width N/2 */
+#define MVE_GEMM_OUT_F32 2   /* out is float32 instead of `dtype` */
+
+/* out[m][n] = out_scale * ( sum_k A[m][k]*W[n][k] + bias[n] + rowvec[m/rows_per_vec][n] + residual[m][n] )
+ * A: [M][lda] dtype, W: [N][K] dtype (torch Linear / 1x1-conv layout), out: [M][ldc];
+ * bias: [N] f32 or NULL; rowvec: [ceil(M/rows_per_vec)][N] f32 or NULL (the per-image time embedding of
+ * ResnetBlock2D); residual: [M][ldr] dtype or NULL.  N, K, lda, ldr multiples of 8. */
+MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, void* d_out, int ldc, int M, int N, int K,
+                     const float* d_bias, const float* d_rowvec, int rows_per_vec, const void* d_residual, int ldr,
+                     int flags, float out_scale, void* stream);
+
+/* 3x3 convolution, padding 1, as an implicit GEMM over NHWC input(s):
+ *   input = concat_channels(x1[B,Hs,Ws,C1], x2[B,Hs,Ws,C2]) (C2 = 0: single input), optionally
+ *   nearest-upsampled 2x (`upsample`; diffusers Upsample2D) and/or strided (`stride` 1|2; Downsample2D);
+ *   W: [Cout][3][3][C1+C2] dtype; out: [B*Ho*Wo][ldc]; epilogue as mve_gemm with rows_per_vec = Ho*Wo. */
+MVE_API int mve_conv3x3(int dtype, const void* d_x1, int C1, const void* d_x2, int C2, int B, int Hs, int Ws,
+                        int stride, int upsample, const void* d_W, int Cout, void* d_out, int ldc,
+                        const float* d_bias, const float* d_rowvec, const void* d_residual, int ldr, int flags,
+                        float out_scale, void* stream);
+
+/* Scaled-dot-product attention over packed projections (no head permutes):
+ *   Q row (b,i) at d_Q + (b*Lq+i)*ldq, head h at column h*head_dim; same for K/V with Lk, O with Lq.
+ *   Optional second KV segment (K2,V2,Lk2) is logically concatenated after the first along the key
+ *   axis (reference attention: lib/pipelines/zero123plus.py:66-69, lib/models/architecture/diffusers.py:646-673).
+ *   Cross-image attention (lib/models/architecture/joint_attn.py:13-17) is B/=n, Lq*=n by the caller.
+ *   head_dim in {40, 64, 80, 160}.  Replaces F.scaled_dot_product_attention
+ *   (lib/models/architecture/ip_adapter/attention_processor.py:246-248). */
+MVE_API int mve_attention(int dtype, const void* d_Q, int ldq, const void* d_K, int ldk, const void* d_V, int ldv,
+                          const void* d_K2, int ldk2, const void* d_V2, int ldv2, void* d_O, int ldo,
+                          int B, int Lq, int Lk, int Lk2, int heads, int head_dim, float scale, void* stream);
+
+/* GroupNorm over NHWC input (optionally the channel-concat of two tensors) with optional fused SiLU:
+ *   out[B*HW][C1+C2] = act( (x - mean_g) * rstd_g * gamma + beta ), torch.nn.GroupNorm semantics.
+ * gamma/beta: [C1+C2] f32.  d_workspace: >= mve_groupnorm_workspace_bytes(B,HW,C,G) bytes.
+ * (ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out of diffusers 0.27.2,
+ * reached from lib/models/architecture/diffusers.py:86-97,139-162.) */
+MVE_API size_t mve_groupnorm_workspace_bytes(int B, int HW, int C, int G);
+MVE_API int mve_groupnorm_silu(int dtype, const void* d_x1, int C1, const void* d_x2, int C2, int B, int HW, int G,
+                               float eps, const float* d_gamma, const float* d_beta, int silu, void* d_out,
+                               void* d_workspace, void* stream);
+
+/* LayerNorm over the last axis of x[M][ldx] (C <= 2048, C % 8 == 0); gamma/beta f32 [C]. */
+MVE_API int mve_layernorm(int dtype, const void* d_x, int ldx, void* d_y, int ldy, int M, int C,
+                          const float* d_gamma, const float* d_beta, float eps, void* stream);
+
+/* Boundary helpers: the reference seam `unet(sample, t, ...)` is NCHW (adapter3d_mixin.py:117-125). */
+MVE_API int mve_nchw_to_nhwc(int dst_dtype, int src_dtype, const void* d_x, int B, int C, int H, int W, int Cpad,
+                             void* d_y, void* stream);
+MVE_API int mve_nhwc_to_nchw(int dst_dtype, int src_dtype, const void* d_x, int ld, int B, int C, int H, int W,
+                             void* d_y, void* stream);
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out[b] = [cos(t*f_k) | sin(t*f_k)] */
+MVE_API int mve_timestep_embedding(int dtype, const float* d_t, int B, int dim, void* d_out, void* stream);
+MVE_API int mve_silu(int dtype, const void* d_x, void* d_y, size_t n, void* stream);
+MVE_API int mve_axpy(int dtype, const void* d_a, const void* d_b, float alpha, void* d_y, size_t n, void* stream); /* y = a + alpha*b */
+/* classifier-free guidance, adapter3d_mixin.py:130-134: out = g*text + (1-g)*uncond (f32) */
+MVE_API int mve_cfg_combine(const float* d_uncond, const float* d_text, float guidance_scale, float* d_out, size_t n,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,178 @@
+// Small HBM-bound helpers around the UNet hot path (gfx950): layout conversion at the NCHW boundary of the
+// reference's `unet(sample, ...)` seam, the sinusoidal timestep embedding, SiLU, residual adds and the
+// classifier-free-guidance combine of lib/pipelines/adapter3d_mixin.py:129-134.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// NCHW (f32 | f16 | bf16) -> NHWC 16-bit with the channel axis zero-padded to Cpad (multiple of 8)
+template <class Tag, class Src>
+__global__ __launch_bounds__(NT) void k_nchw_to_nhwc(const Src* __restrict__ x, int B, int C, int HW, int Cpad,
+                                                     typename Tag::T* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;   // over B*HW*Cpad
+    const size_t total = (size_t)B * HW * Cpad;
+    if (i >= total) return;
+    const int c = (int)(i % Cpad);
+    const size_t pix = i / Cpad;
+    const int b = (int)(pix / HW), r = (int)(pix - (size_t)b * HW);
+    float v = 0.f;
+    if (c < C) v = (float)x[((size_t)b * C + c) * HW + r];
+    y[i] = Tag::from_f32(v);
+}
+
+// NHWC (16-bit or f32, row stride ld) -> NCHW (f32 | 16-bit), first C channels
+template <class SrcT, class Dst>
+__global__ __launch_bounds__(NT) void k_nhwc_to_nchw(const SrcT* __restrict__ x, int ld, int B, int C, int HW,
+                                                     Dst* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;   // over B*C*HW (output order)
+    const size_t total = (size_t)B * C * HW;
+    if (i >= total) return;
+    const int r = (int)(i % HW);
+    const size_t bc = i / HW;
+    const int c = (int)(bc % C), b = (int)(bc / C);
+    y[i] = (Dst)(float)x[((size_t)b * HW + r) * ld + c];
+}
+
+// diffusers Timesteps(num_channels=dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin] halves
+template <class Tag>
+__global__ void k_timestep_embedding(const float* __restrict__ t, int B, int dim, typename Tag::T* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, c = i - b * dim, half = dim / 2;
+    const int k = c < half ? c : c - half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);   // ln(10000)
+    const float arg = t[b] * freq;
+    out[i] = Tag::from_f32(c < half ? cosf(arg) : sinf(arg));
+}
+
+template <class Tag>
+__global__ __launch_bounds__(NT) void k_silu(const typename Tag::T* __restrict__ x, typename Tag::T* __restrict__ y, size_t n8) {
+    typedef typename Tag::V8 V8;
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n8) return;
+    const V8 v = reinterpret_cast<const V8*>(x)[i];
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = Tag::to_f32(v[e]); o[e] = Tag::from_f32(f / (1.0f + __expf(-f))); }
+    reinterpret_cast<V8*>(y)[i] = o;
+}
+
+// y = a + alpha * b   (16-bit, fp32 math)
+template <class Tag>
+__global__ __launch_bounds__(NT) void k_axpy(const typename Tag::T* __restrict__ a, const typename Tag::T* __restrict__ b,
+                                             float alpha, typename Tag::T* __restrict__ y, size_t n8) {
+    typedef typename Tag::V8 V8;
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n8) return;
+    const V8 va = reinterpret_cast<const V8*>(a)[i], vb = reinterpret_cast<const V8*>(b)[i];
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = Tag::from_f32(Tag::to_f32(va[e]) + alpha * Tag::to_f32(vb[e]));
+    reinterpret_cast<V8*>(y)[i] = o;
+}
+
+// noise = g * text + (1 - g) * uncond   on f32 NCHW latents (adapter3d_mixin.py:130-134)
+__global__ __launch_bounds__(NT) void k_cfg(const float* __restrict__ uncond, const float* __restrict__ text, float g,
+                                            float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i < n) out[i] = g * text[i] + (1.0f - g) * uncond[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int mve_nchw_to_nhwc(int dst_dtype, int src_dtype, const void* x, int B, int C, int H, int W, int Cpad, void* y, void* stream) {
+    MVE_CHECK(Cpad >= C && Cpad % 8 == 0, MVE_ERR_ARG, "nchw_to_nhwc: Cpad=%d must be >= C=%d and a multiple of 8", Cpad, C);
+    const size_t total = (size_t)B * H * W * Cpad;
+    if (total == 0) return MVE_OK;
+    MVE_CHECK(x && y, MVE_ERR_ARG, "nchw_to_nhwc: null pointer");
+    const unsigned grid = mve_cdiv(total, NT);
+    hipStream_t s = (hipStream_t)stream;
+#define GO(TAG, SRC) k_nchw_to_nhwc<TAG, SRC><<<grid, NT, 0, s>>>((const SRC*)x, B, C, H * W, Cpad, (typename TAG::T*)y)
+    if (dst_dtype == MVE_F16) {
+        if (src_dtype == MVE_F32) GO(F16Tag, float);
+        else if (src_dtype == MVE_F16) GO(F16Tag, f16);
+        else if (src_dtype == MVE_BF16) GO(F16Tag, bf16);
+        else { mve_set_error("nchw_to_nhwc: bad src dtype %d", src_dtype); return MVE_ERR_ARG; }
+    } else if (dst_dtype == MVE_BF16) {
+        if (src_dtype == MVE_F32) GO(BF16Tag, float);
+        else if (src_dtype == MVE_F16) GO(BF16Tag, f16);
+        else if (src_dtype == MVE_BF16) GO(BF16Tag, bf16);
+        else { mve_set_error("nchw_to_nhwc: bad src dtype %d", src_dtype); return MVE_ERR_ARG; }
+    } else { mve_set_error("nchw_to_nhwc: bad dst dtype %d", dst_dtype); return MVE_ERR_ARG; }
+#undef GO
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_nhwc_to_nchw(int dst_dtype, int src_dtype, const void* x, int ld, int B, int C, int H, int W, void* y, void* stream) {
+    const size_t total = (size_t)B * C * H * W;
+    if (total == 0) return MVE_OK;
+    MVE_CHECK(x && y && ld >= C, MVE_ERR_ARG, "nhwc_to_nchw: bad arguments");
+    const unsigned grid = mve_cdiv(total, NT);
+    hipStream_t s = (hipStream_t)stream;
+#define GO(SRC, DST) k_nhwc_to_nchw<SRC, DST><<<grid, NT, 0, s>>>((const SRC*)x, ld, B, C, H * W, (DST*)y)
+    if (src_dtype == MVE_F32) {
+        if (dst_dtype == MVE_F32) GO(float, float);
+        else if (dst_dtype == MVE_F16) GO(float, f16);
+        else if (dst_dtype == MVE_BF16) GO(float, bf16);
+        else { mve_set_error("nhwc_to_nchw: bad dst dtype"); return MVE_ERR_ARG; }
+    } else if (src_dtype == MVE_F16) {
+        if (dst_dtype == MVE_F32) GO(f16, float);
+        else if (dst_dtype == MVE_F16) GO(f16, f16);
+        else { mve_set_error("nhwc_to_nchw: bad dst dtype"); return MVE_ERR_ARG; }
+    } else if (src_dtype == MVE_BF16) {
+        if (dst_dtype == MVE_F32) GO(bf16, float);
+        else if (dst_dtype == MVE_BF16) GO(bf16, bf16);
+        else { mve_set_error("nhwc_to_nchw: bad dst dtype"); return MVE_ERR_ARG; }
+    } else { mve_set_error("nhwc_to_nchw: bad src dtype"); return MVE_ERR_ARG; }
+#undef GO
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_timestep_embedding(int dtype, const float* t, int B, int dim, void* out, void* stream) {
+    if (B == 0) return MVE_OK;
+    MVE_CHECK(t && out && dim > 0 && dim % 2 == 0, MVE_ERR_ARG, "timestep_embedding: bad arguments");
+    const unsigned grid = mve_cdiv((size_t)B * dim, 256);
+    if (dtype == MVE_F16) k_timestep_embedding<F16Tag><<<grid, 256, 0, (hipStream_t)stream>>>(t, B, dim, (f16*)out);
+    else if (dtype == MVE_BF16) k_timestep_embedding<BF16Tag><<<grid, 256, 0, (hipStream_t)stream>>>(t, B, dim, (bf16*)out);
+    else { mve_set_error("timestep_embedding: bad dtype"); return MVE_ERR_ARG; }
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_silu(int dtype, const void* x, void* y, size_t n, void* stream) {
+    if (n == 0) return MVE_OK;
+    MVE_CHECK(x && y && n % 8 == 0, MVE_ERR_ARG, "silu: n must be a multiple of 8");
+    const unsigned grid = mve_cdiv(n / 8, NT);
+    if (dtype == MVE_F16) k_silu<F16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const f16*)x, (f16*)y, n / 8);
+    else if (dtype == MVE_BF16) k_silu<BF16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const bf16*)x, (bf16*)y, n / 8);
+    else { mve_set_error("silu: bad dtype"); return MVE_ERR_ARG; }
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_axpy(int dtype, const void* a, const void* b, float alpha, void* y, size_t n, void* stream) {
+    if (n == 0) return MVE_OK;
+    MVE_CHECK(a && b && y && n % 8 == 0, MVE_ERR_ARG, "axpy: n must be a multiple of 8");
+    const unsigned grid = mve_cdiv(n / 8, NT);
+    if (dtype == MVE_F16) k_axpy<F16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const f16*)a, (const f16*)b, alpha, (f16*)y, n / 8);
+    else if (dtype == MVE_BF16) k_axpy<BF16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const bf16*)a, (const bf16*)b, alpha, (bf16*)y, n / 8);
+    else { mve_set_error("axpy: bad dtype"); return MVE_ERR_ARG; }
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_cfg_combine(const float* uncond, const float* text, float guidance_scale, float* out, size_t n, void* stream) {
+    if (n == 0) return MVE_OK;
+    MVE_CHECK(uncond && text && out, MVE_ERR_ARG, "cfg_combine: null pointer");
+    k_cfg<<<mve_cdiv(n, NT), NT, 0, (hipStream_t)stream>>>(uncond, text, guidance_scale, out, n);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,375 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (fp16 or bf16 storage, fp32 accumulate).
+//
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] )
+//
+// A is either a dense row-major matrix (Linear / 1x1 conv over NHWC activations) or the im2col
+// view of an NHWC activation tensor gathered on the fly (3x3 conv, pad 1; stride 1 or 2; optional
+// nearest 2x upsample of the input; optional channel-concat of two inputs).  W is [N][K] row-major
+// ("B^T"), which is PyTorch's Linear layout and, for convs, [Cout][kh][kw][Cin].
+//
+// Work decomposition (all wave64):
+//   block tile 128 x BN (BN = 128 | 160 | 64) x 64, 256 threads = 4 waves in a 2x2 grid;
+//   each wave owns a 64 x BN/2 sub-tile = 4 x (BN/32) fragments of v_mfma_f32_16x16x32_{f16,bf16};
+//   the MFMA is issued "swapped" (W fragment as the A operand, activation fragment as B), so every
+//   lane ends up with 4 consecutive n for one m -- the epilogue then moves whole float4s;
+//   LDS tiles are [rows][64] 16-bit with a 16-byte-chunk XOR swizzle chunk ^= (row>>1)&7 that makes
+//   the ds_read_b128 fragment reads conflict free; two LDS stages, global loads for tile k+1 are
+//   issued before the MFMAs of tile k and written to LDS after them (one barrier per K tile);
+//   the accumulator tile is staged through LDS in fp32 (two 64-row passes) so that bias / time-embedding
+//   / residual / GEGLU are applied in fp32 and the global stores are full 16-byte row segments.
+//   blockIdx -> tile uses the XCD-aware bijective remap so that tiles sharing an activation row panel
+//   run on one XCD (one L2).
+//
+// Replaces (behaviourally) the cuDNN/cuBLAS calls behind diffusers' ResnetBlock2D / Attention /
+// FeedForward as driven by lib/models/architecture/diffusers.py:57-164 of the reference.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;           // elements
+constexpr int NT = 256;
+constexpr int ROW_BYTES = BK * 2;  // 128 B per tile row
+
+struct ConvGeom {
+    // virtual input (after optional upsample) Hv x Wv, source tensors Hs x Ws
+    int Hs, Ws, Hv, Wv, Ho, Wo;
+    int C1, C2;        // channels of source 1 / source 2 (C2 = 0: no concat)
+    int stride;        // 1 or 2
+    int ups;           // 0 or 1 (nearest 2x)
+};
+
+struct GemmParams {
+    const void* A;     // dense A [M][lda]  or conv source 1 (NHWC)
+    const void* A2;    // conv source 2 (concat) or null
+    const void* W;     // [N][K]
+    void* out;         // [M][ldc] (or [M][ldc] with N/2 valid columns for GEGLU)
+    const float* bias;       // [N] or null
+    const float* rowvec;     // [M/rows_per_vec][N] f32 (time embedding), or null
+    const void* residual;    // [M][ldr] 16-bit or null
+    int M, N, K;
+    int lda, ldc, ldr;
+    int rows_per_vec;
+    int geglu;         // 1: out[m][i] = v[2i] * gelu(v[2i+1])
+    int out_f32;       // 1: out is float
+    float out_scale;   // multiplies the final value (1/output_scale_factor)
+    ConvGeom g;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <class Tag, int BN, int MODE>   // MODE 0: dense A, 1: conv3x3 gather
+__global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
+    constexpr int WN = BN / 2;          // wave sub-tile width
+    constexpr int NF = WN / 16;         // W fragments per wave (4 / 5 / 2)
+    constexpr int MF = 4;               // activation fragments per wave (64 rows)
+    constexpr int B_ROWS_PER_PASS = NT / 8;             // 32 rows per load pass
+    constexpr int A_PASSES = BM / B_ROWS_PER_PASS;      // 4
+    constexpr int B_PASSES = BN / B_ROWS_PER_PASS;      // 4 / 5 / 2
+    constexpr int A_STAGE = BM * ROW_BYTES;             // 16 KB
+    constexpr int B_STAGE = BN * ROW_BYTES;
+    constexpr int STAGE = A_STAGE + B_STAGE;
+    constexpr int CS_LD = BN + 4;                       // fp32 staging row stride (floats)
+    constexpr int SMEM = (2 * STAGE > 64 * CS_LD * 4) ? 2 * STAGE : 64 * CS_LD * 4;
+    typedef typename Tag::V8 V8;
+    typedef typename Tag::T T;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const unsigned tile = mve_xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-thread load coordinates ------------------------------------------------------
+    const int lc = tid & 7;            // 16-byte chunk within the 128-byte K slice
+    const int lr = tid >> 3;           // row within a 32-row pass
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W);
+
+    // dense A
+    const T* a_row[A_PASSES];
+    // conv A
+    int cb[A_PASSES], cy[A_PASSES], cx[A_PASSES];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            int m = m0 + lr + j * B_ROWS_PER_PASS;
+            m = m < p.M ? m : p.M - 1;
+            a_row[j] = reinterpret_cast<const T*>(p.A) + (size_t)m * p.lda;
+        }
+    } else {
+        const int hw = p.g.Ho * p.g.Wo;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            int m = m0 + lr + j * B_ROWS_PER_PASS;
+            m = m < p.M ? m : p.M - 1;
+            const int b = m / hw, r = m - b * hw;
+            const int y = r / p.g.Wo;
+            cb[j] = b;
+            cy[j] = y * p.g.stride - 1;
+            cx[j] = (r - y * p.g.Wo) * p.g.stride - 1;
+        }
+    }
+    const T* w_row[B_PASSES];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+        int n = n0 + lr + j * B_ROWS_PER_PASS;
+        n = n < p.N ? n : p.N - 1;
+        w_row[j] = Wp + (size_t)n * p.K;
+    }
+
+    // conv: running (tap, cin) of this thread's chunk
+    const int Ctot = p.g.C1 + p.g.C2;
+    int tap = 0, cin = lc * 8;
+    if constexpr (MODE == 1) {
+        while (cin >= Ctot) { cin -= Ctot; ++tap; }
+    }
+
+    u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + lc * 8;
+        const bool kin = k < p.K;
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < A_PASSES; ++j)
+                a_reg[j] = kin ? *reinterpret_cast<const u32x4*>(a_row[j] + k) : zero4;
+        } else {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const bool second = cin >= p.g.C1;
+            const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
+            const int cs = second ? p.g.C2 : p.g.C1;
+            const int ch = second ? cin - p.g.C1 : cin;
+#pragma unroll
+            for (int j = 0; j < A_PASSES; ++j) {
+                const int yi = cy[j] + dy, xi = cx[j] + dx;
+                const bool ok = kin && yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv;
+                const int ys = yi >> p.g.ups, xs = xi >> p.g.ups;
+                const size_t off = (((size_t)cb[j] * p.g.Hs + ys) * p.g.Ws + xs) * cs + ch;
+                a_reg[j] = ok ? *reinterpret_cast<const u32x4*>(src + off) : zero4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j)
+            b_reg[j] = kin ? *reinterpret_cast<const u32x4*>(w_row[j] + k) : zero4;
+        if constexpr (MODE == 1) {
+            cin += BK;
+            while (cin >= Ctot) { cin -= Ctot; ++tap; }
+        }
+    };
+
+    auto store_tile = [&](int stage) {
+        unsigned char* As = smem + stage * STAGE;
+        unsigned char* Bs = As + A_STAGE;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            const int row = lr + j * B_ROWS_PER_PASS;
+            *reinterpret_cast<u32x4*>(As + swz(row, lc)) = a_reg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) {
+            const int row = lr + j * B_ROWS_PER_PASS;
+            *reinterpret_cast<u32x4*>(Bs + swz(row, lc)) = b_reg[j];
+        }
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned char* As = smem + cur * STAGE;
+        const unsigned char* Bs = As + A_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8 xf[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+                xf[i] = *reinterpret_cast<const V8*>(As + swz(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                wf[j] = *reinterpret_cast<const V8*>(Bs + swz(wn * WN + j * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf[j], xf[i], acc[j][i]);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: two 64-row passes through an fp32 LDS tile -----------------------------------
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CHUNKS = BN / 8;                 // 8-column chunks per row
+    constexpr int TASKS = 64 * CHUNKS;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const int r = i * 16 + (lane & 15);
+                    const int c = wn * WN + j * 16 + (lane >> 4) * 4;
+                    *reinterpret_cast<f32x4*>(Cs + r * CS_LD + c) = acc[j][i];
+                }
+        }
+        __syncthreads();
+        for (int task = tid; task < TASKS; task += NT) {
+            const int r = task / CHUNKS, ch = task - r * CHUNKS;
+            const int m = m0 + pass * 64 + r, n = n0 + ch * 8;
+            if (m >= p.M || n >= p.N) continue;      // N is a multiple of 8: whole chunk in or out
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+            if (p.bias) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            }
+            if (p.rowvec) {
+                const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.N + n;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            }
+            if (p.geglu) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = v[2 * e] * gelu_erf(v[2 * e + 1]);
+                T* op = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1);
+                typedef T T4 __attribute__((ext_vector_type(4)));
+                T4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = Tag::from_f32(o[e]);
+                *reinterpret_cast<T4*>(op) = pk;
+                continue;
+            }
+            if (p.residual) {
+                const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+            if (p.out_f32) {
+                float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+                *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                V8 pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
+                *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = pk;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <class Tag, int MODE>
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    // tile width: prefer the widest tile that divides N (no dead columns), else 128
+    int bn = 128;
+    if (p.N % 160 == 0) bn = 160;
+    else if (p.N % 128 == 0) bn = 128;
+    else if (p.N <= 64) bn = 64;
+    const unsigned tiles_m = mve_cdiv(p.M, BM), tiles_n = mve_cdiv(p.N, bn);
+    const unsigned grid = tiles_m * tiles_n;
+    if (bn == 160) k_gemm<Tag, 160, MODE><<<grid, NT, 0, s>>>(p);
+    else if (bn == 128) k_gemm<Tag, 128, MODE><<<grid, NT, 0, s>>>(p);
+    else k_gemm<Tag, 64, MODE><<<grid, NT, 0, s>>>(p);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int check_common(const GemmParams& p, const char* who) {
+    MVE_CHECK(p.M > 0 && p.N > 0 && p.K > 0, MVE_ERR_ARG, "%s: empty problem M=%d N=%d K=%d", who, p.M, p.N, p.K);
+    MVE_CHECK(p.N % 8 == 0 && p.K % 8 == 0, MVE_ERR_ARG, "%s: N (%d) and K (%d) must be multiples of 8", who, p.N, p.K);
+    MVE_CHECK(p.W && p.out, MVE_ERR_ARG, "%s: null pointer", who);
+    MVE_CHECK(p.ldc % 4 == 0, MVE_ERR_ARG, "%s: ldc must be a multiple of 4", who);
+    MVE_CHECK(!p.residual || p.ldr % 8 == 0, MVE_ERR_ARG, "%s: ldr must be a multiple of 8", who);
+    MVE_CHECK(!p.rowvec || p.rows_per_vec > 0, MVE_ERR_ARG, "%s: rows_per_vec must be > 0", who);
+    MVE_CHECK(!(p.geglu && (p.residual || p.out_f32)), MVE_ERR_ARG, "%s: geglu excludes residual/out_f32", who);
+    return MVE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mve_gemm(int dtype, const void* A, int lda, const void* W, void* out, int ldc, int M, int N, int K,
+             const float* bias, const float* rowvec, int rows_per_vec, const void* residual, int ldr, int flags,
+             float out_scale, void* stream) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.rows_per_vec = rows_per_vec;
+    p.geglu = (flags & MVE_GEMM_GEGLU) ? 1 : 0;
+    p.out_f32 = (flags & MVE_GEMM_OUT_F32) ? 1 : 0;
+    p.out_scale = out_scale;
+    if (M == 0) return MVE_OK;
+    int rc = check_common(p, "gemm");
+    if (rc) return rc;
+    MVE_CHECK(A && lda % 8 == 0 && lda >= K, MVE_ERR_ARG, "gemm: bad A/lda (%d)", lda);
+    if (dtype == MVE_F16) return launch_gemm<F16Tag, 0>(p, (hipStream_t)stream);
+    if (dtype == MVE_BF16) return launch_gemm<BF16Tag, 0>(p, (hipStream_t)stream);
+    mve_set_error("gemm: unsupported dtype %d", dtype);
+    return MVE_ERR_ARG;
+}
+
+int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int Hs, int Ws, int stride,
+                int upsample, const void* W, int Cout, void* out, int ldc, const float* bias, const float* rowvec,
+                const void* residual, int ldr, int flags, float out_scale, void* stream) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    MVE_CHECK(stride == 1 || stride == 2, MVE_ERR_ARG, "conv3x3: stride must be 1 or 2");
+    MVE_CHECK(!(upsample && stride != 1), MVE_ERR_ARG, "conv3x3: upsample requires stride 1");
+    MVE_CHECK(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0, MVE_ERR_ARG,
+              "conv3x3: channel counts must be multiples of 8 (C1=%d C2=%d)", C1, C2);
+    MVE_CHECK(x1 && (C2 == 0 || x2), MVE_ERR_ARG, "conv3x3: null input");
+    if (B == 0) return MVE_OK;
+    p.g.Hs = Hs; p.g.Ws = Ws;
+    p.g.ups = upsample ? 1 : 0;
+    p.g.Hv = Hs << p.g.ups; p.g.Wv = Ws << p.g.ups;
+    p.g.stride = stride;
+    p.g.Ho = (p.g.Hv + 2 - 3) / stride + 1;
+    p.g.Wo = (p.g.Wv + 2 - 3) / stride + 1;
+    p.g.C1 = C1; p.g.C2 = C2;
+    p.A = x1; p.A2 = x2; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
+    p.M = B * p.g.Ho * p.g.Wo; p.N = Cout; p.K = 9 * (C1 + C2);
+    p.ldc = ldc; p.ldr = ldr;
+    p.rows_per_vec = p.g.Ho * p.g.Wo;
+    p.geglu = 0;
+    p.out_f32 = (flags & MVE_GEMM_OUT_F32) ? 1 : 0;
+    p.out_scale = out_scale;
+    int rc = check_common(p, "conv3x3");
+    if (rc) return rc;
+    if (dtype == MVE_F16) return launch_gemm<F16Tag, 1>(p, (hipStream_t)stream);
+    if (dtype == MVE_BF16) return launch_gemm<BF16Tag, 1>(p, (hipStream_t)stream);
+    mve_set_error("conv3x3: unsupported dtype %d", dtype);
+    return MVE_ERR_ARG;
+}
+
+}  // extern "C"

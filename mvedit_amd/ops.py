@@ -1,0 +1,152 @@
+"""Thin typed wrappers over the UNet-primitive entry points of libmvedit_amd (section 2 of
+include/mvedit_amd.h).  Tensors are PyTorch-ROCm tensors used as storage; activations are NHWC
+(`[B*H*W, C]` row-major) in fp16 or bf16.  No op here has a torch fallback: if the extension is
+missing, importing `mvedit_amd._lib` raises.
+"""
+import torch
+
+from . import _lib
+
+GEGLU = 1
+OUT_F32 = 2
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.int32: 3, torch.uint8: 4}
+
+
+def dt(t):
+    return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+
+
+def _s(t):
+    return _lib.stream_ptr(t.device)
+
+
+def _chk16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float16, torch.bfloat16), (t.dtype, t.shape)
+
+
+def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, out=None, out_scale=1.0):
+    """a [M,K], w [N,K] -> [M,N] (or [M,N/2] with GEGLU).  bias/rowvec fp32."""
+    _chk16(a, w, residual)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    n_out = N // 2 if flags & GEGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.float32 if flags & OUT_F32 else a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.call('mve_gemm', dt(a), _lib.ptr(a), a.stride(0), _lib.ptr(w), _lib.ptr(out), out.stride(0), M, N, K,
+                  _lib.ptr(bias), _lib.ptr(rowvec), int(rows_per_vec), _lib.ptr(residual),
+                  residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _s(a))
+    return out
+
+
+def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec=None, residual=None, flags=0,
+            out_scale=1.0):
+    """x1 [B*H*W, C1] (+ x2 [B*H*W, C2]) NHWC, w [Cout,3,3,C1+C2] -> ([B*Ho*Wo, Cout], Ho, Wo)."""
+    _chk16(x1, x2, w, residual)
+    C1 = x1.shape[1]
+    C2 = x2.shape[1] if x2 is not None else 0
+    Cout = w.shape[0]
+    assert w.shape[1:] == (3, 3, C1 + C2)
+    Hv, Wv = (H * 2, W * 2) if upsample else (H, W)
+    Ho, Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
+    out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32 if flags & OUT_F32 else x1.dtype, device=x1.device)
+    with torch.cuda.device(x1.device):
+        _lib.call('mve_conv3x3', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x2), C2, B, H, W, stride, int(bool(upsample)),
+                  _lib.ptr(w), Cout, _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(rowvec), _lib.ptr(residual),
+                  residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _s(x1))
+    return out, Ho, Wo
+
+
+def groupnorm(x1, B, HW, gamma, beta, G=32, eps=1e-5, silu=True, x2=None):
+    _chk16(x1, x2)
+    C1 = x1.shape[1]
+    C2 = x2.shape[1] if x2 is not None else 0
+    C = C1 + C2
+    out = torch.empty(B * HW, C, dtype=x1.dtype, device=x1.device)
+    ws = torch.empty(_lib.raw('mve_groupnorm_workspace_bytes')(B, HW, C, G), dtype=torch.uint8, device=x1.device)
+    with torch.cuda.device(x1.device):
+        _lib.call('mve_groupnorm_silu', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x2), C2, B, HW, G, float(eps), _lib.ptr(gamma),
+                  _lib.ptr(beta), int(bool(silu)), _lib.ptr(out), _lib.ptr(ws), _s(x1))
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _chk16(x)
+    M, C = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.call('mve_layernorm', dt(x), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), M, C, _lib.ptr(gamma),
+                  _lib.ptr(beta), float(eps), _s(x))
+    return y
+
+
+def attention(q, k, v, B, Lq, Lk, heads, head_dim, scale=None, k2=None, v2=None, Lk2=0, out=None):
+    """q: [B*Lq, >=heads*d] view (any row stride), k/v: [B*Lk, ...] views; returns [B*Lq, heads*d]."""
+    for t in (q, k, v, k2, v2):
+        if t is not None:
+            assert t.is_cuda and t.stride(1) == 1 and t.dtype in (torch.float16, torch.bfloat16)
+    if scale is None:
+        scale = head_dim ** -0.5
+    if out is None:
+        out = torch.empty(B * Lq, heads * head_dim, dtype=q.dtype, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.call('mve_attention', dt(q), _lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0),
+                  _lib.ptr(k2), k2.stride(0) if k2 is not None else 0, _lib.ptr(v2), v2.stride(0) if v2 is not None else 0,
+                  _lib.ptr(out), out.stride(0), B, Lq, Lk, int(Lk2), heads, head_dim, float(scale), _s(q))
+    return out
+
+
+def nchw_to_nhwc(x, dtype, cpad=None):
+    B, C, H, W = x.shape
+    cpad = cpad or (C + 7) // 8 * 8
+    x = x.contiguous()
+    y = torch.empty(B * H * W, cpad, dtype=dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call('mve_nchw_to_nhwc', dt(dtype), dt(x), _lib.ptr(x), B, C, H, W, cpad, _lib.ptr(y), _s(x))
+    return y
+
+
+def nhwc_to_nchw(x, B, C, H, W, dtype):
+    assert x.is_contiguous() or x.stride(1) == 1
+    y = torch.empty(B, C, H, W, dtype=dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call('mve_nhwc_to_nchw', dt(dtype), dt(x), _lib.ptr(x), x.stride(0), B, C, H, W, _lib.ptr(y), _s(x))
+    return y
+
+
+def timestep_embedding(t, dim, dtype):
+    t = t.float().contiguous()
+    out = torch.empty(t.shape[0], dim, dtype=dtype, device=t.device)
+    with torch.cuda.device(t.device):
+        _lib.call('mve_timestep_embedding', dt(dtype), _lib.ptr(t), t.shape[0], dim, _lib.ptr(out), _s(t))
+    return out
+
+
+def silu(x):
+    _chk16(x)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.call('mve_silu', dt(x), _lib.ptr(x), _lib.ptr(y), x.numel(), _s(x))
+    return y
+
+
+def axpy(a, b, alpha=1.0):
+    _chk16(a, b)
+    y = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.call('mve_axpy', dt(a), _lib.ptr(a), _lib.ptr(b), float(alpha), _lib.ptr(y), a.numel(), _s(a))
+    return y
+
+
+def cfg_combine(uncond, text, guidance_scale):
+    uncond = uncond.float().contiguous()
+    text = text.float().contiguous()
+    out = torch.empty_like(uncond)
+    with torch.cuda.device(uncond.device):
+        _lib.call('mve_cfg_combine', _lib.ptr(uncond), _lib.ptr(text), float(guidance_scale), _lib.ptr(out),
+                  uncond.numel(), _s(uncond))
+    return out

@@ -1,0 +1,236 @@
+"""UNet primitive kernels (C ABI section 2) against plain torch fp32 on CPU -- the same primitives
+(F.linear / F.conv2d / F.group_norm / F.layer_norm / softmax attention) the UNet oracle is built from.
+
+Tolerance (stated once): inputs are rounded to the storage dtype first and fed identically to both
+sides; the HIP kernels accumulate in fp32 and round the result once to the storage dtype, so
+    max|hip - ref| / max|ref|  <= 1e-3 (fp16)   /  8e-3 (bf16: 2^-8 output rounding)
+and the relative L2 error is bounded by the same number.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def check(name, got, ref, dtype, extra=''):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f'{name}: non-finite output {extra}'
+    err = (got - ref).abs()
+    rel_max = (err.max() / ref.abs().max().clamp_min(1e-12)).item()
+    rel_l2 = ((got - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+    if not (rel_max <= TOL[dtype] and rel_l2 <= TOL[dtype]):
+        idx = np.unravel_index(int(err.argmax()), err.shape)
+        bad = (err > 10 * TOL[dtype] * ref.abs().max()).float()
+        rows_bad = bad.reshape(bad.shape[0], -1).mean(1)
+        msg = (f'{name} {extra}: rel_max={rel_max:.3e} rel_l2={rel_l2:.3e} tol={TOL[dtype]:.0e}; worst at {idx}: '
+               f'got {got[idx].item():.5f} ref {ref[idx].item():.5f}; frac bad={bad.mean().item():.4f}; '
+               f'first bad rows={torch.nonzero(rows_bad > 0)[:8].flatten().tolist()}')
+        raise AssertionError(msg)
+    return rel_max, rel_l2
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 320, 320), (1000, 640, 328), (77, 1280, 768), (4096, 320, 2880),
+                                   (130, 8, 40), (512, 2560, 320), (64, 1280, 1280), (300, 200, 136)])
+def test_gemm_plain(lib, dtype, M, N, K):
+    from mvedit_amd import ops
+    a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    out = ops.gemm(a.cuda(), w.cuda())
+    check('gemm', out, a.float() @ w.float().t(), dtype, f'M={M} N={N} K={K}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_gemm_epilogues(lib, dtype):
+    from mvedit_amd import ops
+    M, N, K = 2 * 333, 640, 320
+    a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    bias = rnd((N,), torch.float32, 3)
+    rowvec = rnd((2, N), torch.float32, 4)
+    res = rnd((M, N), dtype, 5)
+    ref = a.float() @ w.float().t() + bias + rowvec.repeat_interleave(333, 0) + res.float()
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), rowvec=rowvec.cuda(), rows_per_vec=333, residual=res.cuda())
+    check('gemm+bias+rowvec+residual', out, ref, dtype)
+    out32 = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), flags=ops.OUT_F32, out_scale=0.5)
+    assert out32.dtype == torch.float32
+    check('gemm f32 out', out32, 0.5 * (a.float() @ w.float().t() + bias), dtype)
+    # GEGLU: interleaved (value, gate) rows, as the engine packs diffusers' GEGLU.proj
+    wv, wg = rnd((N, K), dtype, 6, K ** -0.5), rnd((N, K), dtype, 7, K ** -0.5)
+    bv, bg = rnd((N,), torch.float32, 8), rnd((N,), torch.float32, 9)
+    w_il = torch.stack([wv, wg], 1).reshape(2 * N, K).contiguous()
+    b_il = torch.stack([bv, bg], 1).reshape(2 * N).contiguous()
+    ref = (a.float() @ wv.float().t() + bv) * F.gelu(a.float() @ wg.float().t() + bg)
+    out = ops.gemm(a.cuda(), w_il.cuda(), bias=b_il.cuda(), flags=ops.GEGLU)
+    assert out.shape == (M, N)
+    check('gemm geglu', out, ref, dtype)
+    # strided A and residual views (a column slice of a wider buffer)
+    wide = rnd((M, K + 64), dtype, 10).cuda()
+    out = ops.gemm(wide[:, 64:], w.cuda())
+    check('gemm strided A', out, wide[:, 64:].float().cpu() @ w.float().t(), dtype)
+
+
+def conv_ref(x_nchw, w_oihw, bias=None, stride=1, upsample=False):
+    x = x_nchw.float()
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode='nearest')
+    return F.conv2d(x, w_oihw.float(), bias, stride=stride, padding=1)
+
+
+def to_nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('B,H,W,C1,C2,Cout,stride,ups', [
+    (2, 16, 16, 64, 0, 128, 1, False),
+    (1, 64, 64, 320, 0, 320, 1, False),      # the heaviest SD-1.5 shape (one image)
+    (3, 8, 8, 8, 0, 320, 1, False),          # conv_in (4 latent channels zero padded to 8)
+    (2, 12, 20, 320, 0, 8, 1, False),        # conv_out (4 output channels padded to 8), non-square
+    (2, 16, 16, 320, 0, 320, 2, False),      # Downsample2D
+    (2, 8, 8, 640, 0, 640, 1, True),         # Upsample2D: nearest 2x fused into the gather
+    (2, 8, 8, 640, 320, 320, 1, False),      # skip-concat input (two sources)
+    (5, 9, 7, 72, 40, 88, 1, False),         # ragged everything
+    (2, 9, 7, 72, 0, 88, 2, False),          # odd size, stride 2
+])
+def test_conv3x3(lib, dtype, B, H, W, C1, C2, Cout, stride, ups):
+    from mvedit_amd import ops
+    x1 = rnd((B, C1, H, W), dtype, 1)
+    x2 = rnd((B, C2, H, W), dtype, 2) if C2 else None
+    C = C1 + C2
+    w = rnd((Cout, C, 3, 3), dtype, 3, (9 * C) ** -0.5)
+    bias = rnd((Cout,), torch.float32, 4)
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    ref = conv_ref(xin, w, bias, stride, ups)
+    w_k = w.permute(0, 2, 3, 1).contiguous()            # [Cout][kh][kw][Cin]
+    out, Ho, Wo = ops.conv3x3(to_nhwc(x1).cuda(), w_k.cuda(), B, H, W, x2=to_nhwc(x2).cuda() if C2 else None,
+                              stride=stride, upsample=ups, bias=bias.cuda())
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    check('conv3x3', out, to_nhwc(ref), dtype, f'{(B, H, W, C1, C2, Cout, stride, ups)}')
+
+
+def test_conv3x3_resblock_epilogue(lib):
+    """conv + bias + per-image time embedding + residual, as ResnetBlock2D uses it."""
+    from mvedit_amd import ops
+    dtype = torch.float16
+    B, H, W, C = 3, 16, 16, 320
+    x = rnd((B, C, H, W), dtype, 1)
+    w = rnd((C, C, 3, 3), dtype, 2, (9 * C) ** -0.5)
+    bias, temb = rnd((C,), torch.float32, 3), rnd((B, C), torch.float32, 4)
+    res = rnd((B, C, H, W), dtype, 5)
+    ref = conv_ref(x, w, bias) + temb[:, :, None, None] + res.float()
+    out, _, _ = ops.conv3x3(to_nhwc(x).cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), B, H, W, bias=bias.cuda(),
+                            rowvec=temb.cuda(), residual=to_nhwc(res).cuda())
+    check('conv3x3 resblock epilogue', out, to_nhwc(ref), dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('B,HW,C1,C2,silu,eps', [(2, 64 * 64, 320, 0, True, 1e-5), (3, 16 * 16, 1280, 640, True, 1e-5),
+                                                  (2, 8 * 8, 2560, 0, True, 1e-5), (2, 32 * 32, 640, 0, False, 1e-6),
+                                                  (1, 33, 640, 320, True, 1e-5)])
+def test_groupnorm(lib, dtype, B, HW, C1, C2, silu, eps):
+    from mvedit_amd import ops
+    C = C1 + C2
+    x1 = rnd((B * HW, C1), dtype, 1) + 0.5
+    x2 = (rnd((B * HW, C2), dtype, 2) * 2 - 1).to(dtype) if C2 else None
+    gamma, beta = 1 + 0.2 * rnd((C,), torch.float32, 3), 0.2 * rnd((C,), torch.float32, 4)
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    xr = xin.float().reshape(B, HW, C).permute(0, 2, 1)
+    ref = F.group_norm(xr, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(B * HW, C)
+    out = ops.groupnorm(x1.cuda(), B, HW, gamma.cuda(), beta.cuda(), 32, eps, silu, x2.cuda() if C2 else None)
+    check('groupnorm', out, ref, dtype, f'{(B, HW, C1, C2, silu)}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('M,C', [(4096, 320), (1023, 640), (70, 1280), (5, 2048)])
+def test_layernorm(lib, dtype, M, C):
+    from mvedit_amd import ops
+    x = rnd((M, C), dtype, 1) * 3 + 1
+    gamma, beta = 1 + 0.2 * rnd((C,), torch.float32, 3), 0.2 * rnd((C,), torch.float32, 4)
+    out = ops.layernorm(x.cuda(), gamma.cuda(), beta.cuda())
+    check('layernorm', out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), dtype)
+
+
+def attn_ref(q, k, v, B, Lq, Lk, heads, d):
+    q = q.float().reshape(B, Lq, heads, d).transpose(1, 2)
+    k = k.float().reshape(B, Lk, heads, d).transpose(1, 2)
+    v = v.float().reshape(B, Lk, heads, d).transpose(1, 2)
+    p = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1)
+    return (p @ v).transpose(1, 2).reshape(B * Lq, heads * d)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('B,Lq,Lk,heads,d', [(2, 256, 256, 8, 40), (1, 4096, 4096, 2, 40), (2, 1024, 1024, 8, 80),
+                                             (2, 256, 256, 8, 160), (3, 64, 64, 8, 160), (2, 1000, 77, 8, 40),
+                                             (2, 256, 77, 8, 80), (1, 64, 93, 8, 160), (2, 300, 300, 5, 64),
+                                             (1, 128, 16, 8, 40)])
+def test_attention(lib, dtype, B, Lq, Lk, heads, d):
+    from mvedit_amd import ops
+    C = heads * d
+    q, k, v = rnd((B * Lq, C), dtype, 1), rnd((B * Lk, C), dtype, 2), rnd((B * Lk, C), dtype, 3)
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), B, Lq, Lk, heads, d)
+    check('attention', out, attn_ref(q, k, v, B, Lq, Lk, heads, d), dtype, f'{(B, Lq, Lk, heads, d)}')
+
+
+def test_attention_packed_qkv_spike_and_segments(lib):
+    from mvedit_amd import ops
+    dtype = torch.float16
+    B, L, heads, d = 2, 320, 8, 40
+    C = heads * d
+    qkv = rnd((B * L, 3 * C), dtype, 1)
+    # force the online-softmax rescale path: one key row dominates a late tile for one query
+    qkv[5, :C] *= 6
+    qkv[300, C:2 * C] = qkv[5, :C]
+    g = qkv.cuda()
+    out = ops.attention(g[:, :C], g[:, C:2 * C], g[:, 2 * C:], B, L, L, heads, d)
+    check('attention packed qkv', out, attn_ref(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, L, L, heads, d), dtype)
+    # two KV segments == concatenation along the key axis (reference attention)
+    L2 = 150
+    k2, v2 = rnd((B * L2, C), dtype, 4), rnd((B * L2, C), dtype, 5)
+    kc = torch.cat([qkv[:, C:2 * C].reshape(B, L, C), k2.reshape(B, L2, C)], 1).reshape(-1, C)
+    vc = torch.cat([qkv[:, 2 * C:].reshape(B, L, C), v2.reshape(B, L2, C)], 1).reshape(-1, C)
+    out = ops.attention(g[:, :C], g[:, C:2 * C], g[:, 2 * C:], B, L, L, heads, d, k2=k2.cuda(), v2=v2.cuda(), Lk2=L2)
+    check('attention 2 segments', out, attn_ref(qkv[:, :C], kc, vc, B, L, L + L2, heads, d), dtype)
+    # cross-image attention (joint_attn.py:13-17): [2b, L, C] viewed as [b, 2L, C]
+    out = ops.attention(g[:, :C], g[:, C:2 * C], g[:, 2 * C:], B // 2, 2 * L, 2 * L, heads, d)
+    check('attention cross-image', out,
+          attn_ref(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B // 2, 2 * L, 2 * L, heads, d), dtype)
+
+
+def test_boundary_helpers(lib):
+    from mvedit_amd import ops
+    x = rnd((3, 4, 8, 6), torch.float32, 1)
+    y = ops.nchw_to_nhwc(x.cuda(), torch.float16)
+    assert y.shape == (3 * 48, 8)
+    ref = torch.zeros(3, 8, 6, 8)
+    ref[..., :4] = x.permute(0, 2, 3, 1)
+    assert torch.equal(y.cpu().float(), ref.reshape(-1, 8).half().float())
+    back = ops.nhwc_to_nchw(y, 3, 4, 8, 6, torch.float32)
+    assert torch.equal(back.cpu(), x.half().float())
+    t = torch.tensor([499.0, 3.0, 981.0])
+    emb = ops.timestep_embedding(t.cuda(), 320, torch.float16).float().cpu()
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half) / half)
+    arg = t[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1)
+    assert (emb - ref).abs().max() < 2e-3
+    a, b = rnd((64, 320), torch.float16, 2), rnd((64, 320), torch.float16, 3)
+    assert torch.allclose(ops.axpy(a.cuda(), b.cuda(), 0.5).float().cpu(), (a.float() + 0.5 * b.float()).half().float())
+    assert torch.allclose(ops.silu(a.cuda()).float().cpu(), F.silu(a.float()).half().float(), atol=2e-3)
+    u, tx = rnd((2, 4, 8, 8), torch.float32, 4), rnd((2, 4, 8, 8), torch.float32, 5)
+    assert torch.allclose(ops.cfg_combine(u.cuda(), tx.cuda(), 7.0).cpu(), 7.0 * tx + (1 - 7.0) * u, atol=1e-5)
