@@ -141,12 +141,12 @@ MVE_API int mve_compact_alive(const int32_t* d_rays_alive, uint32_t n_alive, int
 #define MVE_GEMM_OUT_F32 2   /* out is float32 instead of `dtype` */
 
 /* out[m][n] = out_scale * ( sum_k A[m][k]*W[n][k] + bias[n] + rowvec[m/rows_per_vec][n] + residual[m][n] )
- * A: [M][lda] dtype, W: [N][K] dtype (torch Linear / 1x1-conv layout), out: [M][ldc];
- * bias: [N] f32 or NULL; rowvec: [ceil(M/rows_per_vec)][N] f32 or NULL (the per-image time embedding of
- * ResnetBlock2D); residual: [M][ldr] dtype or NULL.  N, K, lda, ldr multiples of 8. */
-MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, void* d_out, int ldc, int M, int N, int K,
-                     const float* d_bias, const float* d_rowvec, int rows_per_vec, const void* d_residual, int ldr,
-                     int flags, float out_scale, void* stream);
+ * A: [M][lda] dtype, W: [N][ldw] dtype (torch Linear / 1x1-conv layout; ldw > K selects a column block),
+ * out: [M][ldc]; bias: [N] f32 or NULL; rowvec: [ceil(M/rows_per_vec)][ldrv] f32 or NULL (the per-image time
+ * embedding of ResnetBlock2D); residual: [M][ldr] dtype or NULL.  N, K, lda, ldw, ldr multiples of 8. */
+MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int ldw, void* d_out, int ldc,
+                     int M, int N, int K, const float* d_bias, const float* d_rowvec, int ldrv, int rows_per_vec,
+                     const void* d_residual, int ldr, int flags, float out_scale, void* stream);
 
 /* 3x3 convolution, padding 1, as an implicit GEMM over NHWC input(s):
  *   input = concat_channels(x1[B,Hs,Ws,C1], x2[B,Hs,Ws,C2]) (C2 = 0: single input), optionally
@@ -154,8 +154,8 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, void*
  *   W: [Cout][3][3][C1+C2] dtype; out: [B*Ho*Wo][ldc]; epilogue as mve_gemm with rows_per_vec = Ho*Wo. */
 MVE_API int mve_conv3x3(int dtype, const void* d_x1, int C1, const void* d_x2, int C2, int B, int Hs, int Ws,
                         int stride, int upsample, const void* d_W, int Cout, void* d_out, int ldc,
-                        const float* d_bias, const float* d_rowvec, const void* d_residual, int ldr, int flags,
-                        float out_scale, void* stream);
+                        const float* d_bias, const float* d_rowvec, int ldrv, const void* d_residual, int ldr,
+                        int flags, float out_scale, void* stream);
 
 /* Scaled-dot-product attention over packed projections (no head permutes):
  *   Q row (b,i) at d_Q + (b*Lq+i)*ldq, head h at column h*head_dim; same for K/V with Lk, O with Lq.

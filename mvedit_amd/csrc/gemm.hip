@@ -48,7 +48,7 @@ struct GemmParams {
     const float* rowvec;     // [M/rows_per_vec][N] f32 (time embedding), or null
     const void* residual;    // [M][ldr] 16-bit or null
     int M, N, K;
-    int lda, ldc, ldr;
+    int lda, ldw, ldc, ldr, ldrv;   // row strides (elements) of A, W, out, residual, rowvec
     int rows_per_vec;
     int geglu;         // 1: out[m][i] = v[2i] * gelu(v[2i+1])
     int out_f32;       // 1: out is float
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     for (int j = 0; j < B_PASSES; ++j) {
         int n = n0 + lr + j * B_ROWS_PER_PASS;
         n = n < p.N ? n : p.N - 1;
-        w_row[j] = Wp + (size_t)n * p.K;
+        w_row[j] = Wp + (size_t)n * p.ldw;
     }
 
     // conv: running (tap, cin) of this thread's chunk
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
                 for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
             }
             if (p.rowvec) {
-                const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.N + n;
+                const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.ldrv + n;
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + 4);
 #pragma unroll
@@ -310,7 +310,9 @@ int check_common(const GemmParams& p, const char* who) {
     MVE_CHECK(p.W && p.out, MVE_ERR_ARG, "%s: null pointer", who);
     MVE_CHECK(p.ldc % 4 == 0, MVE_ERR_ARG, "%s: ldc must be a multiple of 4", who);
     MVE_CHECK(!p.residual || p.ldr % 8 == 0, MVE_ERR_ARG, "%s: ldr must be a multiple of 8", who);
-    MVE_CHECK(!p.rowvec || p.rows_per_vec > 0, MVE_ERR_ARG, "%s: rows_per_vec must be > 0", who);
+    MVE_CHECK(!p.rowvec || (p.rows_per_vec > 0 && p.ldrv % 4 == 0 && p.ldrv >= p.N), MVE_ERR_ARG,
+              "%s: rowvec needs rows_per_vec > 0 and ldrv (%d) a multiple of 4 >= N", who, p.ldrv);
+    MVE_CHECK(p.ldw % 8 == 0 && p.ldw >= p.K, MVE_ERR_ARG, "%s: ldw (%d) must be a multiple of 8 and >= K", who, p.ldw);
     MVE_CHECK(!(p.geglu && (p.residual || p.out_f32)), MVE_ERR_ARG, "%s: geglu excludes residual/out_f32", who);
     return MVE_OK;
 }
@@ -319,13 +321,14 @@ int check_common(const GemmParams& p, const char* who) {
 
 extern "C" {
 
-int mve_gemm(int dtype, const void* A, int lda, const void* W, void* out, int ldc, int M, int N, int K,
-             const float* bias, const float* rowvec, int rows_per_vec, const void* residual, int ldr, int flags,
+int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
+             const float* bias, const float* rowvec, int ldrv, int rows_per_vec, const void* residual, int ldr, int flags,
              float out_scale, void* stream) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
-    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.rows_per_vec = rows_per_vec;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrv = ldrv;
+    p.rows_per_vec = rows_per_vec;
     p.geglu = (flags & MVE_GEMM_GEGLU) ? 1 : 0;
     p.out_f32 = (flags & MVE_GEMM_OUT_F32) ? 1 : 0;
     p.out_scale = out_scale;
@@ -341,7 +344,7 @@ int mve_gemm(int dtype, const void* A, int lda, const void* W, void* out, int ld
 
 int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int Hs, int Ws, int stride,
                 int upsample, const void* W, int Cout, void* out, int ldc, const float* bias, const float* rowvec,
-                const void* residual, int ldr, int flags, float out_scale, void* stream) {
+                int ldrv, const void* residual, int ldr, int flags, float out_scale, void* stream) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     MVE_CHECK(stride == 1 || stride == 2, MVE_ERR_ARG, "conv3x3: stride must be 1 or 2");
@@ -359,7 +362,7 @@ int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B
     p.g.C1 = C1; p.g.C2 = C2;
     p.A = x1; p.A2 = x2; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
     p.M = B * p.g.Ho * p.g.Wo; p.N = Cout; p.K = 9 * (C1 + C2);
-    p.ldc = ldc; p.ldr = ldr;
+    p.ldc = ldc; p.ldr = ldr; p.ldrv = ldrv; p.ldw = p.K;
     p.rows_per_vec = p.g.Ho * p.g.Wo;
     p.geglu = 0;
     p.out_f32 = (flags & MVE_GEMM_OUT_F32) ? 1 : 0;

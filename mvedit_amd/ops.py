@@ -22,9 +22,10 @@ def _s(t):
 
 
 def _chk16(*ts):
+    """16-bit CUDA tensors whose last axis is dense (row-strided views are fine: lda/ldr/ldc are passed)."""
     for t in ts:
         if t is not None:
-            assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float16, torch.bfloat16), (t.dtype, t.shape)
+            assert t.is_cuda and t.stride(-1) == 1 and t.dtype in (torch.float16, torch.bfloat16), (t.dtype, t.shape)
 
 
 def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, out=None, out_scale=1.0):
@@ -32,13 +33,14 @@ def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, o
     _chk16(a, w, residual)
     M, K = a.shape
     N = w.shape[0]
-    assert w.shape[1] == K
+    assert w.shape[1] == K and (rowvec is None or rowvec.stride(-1) == 1)
     n_out = N // 2 if flags & GEGLU else N
     if out is None:
         out = torch.empty(M, n_out, dtype=torch.float32 if flags & OUT_F32 else a.dtype, device=a.device)
     with torch.cuda.device(a.device):
-        _lib.call('mve_gemm', dt(a), _lib.ptr(a), a.stride(0), _lib.ptr(w), _lib.ptr(out), out.stride(0), M, N, K,
-                  _lib.ptr(bias), _lib.ptr(rowvec), int(rows_per_vec), _lib.ptr(residual),
+        _lib.call('mve_gemm', dt(a), _lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(out), out.stride(0),
+                  M, N, K, _lib.ptr(bias), _lib.ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
+                  int(rows_per_vec), _lib.ptr(residual),
                   residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _s(a))
     return out
 
@@ -56,7 +58,8 @@ def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec
     out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32 if flags & OUT_F32 else x1.dtype, device=x1.device)
     with torch.cuda.device(x1.device):
         _lib.call('mve_conv3x3', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x2), C2, B, H, W, stride, int(bool(upsample)),
-                  _lib.ptr(w), Cout, _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(rowvec), _lib.ptr(residual),
+                  _lib.ptr(w), Cout, _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(rowvec),
+                  rowvec.stride(0) if rowvec is not None else 0, _lib.ptr(residual),
                   residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _s(x1))
     return out, Ho, Wo
 

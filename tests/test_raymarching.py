@@ -336,9 +336,26 @@ def test_gpu_full_size_properties(lib):
     sel = np.concatenate([np.arange(a, a + b) for a, b in rr if b > 0])
     assert (xyzs.cpu().numpy()[sel] == xo).all() and (ts.cpu().numpy()[sel] == to).all()
     # compositing: opaque medium -> alpha saturates to 1 inside the silhouette, 0 outside
-    sig = torch.full((M,), 50.0, device='cuda')
+    sig = torch.full((M,), 400.0, device='cuda')     # dt = dt_min = 2*sqrt(3)/1024 here: alpha = 0.74 per sample
     rgb = torch.rand(M, 3, device='cuda')
     w, ws, dep, img = G.composite_rays_train(sig, rgb, ts, rays, 1e-4)
-    hit = cnt > 8
+    hit = cnt > 16
     assert bool((ws[hit] > 0.99).all()) and bool((ws[cnt == 0] == 0).all())
     assert bool((img.amax(-1) <= ws + 1e-5).all())
+
+
+def test_oracle_matches_reference_kernel_outputs():
+    """tests/golden/raymarching_ref_gfx950.npz holds outputs of the REFERENCE's own kernels
+    (oracle/_ref, built from /root/reference by oracle/build_ref.py) run on an MI355X by
+    tests/test_raymarching_ref.py (MVE_DUMP_REF_GOLDEN): per-ray sample counts and, per ray in ray
+    order, the marched samples.  The C oracle must reproduce them bit-for-bit."""
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'raymarching_ref_gfx950.npz'))
+    cs = small_case(H=64, S=48, views=3, contract=False, dt_gamma=0.0, bound=1.0, C=1)
+    xo, _, to, ro = O.march_rays_train(cs['o'], cs['d'], 1.0, cs['bits'], 1, 64, cs['nears'], cs['fars'], cs['noises'],
+                                       0.0, 512, False)
+    assert (ro[:, 1] == gold['rays_counts']).all()
+    assert xo.shape[0] == int(gold['n_samples'])
+    n = gold['xyzs_head'].shape[0]
+    assert (xo[:n] == gold['xyzs_head']).all() and (to[:n] == gold['ts_head']).all()
+    np.testing.assert_array_equal(xo.astype(np.float64).sum(0), gold['xyz_sum'])
+    np.testing.assert_array_equal(to.astype(np.float64).sum(0), gold['ts_sum'])
