@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Headline benchmark: multi-view denoise-steps/sec (32 views, 512^2) on N MI355X.
+
+One "step" = one pass of the reference's `Adapter3DMixin.get_noise_pred`
+(lib/pipelines/adapter3d_mixin.py:68-135) over ALL V=32 views with classifier-free guidance:
+2*V = 64 SD-1.5 UNet forwards on 64x64 latents (512^2 images) followed by the CFG combine.  ControlNet
+residuals are zero-valued inputs (UNet-only metric); weights are seeded random
+SD-1.5-topology tensors (no checkpoint is reachable offline), data is synthetic and resident in HBM before
+the timed region.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the V views are partitioned across
+ranks (strong scaling: total work fixed at 32 views); every rank denoises its V/N views, then ONE RCCL
+all-gather over xGMI gives every rank the full [V,4,64,64] noise prediction (what the replicated 3D update
+consumes).  value = steps/s of the whole 32-view job = 1 / max-over-ranks(step time).
+
+The JSON line also carries
+  roofline     : the dominant kernel (3x3 implicit-GEMM conv, MFMA bound): algorithmic FLOPs of all its launches in
+                 one step / their summed HIP-event durations, measured in the timed region on the launch stream;
+  cpu_baseline : the torch-fp32 oracle of the same UNet timed on this box's host cores on a bounded sample
+                 (one forward of one image), scaled to 64 forwards/step.  Baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS_F16 = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+VIEWS = 32
+LATENT = 64
+CTX_LEN = 77
+GUIDANCE = 7.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
+    ap.add_argument('--views', type=int, default=VIEWS)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-op-timing', action='store_true', help='time the steps without per-op HIP events')
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg):
+    """Oracle (kind "port") on the host cores: one 64x64 forward of one image, fp32."""
+    from oracle import unet_oracle as U
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    sd = U.make_state_dict(cfg, seed=1234)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, LATENT, LATENT, generator=g)
+    ctx = torch.randn(1, CTX_LEN, cfg['cross_attention_dim'], generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        U.unet_forward(sd, cfg, x, 499, ctx)
+        dt1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        U.unet_forward(sd, cfg, x, 499, ctx)
+        dt2 = time.perf_counter() - t0
+    dt = min(dt1, dt2)
+    return dict(value=1.0 / (2 * VIEWS * dt), unit='denoise-steps/s (32 views)', cores=threads, kind='port',
+                sample=f'1 of the {2 * VIEWS} UNet forwards of a step (1 image, 64x64 latent, fp32 torch oracle), '
+                       f'best of 2: {dt:.2f} s; scaled linearly to {2 * VIEWS} forwards')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists for the HIP path)'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG
+    from mvedit_amd import ops
+    from mvedit_amd.parallel import partition_views
+    from oracle import unet_oracle as U   # weights generator only (shared with the cpu_baseline leg)
+
+    dtype = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
+    cfg = dict(SD15_CONFIG)
+    V = args.views
+    lo, hi = partition_views(V, world, rank)
+    v_loc = hi - lo
+    B = 2 * v_loc
+
+    # ---- weights + synthetic inputs, resident in HBM -------------------------------------------------------
+    sd = U.make_state_dict(cfg, seed=1234, dtype=dtype)
+    eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype, dev)
+    del sd
+    g = torch.Generator().manual_seed(0)
+    latents_all = torch.randn(V, 4, LATENT, LATENT, generator=g)
+    ctx_uncond = torch.randn(1, CTX_LEN, cfg['cross_attention_dim'], generator=g)
+    ctx_text = torch.randn(V, CTX_LEN, cfg['cross_attention_dim'], generator=g)
+    lat = latents_all[lo:hi].to(dev, dtype)
+    sample = torch.cat([lat, lat], 0).contiguous()                                   # [uncond | text] halves
+    ctx = torch.cat([ctx_uncond.expand(v_loc, -1, -1), ctx_text[lo:hi]], 0).to(dev, dtype).contiguous()
+    t = torch.full((B,), 499.0, device=dev)
+    info = eng.plan(B, LATENT, LATENT, CTX_LEN, 1, False, dtype)
+    optab = eng.op_table()
+    gathered = torch.empty(V, 4, LATENT, LATENT, device=dev, dtype=torch.float32) if world > 1 else None
+
+    def step(profile):
+        if profile:
+            out, ms = eng._run(0, sample, t, ctx, 1, None, None, None, profile=True)
+        else:
+            out, ms = eng(sample, t, ctx)[0], None
+        un, tx = out[:v_loc].float(), out[v_loc:].float()
+        noise = ops.cfg_combine(un, tx, GUIDANCE)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, noise.contiguous())
+        return noise, ms
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    per_op = [0.0] * info['n_ops']
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, ms = step(not args.no_op_timing)
+        if ms is not None:
+            per_op = [a + b for a, b in zip(per_op, ms)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------------------------
+    roof = None
+    breakdown = {}
+    if not args.no_op_timing:
+        for (ph, cls, fl, lab), m in zip(optab, per_op):
+            d = breakdown.setdefault(cls, dict(ms=0.0, flops=0.0, launches=0))
+            d['ms'] += m / args.steps
+            d['flops'] += fl
+            d['launches'] += 1
+        dom = max(('conv3x3', 'linear', 'attention'), key=lambda k: breakdown[k]['ms'])
+        b = breakdown[dom]
+        achieved = b['flops'] / (b['ms'] * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel={'conv3x3': 'k_gemm<MODE=1> implicit-GEMM conv3x3', 'linear': 'k_gemm<MODE=0>',
+                                          'attention': 'k_attention'}[dom],
+                    achieved=round(achieved, 1), peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(achieved / PEAK_TFLOPS_F16, 4),
+                    traffic=None, launches_per_step=b['launches'], flops_per_step=b['flops'],
+                    avg_launch_ms=round(b['ms'] / b['launches'], 4),
+                    per_class_ms={k: round(v['ms'], 3) for k, v in breakdown.items()},
+                    per_class_tflops={k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) for k, v in breakdown.items() if v['flops'] > 0})
+
+    if rank == 0:
+        total_flops = sum(info['flops'][k] for k in ('conv3x3', 'linear', 'attention')) * world
+        line = {
+            'metric': 'multi-view denoise-steps/sec (32 views, 512^2)',
+            'value': round(1e3 / ms_per_step, 4), 'unit': 'denoise-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f16' if dtype == torch.float16 else 'bf16',
+            'data': 'synthetic (seeded random SD-1.5-topology weights and latents)',
+            'config': {'workload': f'{V}-view 512x512 get_noise_pred: {2 * V} SD-1.5 UNet forwards (64x64 latents, ctx 77x768) + CFG per step; '
+                                   'ControlNet residuals zero', 'views': V, 'latent': LATENT, 'cfg': True,
+                       'parallelism': f'views/{world}' + (' + all_gather(noise_pred)' if world > 1 else '')},
+            'model_tflops_per_s': round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
+            'model_flops_frac_of_peak': round(total_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_TFLOPS_F16 * world), 4),
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

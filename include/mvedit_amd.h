@@ -195,6 +195,49 @@ MVE_API int mve_axpy(int dtype, const void* d_a, const void* d_b, float alpha, v
 MVE_API int mve_cfg_combine(const float* d_uncond, const float* d_text, float guidance_scale, float* d_out, size_t n,
                             void* stream);
 
+/* =========================================================================
+ * 3. UNet2DCondition executor (native runtime behind the reference's UNet seam).
+ *    Replaces `self.unet(sample, t, encoder_hidden_states=..., cross_attention_kwargs=...,
+ *    down_block_additional_residuals=..., mid_block_additional_residual=...)`
+ *    (lib/pipelines/adapter3d_mixin.py:117-125) and `unet_enc` / `unet_dec`
+ *    (lib/models/architecture/diffusers.py:57-99 / :102-164).
+ *
+ *    Topology arguments are diffusers' UNet2DConditionModel config values: per level i,
+ *    block_out_channels[i], down_attn[i] (CrossAttnDownBlock2D vs DownBlock2D), num_heads[i],
+ *    transformer_layers[i].  Weights are engine-owned: mve_unet_load_param copies one tensor of
+ *    the diffusers state dict (by its diffusers name, in its torch layout, any float dtype) into
+ *    packed device storage; the caller's tensor is not retained.
+ * ========================================================================= */
+MVE_API int mve_unet_create(void** handle, int dtype, int in_channels, int out_channels, int n_levels,
+                            const int* block_out_channels, int layers_per_block, const int* down_attn,
+                            const int* num_heads, const int* transformer_layers, int cross_attention_dim,
+                            int norm_num_groups, float norm_eps, int use_linear_projection);
+MVE_API int mve_unet_destroy(void* handle);
+MVE_API size_t mve_unet_weight_bytes(void* handle);
+MVE_API int mve_unet_load_param(void* handle, const char* name, const void* d_src, int src_dtype, int ndim,
+                                const long long* shape, void* stream);
+/* returns the number of diffusers parameters not loaded yet; buf receives the first missing name */
+MVE_API int mve_unet_missing_params(void* handle, char* buf, int buf_len);
+
+/* Builds (and caches) the static op list for this problem size.  flops[5] = analytic 2*MAC counts per class
+ * {conv3x3, linear/1x1, attention, norm, other}. */
+MVE_API int mve_unet_plan(void* handle, int B, int H, int W, int ctx_len, int num_cross_attn_imgs, int has_residuals,
+                          int io_dtype, int residuals_nhwc, size_t* workspace_bytes, int* n_ops, double* flops);
+
+/* phase 0: full forward; 1: unet_enc only (state stays in the workspace); 2: unet_dec only (same workspace).
+ * sample: [B, in_channels, H, W] NCHW io_dtype; timesteps: [B] f32 device; ctx: [B, ctx_len, cross_dim] io_dtype;
+ * num_cross_attn_imgs: CrossImageAttnProcWrapper group size (lib/models/architecture/joint_attn.py:11-37), 1 = off;
+ * down_residuals: host array of 3*n_levels device pointers (ControlNet down_block_res_samples, NCHW io_dtype,
+ * or NHWC engine dtype if residuals_nhwc) or NULL; out: [B, out_channels, H, W] NCHW io_dtype.
+ * op_ms: optional HOST array [n_ops]; when given every op is bracketed with HIP events on `stream` and the call
+ * synchronises the stream before returning (profiling mode). */
+MVE_API int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype, const float* d_timesteps,
+                             const void* d_ctx, int B, int H, int W, int ctx_len, int num_cross_attn_imgs,
+                             const void* const* down_residuals, const void* d_mid_residual, int residuals_nhwc,
+                             void* d_out, void* d_workspace, size_t workspace_bytes, float* op_ms, void* stream);
+/* op i of the cached plan: class, flops, label; returns 1 if the op belongs to unet_enc, 2 for unet_dec */
+MVE_API int mve_unet_op_info(void* handle, int i, int* cls, double* flops, char* label, int label_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,64 @@
+"""View-parallel execution across the GPUs of one node (new design; the reference pipelines are
+single-GPU: lib/pipelines/mvedit_3d_pipeline.py:11 imports torch.distributed and never calls it).
+
+Views are independent in get_noise_pred (lib/pipelines/adapter3d_mixin.py:77-129) and in rendering
+(lib/pipelines/mvedit_3d_pipeline.py:1341-1389); the 3D update consumes all views.  So: contiguous blocks of
+views per rank, ONE all-gather per outer step (RCCL over xGMI when the backend is "nccl"; gloo in CPU tests),
+then every rank runs the identical seeded 3D update.  Camera pruning (mvedit_3d_pipeline.py:1180-1215)
+shrinks V during the loop: partitions are recomputed from the current V every step.
+"""
+import torch
+import torch.distributed as dist
+
+
+def partition_views(num_views, world_size, rank):
+    """Contiguous [lo, hi) block of views for `rank`; the first (num_views % world_size) ranks get one extra.
+    Rank 0 always owns view 0 (the reference's keep_views are reordered to the front,
+    mvedit_3d_pipeline.py:1149-1175)."""
+    assert 0 <= rank < world_size and num_views >= 0
+    q, r = divmod(num_views, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def partition_sizes(num_views, world_size):
+    return [partition_views(num_views, world_size, r)[1] - partition_views(num_views, world_size, r)[0]
+            for r in range(world_size)]
+
+
+def all_gather_views(local, num_views, group=None):
+    """local: [v_local, ...] tensor of this rank's views -> [num_views, ...] on every rank.
+
+    One collective.  Equal shards use all_gather_into_tensor (a single RCCL call writing straight into the
+    output); ragged shards (V not divisible by the world size, e.g. after camera pruning 32 -> 9) pad to
+    the largest shard and trim.
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        assert local.shape[0] == num_views
+        return local
+    world = dist.get_world_size(group)
+    sizes = partition_sizes(num_views, world)
+    assert local.shape[0] == sizes[dist.get_rank(group)], (local.shape, sizes)
+    local = local.contiguous()
+    if len(set(sizes)) == 1:
+        out = torch.empty((num_views,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    big = max(sizes)
+    pad = torch.zeros((big,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * big,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * big:r * big + s] for r, s in enumerate(sizes)], 0)
+
+
+def repartition(per_view, old_num, keep_ids, group=None):
+    """After camera pruning: per_view holds this rank's slice of `old_num` views; keep_ids (global indices, sorted)
+    are the surviving views.  Returns this rank's slice of the new, smaller view set.  Implemented as
+    all-gather + local slice: per-view state is small (latents 32 KiB/view) next to one UNet step."""
+    full = all_gather_views(per_view, old_num, group)
+    kept = full[torch.as_tensor(keep_ids, device=full.device, dtype=torch.long)]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = partition_views(len(keep_ids), world, rank)
+    return kept[lo:hi].contiguous()

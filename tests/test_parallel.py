@@ -1,0 +1,54 @@
+"""View partitioning + the single all-gather of the multi-GPU design, exercised with world_size 2 and 3 on
+CPU (gloo).  On the GPU box the same code runs over RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mvedit_amd.parallel import partition_views, partition_sizes, all_gather_views, repartition
+
+
+def test_partition_covers_views_exactly():
+    for V in (0, 1, 6, 9, 16, 32, 33, 64):
+        for W in (1, 2, 3, 4, 8):
+            blocks = [partition_views(V, W, r) for r in range(W)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == V
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = partition_sizes(V, W)
+            assert max(sizes) - min(sizes) <= 1 and sum(sizes) == V
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, V, keep):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        full = torch.arange(V * 4 * 2 * 2, dtype=torch.float32).reshape(V, 4, 2, 2)
+        lo, hi = partition_views(V, world, rank)
+        got = all_gather_views(full[lo:hi].clone(), V)
+        assert torch.equal(got, full), (rank, got.shape)
+        # camera pruning: keep a subset, re-partition; the union over ranks must be full[keep]
+        mine = repartition(full[lo:hi].clone(), V, keep)
+        lo2, hi2 = partition_views(len(keep), world, rank)
+        assert torch.equal(mine, full[keep][lo2:hi2])
+        # view-parallel "denoise": each rank transforms its own views, one gather, every rank has the full step result
+        step = all_gather_views(full[lo:hi] * 2 + 1, V)
+        assert torch.equal(step, full * 2 + 1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,V', [(2, 32), (2, 9), (3, 16)])
+def test_all_gather_and_repartition_gloo(world, V):
+    keep = sorted(set(range(0, V, 2)) | {1})
+    mp.spawn(_worker, args=(world, _free_port(), V, keep), nprocs=world, join=True)

@@ -1,0 +1,88 @@
+"""`Adapter3DMixin.get_noise_pred` mirror (lib/pipelines/adapter3d_mixin.py:68-135): chunked walk == fused
+single pass (batch invariance), reference pairing, CFG, against the oracle."""
+import pytest
+import torch
+
+from oracle import unet_oracle as U
+
+pytestmark = pytest.mark.gpu
+
+
+class _Pipe:
+    pass
+
+
+def _make(cfg, dtype, with_cn):
+    from mvedit_amd.unet import UNet2DConditionEngine
+    from mvedit_amd.pipelines import Adapter3DMixin
+
+    class Pipe(Adapter3DMixin):
+        pass
+    sd = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=21).items()}
+    p = Pipe()
+    p.unet = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype)
+    p.controlnet = None
+    if with_cn:
+        from test_unet import residuals
+
+        def controlnet(sample, t, encoder_hidden_states, controlnet_cond, conditioning_scale, guess_mode, added_cond_kwargs,
+                       return_dict):
+            # stand-in ControlNet: deterministic residuals scaled by the conditioning weights
+            down, mid = residuals(cfg, sample.shape[0], sample.shape[-1], seed=5)
+            s = float(conditioning_scale[0]) + float(conditioning_scale[1])
+            return [(s * d).to(sample.dtype).cuda() for d in down], (s * mid).to(sample.dtype).cuda()
+        p.controlnet = controlnet
+    return p, sd
+
+
+def test_get_noise_pred_fused_equals_chunked_and_oracle(lib):
+    cfg, dtype = U.TINY, torch.float16
+    p, sd = _make(cfg, dtype, with_cn=False)
+    V, S = 6, 16
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(V, 4, S, S, generator=g).to(dtype)
+    emb_u = torch.randn(1, 77, 768, generator=g).to(dtype).expand(V, -1, -1)
+    emb_t = torch.randn(V, 77, 768, generator=g).to(dtype)
+    lat2 = torch.cat([lat, lat]).cuda()
+    emb2 = torch.cat([emb_u, emb_t]).cuda()
+    chunks = lambda x, n: list(x.split(n, dim=0))
+    p.fuse_chunks = True
+    fused = p.get_noise_pred(chunks(lat2, 4), chunks(emb2, 4), [None] * 3, None, 499, 0.0, 0.0, 7.0)
+    p.fuse_chunks = False
+    walked = p.get_noise_pred(chunks(lat2, 4), chunks(emb2, 4), [None] * 3, None, 499, 0.0, 0.0, 7.0)
+    assert fused.shape == (V, 4, S, S)
+    assert torch.equal(fused, walked), 'the UNet engine must be batch-invariant'
+    with torch.no_grad():
+        ref = U.unet_forward(sd, cfg, lat2.float().cpu(), 499, emb2.float().cpu(), q=U.quantizer(dtype))
+    ref = 7.0 * ref[V:] + (1 - 7.0) * ref[:V]
+    rel = ((fused.float().cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 4e-3, rel          # CFG amplifies the fp16 difference of the two halves by ~(2g-1)
+    adapter = p.get_noise_pred(chunks(lat2, 4), chunks(emb2, 4), [None] * 3, None, 499, 0.0, 0.0, 7.0, adapter_scale=2.0)
+    assert adapter.shape == fused.shape
+
+
+def test_get_noise_pred_reference_pairing_with_controlnet(lib):
+    """use_reference: latents are [b, 4, 2H, W] (reference image on top), cross-image attention, zero ControlNet
+    residuals for the reference rows, only the view half is returned (adapter3d_mixin.py:86-127)."""
+    cfg, dtype = U.TINY, torch.float16
+    p, sd = _make(cfg, dtype, with_cn=True)
+    V, S = 2, 16
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(2 * V, 4, 2 * S, S, generator=g).to(dtype).cuda()
+    emb = torch.randn(2 * V, 77, 768, generator=g).to(dtype).cuda()
+    ci = torch.zeros(2 * V, 3, 8 * S, 8 * S, dtype=dtype).cuda()
+    out = p.get_noise_pred([lat[:V], lat[V:]], [emb[:V], emb[V:]], [ci[:V], ci[V:]], [ci[:V], ci[V:]], 321, 0.5, 0.25, 5.0)
+    assert out.shape == (V, 4, S, S) and torch.isfinite(out).all()
+    # oracle: un-tile, pair, zero residual rows for the reference image
+    from test_unet import residuals
+    x = lat.float().cpu().reshape(2 * V, 4, 2, S, S).permute(0, 2, 1, 3, 4).reshape(4 * V, 4, S, S)
+    e = emb.float().cpu().unsqueeze(1).expand(-1, 2, -1, -1).reshape(4 * V, 77, 768)
+    down, mid = residuals(cfg, 2 * V, S, seed=5)
+    q = U.quantizer(dtype)
+    zs = lambda r: torch.stack([torch.zeros_like(r), q(0.75 * r)], dim=1).view(-1, *r.shape[1:])
+    with torch.no_grad():
+        ref = U.unet_forward(sd, cfg, x, 321, e, 2, [zs(d) for d in down], zs(mid), q=q)
+    ref = ref.view(2 * V, 2, 4, S, S)[:, 1]
+    ref = 5.0 * ref[V:] + (1 - 5.0) * ref[:V]
+    rel = ((out.float().cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 4e-3, rel
