@@ -227,7 +227,7 @@ MVE_API int mve_unet_plan(void* handle, int B, int H, int W, int ctx_len, int nu
 /* phase 0: full forward; 1: unet_enc only (state stays in the workspace); 2: unet_dec only (same workspace).
  * sample: [B, in_channels, H, W] NCHW io_dtype; timesteps: [B] f32 device; ctx: [B, ctx_len, cross_dim] io_dtype;
  * num_cross_attn_imgs: CrossImageAttnProcWrapper group size (lib/models/architecture/joint_attn.py:11-37), 1 = off;
- * down_residuals: host array of 3*n_levels device pointers (ControlNet down_block_res_samples, NCHW io_dtype,
+ * down_residuals: host array of n_levels*(layers_per_block+1) device pointers (ControlNet down_block_res_samples, NCHW io_dtype,
  * or NHWC engine dtype if residuals_nhwc) or NULL; out: [B, out_channels, H, W] NCHW io_dtype.
  * op_ms: optional HOST array [n_ops]; when given every op is bracketed with HIP events on `stream` and the call
  * synchronises the stream before returning (profiling mode). */

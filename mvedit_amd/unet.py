@@ -145,7 +145,7 @@ class UNet2DConditionEngine:
         keep = []
         res_arr = None
         if has_res:
-            want = 3 * len(self.cfg['block_out_channels'])
+            want = len(self.cfg['block_out_channels']) * (self.cfg['layers_per_block'] + 1)
             assert len(down_res) == want, f'expected {want} down-block residuals, got {len(down_res)}'
             rdt = self.dtype if residuals_nhwc else io_dtype
             keep = [r.to(device=self.device, dtype=rdt).contiguous() for r in down_res]
@@ -219,7 +219,7 @@ class UNet2DConditionEngine:
         if phase == 1:
             # plan with residual slots, but phase 1 never touches them: pass dummies
             dummy = torch.zeros(8, dtype=ctx.dtype, device=self.device)
-            down_res = [dummy] * (3 * len(self.cfg['block_out_channels']))
+            down_res = [dummy] * (len(self.cfg['block_out_channels']) * (self.cfg['layers_per_block'] + 1))
             mid_res = dummy
             return self._run_raw(1, st, sample, ctx, down_res, mid_res)
         return self._run_raw(2, st, None, ctx, down_res, mid_res)

