@@ -139,6 +139,7 @@ MVE_API int mve_compact_alive(const int32_t* d_rays_alive, uint32_t n_alive, int
 
 #define MVE_GEMM_GEGLU   1   /* W rows interleaved (value,gate): out[m][i] = v[2i]*gelu(v[2i+1]), out width N/2 */
 #define MVE_GEMM_OUT_F32 2   /* out is float32 instead of `dtype` */
+#define MVE_CONV_W_CHUNK64 4 /* conv weight is [Cout][Cin/64][3][3][64] (needs C1, C2 multiples of 64) */
 
 /* out[m][n] = out_scale * ( sum_k A[m][k]*W[n][k] + bias[n] + rowvec[m/rows_per_vec][n] + residual[m][n] )
  * A: [M][lda] dtype, W: [N][ldw] dtype (torch Linear / 1x1-conv layout; ldw > K selects a column block),
@@ -151,7 +152,9 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int l
 /* 3x3 convolution, padding 1, as an implicit GEMM over NHWC input(s):
  *   input = concat_channels(x1[B,Hs,Ws,C1], x2[B,Hs,Ws,C2]) (C2 = 0: single input), optionally
  *   nearest-upsampled 2x (`upsample`; diffusers Upsample2D) and/or strided (`stride` 1|2; Downsample2D);
- *   W: [Cout][3][3][C1+C2] dtype; out: [B*Ho*Wo][ldc]; epilogue as mve_gemm with rows_per_vec = Ho*Wo. */
+ *   W: [Cout][3][3][C1+C2] dtype, or with MVE_CONV_W_CHUNK64 [Cout][(C1+C2)/64][3][3][64] (the K order that
+ *   keeps the nine taps of a 64-channel slab adjacent; preferred whenever the channel counts allow it);
+ *   out: [B*Ho*Wo][ldc]; epilogue as mve_gemm with rows_per_vec = Ho*Wo. */
 MVE_API int mve_conv3x3(int dtype, const void* d_x1, int C1, const void* d_x2, int C2, int B, int Hs, int Ws,
                         int stride, int upsample, const void* d_W, int Cout, void* d_out, int ldc,
                         const float* d_bias, const float* d_rowvec, int ldrv, const void* d_residual, int ldr,

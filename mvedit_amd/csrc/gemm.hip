@@ -5,24 +5,33 @@
 // A is either a dense row-major matrix (Linear / 1x1 conv over NHWC activations) or the im2col
 // view of an NHWC activation tensor gathered on the fly (3x3 conv, pad 1; stride 1 or 2; optional
 // nearest 2x upsample of the input; optional channel-concat of two inputs).  W is [N][K] row-major
-// ("B^T"), which is PyTorch's Linear layout and, for convs, [Cout][kh][kw][Cin].
+// ("B^T"), which is PyTorch's Linear layout and, for convs, [Cout][kh][kw][Cin] or the channel-chunk-major
+// [Cout][Cin/64][kh][kw][64] (MVE_CONV_W_CHUNK64): with the latter the nine taps of one 64-channel slab are
+// consecutive K tiles, so the 3x3 re-reads of an input pixel happen within nine tiles and stay in L1/L2
+// instead of being a full pass over the tile apart (rocprof FETCH_SIZE, profiles/r01_*).
 //
 // Work decomposition (all wave64):
 //   block tile 128 x BN (BN = 128 | 160 | 64) x 64, 256 threads = 4 waves in a 2x2 grid;
 //   each wave owns a 64 x BN/2 sub-tile = 4 x (BN/32) fragments of v_mfma_f32_16x16x32_{f16,bf16};
 //   the MFMA is issued "swapped" (W fragment as the A operand, activation fragment as B), so every
-//   lane ends up with 4 consecutive n for one m -- the epilogue then moves whole float4s;
+//   lane ends up with 4 consecutive n for one m and moves whole float4s into an fp32 LDS staging tile (two
+//   64-row passes); bias / time-embedding / residual / GEGLU are applied in fp32 on the way out and the global
+//   stores are full 16-byte row segments;
 //   LDS tiles are [rows][64] 16-bit with a 16-byte-chunk XOR swizzle chunk ^= (row>>1)&7 that makes
-//   the ds_read_b128 fragment reads conflict free; two LDS stages, global loads for tile k+1 are
-//   issued before the MFMAs of tile k and written to LDS after them (one barrier per K tile);
-//   the accumulator tile is staged through LDS in fp32 (two 64-row passes) so that bias / time-embedding
-//   / residual / GEGLU are applied in fp32 and the global stores are full 16-byte row segments.
+//   the ds_read_b128 fragment reads conflict free;
+//   staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, lane-linear destination): the
+//   swizzle is applied to the per-lane SOURCE chunk, zero padding (conv halo, K tail) is sourced from a
+//   16-byte zero page; tile k+1 is in flight while tile k feeds the MFMAs, one barrier per K tile;
 //   blockIdx -> tile uses the XCD-aware bijective remap so that tiles sharing an activation row panel
 //   run on one XCD (one L2).
+// A register-staged variant (global -> VGPR -> ds_write) is kept as variant 0
+// (MVE_GEMM_VARIANT=0) for A/B measurements.
 //
 // Replaces (behaviourally) the cuDNN/cuBLAS calls behind diffusers' ResnetBlock2D / Attention /
 // FeedForward as driven by lib/models/architecture/diffusers.py:57-164 of the reference.
 #include "common.h"
+
+#include <stdlib.h>
 
 namespace {
 
@@ -31,12 +40,18 @@ constexpr int BK = 64;           // elements
 constexpr int NT = 256;
 constexpr int ROW_BYTES = BK * 2;  // 128 B per tile row
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
 struct ConvGeom {
     // virtual input (after optional upsample) Hv x Wv, source tensors Hs x Ws
     int Hs, Ws, Hv, Wv, Ho, Wo;
     int C1, C2;        // channels of source 1 / source 2 (C2 = 0: no concat)
     int stride;        // 1 or 2
     int ups;           // 0 or 1 (nearest 2x)
+    int chunk64;       // 1: K order is (channel slab of 64, tap, channel in slab)
 };
 
 struct GemmParams {
@@ -45,7 +60,7 @@ struct GemmParams {
     const void* W;     // [N][K]
     void* out;         // [M][ldc] (or [M][ldc] with N/2 valid columns for GEGLU)
     const float* bias;       // [N] or null
-    const float* rowvec;     // [M/rows_per_vec][N] f32 (time embedding), or null
+    const float* rowvec;     // [M/rows_per_vec][ldrv] f32 (time embedding), or null
     const void* residual;    // [M][ldr] 16-bit or null
     int M, N, K;
     int lda, ldw, ldc, ldr, ldrv;   // row strides (elements) of A, W, out, residual, rowvec
@@ -60,21 +75,38 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES 
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <class Tag, int BN, int MODE>   // MODE 0: dense A, 1: conv3x3 gather
+// address of the 16-byte source chunk of im2col element (row = output pixel (cb,cy,cx), tap, channel `cin`)
+template <class T>
+__device__ __forceinline__ const T* conv_src(const GemmParams& p, int cb, int cy, int cx, int tap, int cin, bool kin) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int yi = cy + dy, xi = cx + dx;
+    const bool ok = kin && yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv;
+    if (!ok) return nullptr;
+    const bool second = cin >= p.g.C1;
+    const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
+    const int cs = second ? p.g.C2 : p.g.C1;
+    const int ch = second ? cin - p.g.C1 : cin;
+    const int ys = yi >> p.g.ups, xs = xi >> p.g.ups;
+    return src + (((size_t)cb * p.g.Hs + ys) * p.g.Ws + xs) * cs + ch;
+}
+
+template <class Tag, int BN, int MODE, int VARIANT>   // MODE 0: dense A, 1: conv3x3 gather; VARIANT 0: register staged, 1: LDS-DMA
 __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     constexpr int WN = BN / 2;          // wave sub-tile width
     constexpr int NF = WN / 16;         // W fragments per wave (4 / 5 / 2)
     constexpr int MF = 4;               // activation fragments per wave (64 rows)
-    constexpr int B_ROWS_PER_PASS = NT / 8;             // 32 rows per load pass
-    constexpr int A_PASSES = BM / B_ROWS_PER_PASS;      // 4
-    constexpr int B_PASSES = BN / B_ROWS_PER_PASS;      // 4 / 5 / 2
+    constexpr int ROWS_PER_PASS = NT / 8;               // 32 rows per load pass
+    constexpr int A_PASSES = BM / ROWS_PER_PASS;        // 4
+    constexpr int B_PASSES = BN / ROWS_PER_PASS;        // 4 / 5 / 2
     constexpr int A_STAGE = BM * ROW_BYTES;             // 16 KB
     constexpr int B_STAGE = BN * ROW_BYTES;
     constexpr int STAGE = A_STAGE + B_STAGE;
-    constexpr int CS_LD = BN + 4;                       // fp32 staging row stride (floats)
-    constexpr int SMEM = (2 * STAGE > 64 * CS_LD * 4) ? 2 * STAGE : 64 * CS_LD * 4;
+    constexpr int CS_LD = BN + 4;                       // fp32 staging row stride (floats), variant 0 only
+    constexpr int SMEM0 = (2 * STAGE > 64 * CS_LD * 4) ? 2 * STAGE : 64 * CS_LD * 4;
+    constexpr int SMEM = SMEM0;
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
+    typedef T T4 __attribute__((ext_vector_type(4)));
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
@@ -88,18 +120,18 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-thread load coordinates ------------------------------------------------------
-    const int lc = tid & 7;            // 16-byte chunk within the 128-byte K slice
     const int lr = tid >> 3;           // row within a 32-row pass
+    // variant 1 writes LDS lane-linearly, so the lane at physical chunk (tid&7) must FETCH the logical chunk that the
+    // swizzle maps there; (row>>1)&7 == (lr>>1)&7 for every pass because passes advance by 32 rows.
+    const int lc = VARIANT == 0 ? (tid & 7) : ((tid & 7) ^ ((lr >> 1) & 7));
     const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W);
 
-    // dense A
     const T* a_row[A_PASSES];
-    // conv A
     int cb[A_PASSES], cy[A_PASSES], cx[A_PASSES];
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
-            int m = m0 + lr + j * B_ROWS_PER_PASS;
+            int m = m0 + lr + j * ROWS_PER_PASS;
             m = m < p.M ? m : p.M - 1;
             a_row[j] = reinterpret_cast<const T*>(p.A) + (size_t)m * p.lda;
         }
@@ -107,7 +139,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
         const int hw = p.g.Ho * p.g.Wo;
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
-            int m = m0 + lr + j * B_ROWS_PER_PASS;
+            int m = m0 + lr + j * ROWS_PER_PASS;
             m = m < p.M ? m : p.M - 1;
             const int b = m / hw, r = m - b * hw;
             const int y = r / p.g.Wo;
@@ -119,65 +151,79 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     const T* w_row[B_PASSES];
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
-        int n = n0 + lr + j * B_ROWS_PER_PASS;
+        int n = n0 + lr + j * ROWS_PER_PASS;
         n = n < p.N ? n : p.N - 1;
         w_row[j] = Wp + (size_t)n * p.ldw;
     }
 
-    // conv: running (tap, cin) of this thread's chunk
+    // conv, tap-major K order: running (tap, cin) of this thread's chunk
     const int Ctot = p.g.C1 + p.g.C2;
     int tap = 0, cin = lc * 8;
     if constexpr (MODE == 1) {
-        while (cin >= Ctot) { cin -= Ctot; ++tap; }
-    }
-
-    u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + lc * 8;
-        const bool kin = k < p.K;
-        if constexpr (MODE == 0) {
-#pragma unroll
-            for (int j = 0; j < A_PASSES; ++j)
-                a_reg[j] = kin ? *reinterpret_cast<const u32x4*>(a_row[j] + k) : zero4;
-        } else {
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const bool second = cin >= p.g.C1;
-            const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
-            const int cs = second ? p.g.C2 : p.g.C1;
-            const int ch = second ? cin - p.g.C1 : cin;
-#pragma unroll
-            for (int j = 0; j < A_PASSES; ++j) {
-                const int yi = cy[j] + dy, xi = cx[j] + dx;
-                const bool ok = kin && yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv;
-                const int ys = yi >> p.g.ups, xs = xi >> p.g.ups;
-                const size_t off = (((size_t)cb[j] * p.g.Hs + ys) * p.g.Ws + xs) * cs + ch;
-                a_reg[j] = ok ? *reinterpret_cast<const u32x4*>(src + off) : zero4;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < B_PASSES; ++j)
-            b_reg[j] = kin ? *reinterpret_cast<const u32x4*>(w_row[j] + k) : zero4;
-        if constexpr (MODE == 1) {
-            cin += BK;
+        if (!p.g.chunk64)
             while (cin >= Ctot) { cin -= Ctot; ++tap; }
+    }
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+    // source pointers of this thread's chunks of K tile kt (nullptr = zero fill)
+    auto a_src = [&](int kt, int j, bool kin) -> const T* {
+        if constexpr (MODE == 0) {
+            return kin ? a_row[j] + kt * BK + lc * 8 : nullptr;
+        } else {
+            int t_ = tap, c_ = cin;
+            if (p.g.chunk64) { t_ = kt % 9; c_ = (kt / 9) * 64 + lc * 8; }
+            return conv_src<T>(p, cb[j], cy[j], cx[j], t_, c_, kin);
+        }
+    };
+    auto advance = [&]() {
+        if constexpr (MODE == 1) {
+            if (!p.g.chunk64) {
+                cin += BK;
+                while (cin >= Ctot) { cin -= Ctot; ++tap; }
+            }
         }
     };
 
-    auto store_tile = [&](int stage) {
+    // ---- staging ---------------------------------------------------------------------------------
+    u32x4 a_reg[A_PASSES], b_reg[B_PASSES];   // variant 0 only
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_tile = [&](int kt) {             // variant 0: global -> registers
+        const bool kin = kt * BK + lc * 8 < p.K;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            const T* s = a_src(kt, j, kin);
+            a_reg[j] = s ? *reinterpret_cast<const u32x4*>(s) : zero4;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j)
+            b_reg[j] = kin ? *reinterpret_cast<const u32x4*>(w_row[j] + kt * BK + lc * 8) : zero4;
+        advance();
+    };
+    auto store_tile = [&](int stage) {         // variant 0: registers -> LDS
+        unsigned char* As = smem + stage * STAGE;
+        unsigned char* Bs = As + A_STAGE;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) *reinterpret_cast<u32x4*>(As + swz(lr + j * ROWS_PER_PASS, lc)) = a_reg[j];
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<u32x4*>(Bs + swz(lr + j * ROWS_PER_PASS, lc)) = b_reg[j];
+    };
+    auto dma_tile = [&](int kt, int stage) {   // variant 1: global -> LDS directly, 1 KiB per wave instruction
+        const bool kin = kt * BK + lc * 8 < p.K;
         unsigned char* As = smem + stage * STAGE;
         unsigned char* Bs = As + A_STAGE;
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
-            const int row = lr + j * B_ROWS_PER_PASS;
-            *reinterpret_cast<u32x4*>(As + swz(row, lc)) = a_reg[j];
+            const T* s = a_src(kt, j, kin);
+            s = s ? s : zero;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
-            const int row = lr + j * B_ROWS_PER_PASS;
-            *reinterpret_cast<u32x4*>(Bs + swz(row, lc)) = b_reg[j];
+            const T* s = kin ? w_row[j] + kt * BK + lc * 8 : zero;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(Bs + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES), 16, 0, 0);
         }
+        advance();
     };
 
     f32x4 acc[NF][MF];
@@ -187,14 +233,17 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
         for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    if constexpr (VARIANT == 0) { load_tile(0); store_tile(0); }
+    else dma_tile(0, 0);
     __syncthreads();
 
     const int frow = lane & 15, fchunk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) {
+            if constexpr (VARIANT == 0) load_tile(kt + 1);
+            else dma_tile(kt + 1, cur ^ 1);
+        }
         const unsigned char* As = smem + cur * STAGE;
         const unsigned char* Bs = As + A_STAGE;
 #pragma unroll
@@ -211,85 +260,94 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf[j], xf[i], acc[j][i]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
+        if constexpr (VARIANT == 0) {
+            if (kt + 1 < nk) store_tile(cur ^ 1);
+        }
+        __syncthreads();   // variant 1: the compiler drains the in-flight LDS-DMA (vmcnt(0)) ahead of this barrier
     }
 
-    // ---- epilogue: two 64-row passes through an fp32 LDS tile -----------------------------------
-    float* Cs = reinterpret_cast<float*>(smem);
-    constexpr int CHUNKS = BN / 8;                 // 8-column chunks per row
-    constexpr int TASKS = 64 * CHUNKS;
+    {
+        // ---- epilogue: two 64-row passes through an fp32 LDS tile, 16-byte row-segment stores ----------------
+        // (measured: storing 8 bytes per lane straight from the accumulators was 10-20 % slower on the K = 320 GEMMs)
+        float* Cs = reinterpret_cast<float*>(smem);
+        constexpr int CHUNKS = BN / 8;                 // 8-column chunks per row
+        constexpr int TASKS = 64 * CHUNKS;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        if (wm == pass) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wm == pass) {
 #pragma unroll
-            for (int j = 0; j < NF; ++j)
+                for (int j = 0; j < NF; ++j)
 #pragma unroll
-                for (int i = 0; i < MF; ++i) {
-                    const int r = i * 16 + (lane & 15);
-                    const int c = wn * WN + j * 16 + (lane >> 4) * 4;
-                    *reinterpret_cast<f32x4*>(Cs + r * CS_LD + c) = acc[j][i];
+                    for (int i = 0; i < MF; ++i) {
+                        const int r = i * 16 + (lane & 15);
+                        const int c = wn * WN + j * 16 + (lane >> 4) * 4;
+                        *reinterpret_cast<f32x4*>(Cs + r * CS_LD + c) = acc[j][i];
+                    }
+            }
+            __syncthreads();
+            for (int task = tid; task < TASKS; task += NT) {
+                const int r = task / CHUNKS, ch = task - r * CHUNKS;
+                const int m = m0 + pass * 64 + r, n = n0 + ch * 8;
+                if (m >= p.M || n >= p.N) continue;      // N is a multiple of 8: whole chunk in or out
+                float v[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
                 }
+                if (p.rowvec) {
+                    const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.ldrv + n;
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if (p.geglu) {
+                    T4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = Tag::from_f32(v[2 * e] * gelu_erf(v[2 * e + 1]));
+                    *reinterpret_cast<T4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1)) = pk;
+                    continue;
+                }
+                if (p.residual) {
+                    const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+                if (p.out_f32) {
+                    float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+                    *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    V8 pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
+                    *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = pk;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int task = tid; task < TASKS; task += NT) {
-            const int r = task / CHUNKS, ch = task - r * CHUNKS;
-            const int m = m0 + pass * 64 + r, n = n0 + ch * 8;
-            if (m >= p.M || n >= p.N) continue;      // N is a multiple of 8: whole chunk in or out
-            float v[8];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-            if (p.bias) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-            }
-            if (p.rowvec) {
-                const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.ldrv + n;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-            }
-            if (p.geglu) {
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = v[2 * e] * gelu_erf(v[2 * e + 1]);
-                T* op = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1);
-                typedef T T4 __attribute__((ext_vector_type(4)));
-                T4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = Tag::from_f32(o[e]);
-                *reinterpret_cast<T4*>(op) = pk;
-                continue;
-            }
-            if (p.residual) {
-                const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-            if (p.out_f32) {
-                float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
-                *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
-                V8 pk;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
-                *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = pk;
-            }
-        }
-        __syncthreads();
     }
 }
 
-template <class Tag, int MODE>
-int launch_gemm(const GemmParams& p, hipStream_t s) {
+int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MVE_GEMM_VARIANT");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
+template <class Tag, int MODE, int VARIANT>
+int launch_v(const GemmParams& p, hipStream_t s) {
     // tile width: prefer the widest tile that divides N (no dead columns), else 128
     int bn = 128;
     if (p.N % 160 == 0) bn = 160;
@@ -297,11 +355,16 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     else if (p.N <= 64) bn = 64;
     const unsigned tiles_m = mve_cdiv(p.M, BM), tiles_n = mve_cdiv(p.N, bn);
     const unsigned grid = tiles_m * tiles_n;
-    if (bn == 160) k_gemm<Tag, 160, MODE><<<grid, NT, 0, s>>>(p);
-    else if (bn == 128) k_gemm<Tag, 128, MODE><<<grid, NT, 0, s>>>(p);
-    else k_gemm<Tag, 64, MODE><<<grid, NT, 0, s>>>(p);
+    if (bn == 160) k_gemm<Tag, 160, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
+    else if (bn == 128) k_gemm<Tag, 128, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
+    else k_gemm<Tag, 64, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
+}
+
+template <class Tag, int MODE>
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    return gemm_variant() == 0 ? launch_v<Tag, MODE, 0>(p, s) : launch_v<Tag, MODE, 1>(p, s);
 }
 
 int check_common(const GemmParams& p, const char* who) {
@@ -360,6 +423,9 @@ int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B
     p.g.Ho = (p.g.Hv + 2 - 3) / stride + 1;
     p.g.Wo = (p.g.Wv + 2 - 3) / stride + 1;
     p.g.C1 = C1; p.g.C2 = C2;
+    p.g.chunk64 = (flags & MVE_CONV_W_CHUNK64) ? 1 : 0;
+    MVE_CHECK(!p.g.chunk64 || (C1 % 64 == 0 && C2 % 64 == 0), MVE_ERR_ARG,
+              "conv3x3: MVE_CONV_W_CHUNK64 needs channel counts that are multiples of 64 (C1=%d C2=%d)", C1, C2);
     p.A = x1; p.A2 = x2; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
     p.M = B * p.g.Ho * p.g.Wo; p.N = Cout; p.K = 9 * (C1 + C2);
     p.ldc = ldc; p.ldr = ldr; p.ldrv = ldrv; p.ldw = p.K;

@@ -80,14 +80,21 @@ __global__ __launch_bounds__(GN_TX* GN_TY) void k_gn_partial(GNSrc s, int nsplit
 
 __global__ void k_gn_finalize(const float* __restrict__ partial, int B, int nsplit, int C, int G, int HW, float eps,
                               float* __restrict__ stats /* [B][G][2] mean, rstd */) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per (b, group): lanes stride over the nsplit*cpg partials, fixed-order xor-tree merge in fp64
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= B * G) return;
+    const int lane = threadIdx.x & 63;
     const int b = i / G, g = i - b * G, cpg = C / G;
     double a = 0.0, q = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) {
-        const float* p = partial + (((size_t)b * nsplit + sp) * C + (size_t)g * cpg) * 2;
-        for (int c = 0; c < cpg; ++c) { a += (double)p[2 * c]; q += (double)p[2 * c + 1]; }
+    for (int t = lane; t < nsplit * cpg; t += 64) {
+        const int sp = t / cpg, c = t - sp * cpg;
+        const float* p = partial + (((size_t)b * nsplit + sp) * C + (size_t)g * cpg + c) * 2;
+        a += (double)p[0];
+        q += (double)p[1];
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); q += __shfl_xor(q, d, 64); }
+    if (lane != 0) return;
     const double n = (double)cpg * HW;
     const double mean = a / n;
     double var = q / n - mean * mean;
@@ -208,7 +215,7 @@ int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* be
     dim3 grid(ns, ncg, s.B), block(GN_TX, GN_TY);
     k_gn_partial<Tag><<<grid, block, 0, st>>>(s, ns, partial);
     MVE_LAUNCH_CHECK();
-    k_gn_finalize<<<mve_cdiv(s.B * G, 128), 128, 0, st>>>(partial, s.B, ns, C, G, s.HW, eps, stats);
+    k_gn_finalize<<<mve_cdiv(s.B * G, 4), 256, 0, st>>>(partial, s.B, ns, C, G, s.HW, eps, stats);
     MVE_LAUNCH_CHECK();
     k_gn_apply<Tag><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
     MVE_LAUNCH_CHECK();

@@ -377,7 +377,10 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         MVE_CHECK(ndim == 4 && shape[0] == O && shape[1] == I && shape[2] == 3 && shape[3] == 3, MVE_ERR_ARG,
                   "load_param(%s): expected [%lld,%lld,3,3]", name.c_str(), O, I);
         (void)Opad;
-        d = PackDims{{O, 3, 3, Ipad}, {I * 9, 3, 1, 9}, {9 * Ipad, 3 * Ipad, Ipad, 1}, I};
+        if (I % 64 == 0 && Ipad == I)   // channel-slab-major K order [O][I/64][9][64] (MVE_CONV_W_CHUNK64)
+            d = PackDims{{O, I / 64, 9, 64}, {I * 9, 64 * 9, 1, 9}, {9 * I, 9 * 64, 64, 1}, 64};
+        else
+            d = PackDims{{O, 3, 3, Ipad}, {I * 9, 3, 1, 9}, {9 * Ipad, 3 * Ipad, Ipad, 1}, I};
         return pack(src_dtype, c.dtype, src, dstp(p, 0), d, s);
     };
     int rc = MVE_ERR_ARG;
@@ -518,9 +521,10 @@ struct Builder {
         const int Hv = ups ? 2 * H : H, Wv = ups ? 2 * W : W;
         const int Ho = (Hv - 1) / stride + 1, Wo = (Wv - 1) / stride + 1;
         live(x, what); live(out, what); live(res, what); live(rowvec, what);
+        const int fl = flags | (C1 % 64 == 0 ? MVE_CONV_W_CHUNK64 : 0);   // must mirror load_param's packing rule
         op(OC_CONV, 2.0 * Bn * Ho * Wo * (double)Cout * 9 * C1, what, [=](const Run& r) {
             return mve_conv3x3(d, r.p(x), C1, nullptr, 0, Bn, H, W, stride, ups, r.p(Wt), Cout, r.p(out), Cout,
-                               (const float*)r.p(bias), (const float*)r.p(rowvec), ldrv, r.p(res), Cout, flags, 1.0f, r.stream);
+                               (const float*)r.p(bias), (const float*)r.p(rowvec), ldrv, r.p(res), Cout, fl, 1.0f, r.stream);
         });
     }
     void gn(Ref x1, int C1, Ref x2, int C2, int Bn, int HW, float eps, Ref g, Ref b, int silu, Ref out, const char* what) {

@@ -9,6 +9,7 @@ from . import _lib
 
 GEGLU = 1
 OUT_F32 = 2
+W_CHUNK64 = 4
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.int32: 3, torch.uint8: 4}
 
@@ -47,12 +48,13 @@ def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, o
 
 def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec=None, residual=None, flags=0,
             out_scale=1.0):
-    """x1 [B*H*W, C1] (+ x2 [B*H*W, C2]) NHWC, w [Cout,3,3,C1+C2] -> ([B*Ho*Wo, Cout], Ho, Wo)."""
+    """x1 [B*H*W, C1] (+ x2 [B*H*W, C2]) NHWC, w [Cout,3,3,C1+C2] -> ([B*Ho*Wo, Cout], Ho, Wo).
+    With flags & W_CHUNK64 the weight is [Cout, (C1+C2)/64, 3, 3, 64] (see pack_conv_weight)."""
     _chk16(x1, x2, w, residual)
     C1 = x1.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
     Cout = w.shape[0]
-    assert w.shape[1:] == (3, 3, C1 + C2)
+    assert w.numel() == Cout * 9 * (C1 + C2)
     Hv, Wv = (H * 2, W * 2) if upsample else (H, W)
     Ho, Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
     out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32 if flags & OUT_F32 else x1.dtype, device=x1.device)
@@ -62,6 +64,16 @@ def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec
                   rowvec.stride(0) if rowvec is not None else 0, _lib.ptr(residual),
                   residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _s(x1))
     return out, Ho, Wo
+
+
+def pack_conv_weight(w_oihw, chunk64=None):
+    """torch conv weight [O, I, 3, 3] -> (packed weight, flag): [O,3,3,I], or [O, I/64, 3, 3, 64] when I % 64 == 0."""
+    O, I = w_oihw.shape[:2]
+    if chunk64 is None:
+        chunk64 = I % 64 == 0
+    if chunk64:
+        return w_oihw.reshape(O, I // 64, 64, 3, 3).permute(0, 1, 3, 4, 2).contiguous(), W_CHUNK64
+    return w_oihw.permute(0, 2, 3, 1).contiguous(), 0
 
 
 def groupnorm(x1, B, HW, gamma, beta, G=32, eps=1e-5, silu=True, x2=None):

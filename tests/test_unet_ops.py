@@ -114,11 +114,13 @@ def test_conv3x3(lib, dtype, B, H, W, C1, C2, Cout, stride, ups):
     bias = rnd((Cout,), torch.float32, 4)
     xin = torch.cat([x1, x2], 1) if C2 else x1
     ref = conv_ref(xin, w, bias, stride, ups)
-    w_k = w.permute(0, 2, 3, 1).contiguous()            # [Cout][kh][kw][Cin]
-    out, Ho, Wo = ops.conv3x3(to_nhwc(x1).cuda(), w_k.cuda(), B, H, W, x2=to_nhwc(x2).cuda() if C2 else None,
-                              stride=stride, upsample=ups, bias=bias.cuda())
-    assert (Ho, Wo) == tuple(ref.shape[2:])
-    check('conv3x3', out, to_nhwc(ref), dtype, f'{(B, H, W, C1, C2, Cout, stride, ups)}')
+    layouts = [False, True] if (C1 % 64 == 0 and C2 % 64 == 0) else [False]
+    for chunk64 in layouts:      # [Cout][kh][kw][Cin]  and  [Cout][Cin/64][kh][kw][64]
+        w_k, wflag = ops.pack_conv_weight(w, chunk64)
+        out, Ho, Wo = ops.conv3x3(to_nhwc(x1).cuda(), w_k.cuda(), B, H, W, x2=to_nhwc(x2).cuda() if C2 else None,
+                                  stride=stride, upsample=ups, bias=bias.cuda(), flags=wflag)
+        assert (Ho, Wo) == tuple(ref.shape[2:])
+        check('conv3x3', out, to_nhwc(ref), dtype, f'{(B, H, W, C1, C2, Cout, stride, ups)} chunk64={chunk64}')
 
 
 def test_conv3x3_resblock_epilogue(lib):
@@ -131,8 +133,9 @@ def test_conv3x3_resblock_epilogue(lib):
     bias, temb = rnd((C,), torch.float32, 3), rnd((B, C), torch.float32, 4)
     res = rnd((B, C, H, W), dtype, 5)
     ref = conv_ref(x, w, bias) + temb[:, :, None, None] + res.float()
-    out, _, _ = ops.conv3x3(to_nhwc(x).cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), B, H, W, bias=bias.cuda(),
-                            rowvec=temb.cuda(), residual=to_nhwc(res).cuda())
+    w_k, wflag = ops.pack_conv_weight(w)
+    out, _, _ = ops.conv3x3(to_nhwc(x).cuda(), w_k.cuda(), B, H, W, bias=bias.cuda(), rowvec=temb.cuda(),
+                            residual=to_nhwc(res).cuda(), flags=wflag)
     check('conv3x3 resblock epilogue', out, to_nhwc(ref), dtype)
 
 

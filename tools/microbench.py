@@ -37,8 +37,8 @@ def main():
     for (B, H, C1, Cout) in [(32, 64, 320, 320), (32, 32, 640, 640), (32, 16, 1280, 1280), (32, 8, 1280, 1280), (32, 16, 2560, 1280),
                              (32, 64, 960, 320), (8, 64, 320, 320), (8, 8, 1280, 1280)]:
         x = torch.randn(B * H * H, C1, device=dev, dtype=dt)
-        w = torch.randn(Cout, 3, 3, C1, device=dev, dtype=dt)
-        t = timeit(lambda: ops.conv3x3(x, w, B, H, H))
+        w = torch.randn(Cout, C1 // 64, 3, 3, 64, device=dev, dtype=dt)
+        t = timeit(lambda: ops.conv3x3(x, w, B, H, H, flags=ops.W_CHUNK64))
         res.append(dict(op='conv3x3', B=B, H=H, Cin=C1, Cout=Cout, ms=t * 1e3, tflops=2 * B * H * H * Cout * 9 * C1 / t / 1e12))
         print(res[-1], flush=True)
     for (B, L, heads, d) in [(16, 4096, 8, 40), (16, 1024, 8, 80), (16, 256, 8, 160), (8, 8192, 8, 40)]:
