@@ -28,6 +28,9 @@
 //   LDS images use 16-byte-chunk XOR swizzles so the ds_read_b128 fragment reads are (near) conflict free.
 #include "common.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace {
 
 constexpr int QB = 128;      // query rows per block
@@ -282,10 +285,331 @@ __global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention(const AttnPa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Variant 2 (default).  Same math and fragment conventions as k_attention above; what changes is the pipeline:
+//   * LDS is filled 128 keys at a time (64 for d = 160) and consumed as 64-key halves: ONE barrier per fill;
+//   * K tiles arrive by LDS-DMA (global_load_lds_dwordx4, swizzle applied to the source chunk, pad chunks and
+//     out-of-range keys sourced from a zero page) into a double buffer, issued a whole tile ahead;
+//   * V^T is double buffered too: its global loads are issued at the top of the tile, transposed into the
+//     other buffer after the MFMAs, so nothing waits on HBM inside a tile;
+//   * the running-max rescale of O is skipped (wave-uniform branch) whenever no query's maximum grew -- exact,
+//     not a thresholded approximation; after the first few tiles that is almost always;
+//   * P is rounded to the storage dtype with packed converts (v_cvt_pk_{f16,bf16}_f32);
+//   * VALU diet (rocprofv3: the first version issued 8.7 VALU per MFMA and was VALU-issue bound): every LDS address
+//     and DMA slot is a lane constant computed once; the key mask lives in a separately compiled half; for d = 40
+//     a row of ones in the spare rows of the last V^T fragment makes the PV MFMA accumulate the softmax denominator.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_attn_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <int KB2> __device__ __forceinline__ int v_swz2(int row, int chunk) {
+    if constexpr (KB2 == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);   // 256-byte rows: every row starts on bank 0
+    else return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <class Tag, int D, bool SEG2>
+__global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnParams p) {
+    constexpr int DP = (D + 31) / 32 * 32;
+    constexpr int KS = DP / 32;
+    constexpr int DC = D / 8;
+    constexpr int DVF = (D + 15) / 16;
+    constexpr int KB2 = D > 64 ? 64 : 128;       // keys per LDS fill (LDS budget: 2 blocks/CU for d = 80)
+    constexpr int NH = KB2 / 64;                 // 64-key halves per fill
+    constexpr int CPR = DP / 8;                  // 16-byte chunks per K row
+    constexpr int KROW = DP * 2;                 // bytes per K row
+    constexpr int VROW = KB2 * 2;                // bytes per V^T row
+    constexpr int K_BYTES = KB2 * KROW;
+    constexpr int V_BYTES = DVF * 16 * VROW;
+    constexpr int K_INSTR = K_BYTES / 1024 / 4;  // LDS-DMA instructions per wave per fill (1 KiB each)
+    static_assert((K_BYTES / 1024) % 4 == 0, "K tile must split evenly over 4 waves");
+    constexpr int V_TASKS = (KB2 / 2) * DC;
+    constexpr int V_PER_T = (V_TASKS + NT - 1) / NT;
+    // When D is not a multiple of 16 the last V^T fragment has spare rows: row D is set to all ones, so the PV MFMA
+    // itself produces l = sum_j P (rounded exactly like the numerator) and the 32 adds per half disappear.
+    constexpr bool ONES = (D % 16) != 0;
+    constexpr int L_G = (D % 16) / 4, L_R = (D % 16) % 4;
+    typedef typename Tag::V8 V8;
+    typedef typename Tag::T T;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * K_BYTES + 2 * V_BYTES];
+    unsigned char* Kbuf = smem;
+    unsigned char* Vbuf = smem + 2 * K_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+
+    const int q_tiles = (p.Lq + QB - 1) / QB;
+    const unsigned nblk = (unsigned)(q_tiles * p.heads * p.B);
+    const unsigned bid = mve_xcd_remap(blockIdx.x, nblk);
+    const int qt = bid % q_tiles;
+    const int h = (bid / q_tiles) % p.heads;
+    const int b = bid / (q_tiles * p.heads);
+    const int Ltot = p.Lk + p.Lk2;
+
+    const T* Qp = reinterpret_cast<const T*>(p.Q);
+    const T* zero = reinterpret_cast<const T*>(g_attn_zero_page);
+    // per-(batch, head) bases; key j of segment 1 lives at kb1 + j*ldk
+    const T* kb1 = reinterpret_cast<const T*>(p.K) + (size_t)b * p.Lk * p.ldk + h * D;
+    const T* vb1 = reinterpret_cast<const T*>(p.V) + (size_t)b * p.Lk * p.ldv + h * D;
+    const T* kb2 = SEG2 ? reinterpret_cast<const T*>(p.K2) + (size_t)b * p.Lk2 * p.ldk2 + h * D : nullptr;
+    const T* vb2 = SEG2 ? reinterpret_cast<const T*>(p.V2) + (size_t)b * p.Lk2 * p.ldv2 + h * D : nullptr;
+    auto k_row = [&](int j) -> const T* {       // j already clamped to [0, Ltot)
+        if constexpr (SEG2) { if (j >= p.Lk) return kb2 + (size_t)(j - p.Lk) * p.ldk2; }
+        return kb1 + (size_t)j * p.ldk;
+    };
+    auto v_row = [&](int j) -> const T* {
+        if constexpr (SEG2) { if (j >= p.Lk) return vb2 + (size_t)(j - p.Lk) * p.ldv2; }
+        return vb1 + (size_t)j * p.ldv;
+    };
+
+    // V^T buffers: zero (rows dv >= D contribute nothing), then the all-ones row that accumulates l
+    for (int i = tid; i < 2 * V_BYTES / 16; i += NT) reinterpret_cast<u32x4*>(Vbuf)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if constexpr (ONES) {
+        const unsigned short one = __builtin_bit_cast(unsigned short, Tag::from_f32(1.0f));
+        const unsigned two = (unsigned)one | ((unsigned)one << 16);
+        for (int i = tid; i < 2 * (VROW / 4); i += NT) {
+            const int buf = i / (VROW / 4), wofs = i - buf * (VROW / 4);
+            *reinterpret_cast<unsigned*>(Vbuf + buf * V_BYTES + D * VROW + wofs * 4) = two;   // whole row: swizzle only permutes it
+        }
+    }
+
+    V8 qf[2][KS];
+    const int q_base = qt * QB + wid * 32;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        int q = q_base + f * 16 + l16;
+        q = q < p.Lq ? q : p.Lq - 1;
+        const T* row = Qp + ((size_t)b * p.Lq + q) * p.ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 4 + g;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (c < DC) v = *reinterpret_cast<const u32x4*>(row + c * 8);
+            qf[f][ks] = __builtin_bit_cast(V8, v);
+        }
+    }
+
+    // ---- lane constants: LDS-DMA slots of the K tile, V^T staging tasks, fragment read offsets -----------------
+    int kd_row[K_INSTR], kd_col[K_INSTR];        // key row inside the tile, element offset of the logical chunk (-1: pad)
+#pragma unroll
+    for (int i = 0; i < K_INSTR; ++i) {
+        const int pos = (wid * K_INSTR + i) * 64 + lane;
+        const int row = pos / CPR, pc = pos - row * CPR;
+        const int c = (DP == 64) ? (pc ^ ((row >> 1) & 7)) : (pc ^ ((row >> 2) & 3));
+        kd_row[i] = row;
+        kd_col[i] = c < DC ? c * 8 : -1;
+    }
+    int vt_key[V_PER_T], vt_col[V_PER_T], vt_lds[V_PER_T];
+#pragma unroll
+    for (int i = 0; i < V_PER_T; ++i) {
+        const int task = tid + i * NT;
+        const int pair = task / DC, c = task - pair * DC;
+        const int key = 2 * pair;                 // key = 32*kk + 16*hh + 4*gg + jj  ->  slot 32*kk + 8*gg + 4*hh + jj
+        const int kk = key >> 5, hh = (key >> 4) & 1, gg = (key >> 2) & 3, jj = key & 3;
+        const int pos = 32 * kk + 8 * gg + 4 * hh + jj;
+        vt_key[i] = task < V_TASKS ? key : -1;
+        vt_col[i] = c * 8;
+        vt_lds[i] = ((pos >> 3) << 16) | ((pos & 7) * 2);   // (chunk, byte offset inside the chunk)
+    }
+    // K fragment (A operand) of key fragment kf, k-step ks, half hf:  koff[ks] + (hf*64 + kf*16) * KROW
+    // the swizzle term depends on (row>>1)&7 resp. (row>>2)&3, which equals the lane's own l16 term because the
+    // fragment row offsets are multiples of 16.
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = k_swz<DP>(l16, ks * 4 + g);
+    // V^T fragment (A operand) of dv fragment i, key step (hf, kk):  voff[hf*2+kk] + i*16*VROW
+    int voff[NH * 2];
+#pragma unroll
+    for (int s2 = 0; s2 < NH * 2; ++s2) voff[s2] = v_swz2<KB2>(l16, s2 * 4 + g);
+
+    auto dma_k = [&](int t, int buf) {
+        const int j0 = t * KB2;
+#pragma unroll
+        for (int i = 0; i < K_INSTR; ++i) {
+            int j = j0 + kd_row[i];
+            j = j < Ltot ? j : Ltot - 1;                       // clamped rows hold finite data; their scores are masked
+            const T* src = kd_col[i] >= 0 ? k_row(j) + kd_col[i] : zero;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Kbuf + buf * K_BYTES + (wid * K_INSTR + i) * 1024), 16, 0, 0);
+        }
+    };
+    u32x4 vreg[V_PER_T][2];
+    auto load_v = [&](int t) {
+        const int j0 = t * KB2;
+#pragma unroll
+        for (int i = 0; i < V_PER_T; ++i) {
+            if (vt_key[i] >= 0) {
+                int j = j0 + vt_key[i];
+                const int ja = j < Ltot ? j : Ltot - 1, jb = j + 1 < Ltot ? j + 1 : Ltot - 1;
+                vreg[i][0] = *reinterpret_cast<const u32x4*>(v_row(ja) + vt_col[i]);
+                vreg[i][1] = *reinterpret_cast<const u32x4*>(v_row(jb) + vt_col[i]);
+            }
+        }
+    };
+    auto store_v = [&](int buf) {
+        unsigned char* Vs = Vbuf + buf * V_BYTES;
+#pragma unroll
+        for (int i = 0; i < V_PER_T; ++i) {
+            if (vt_key[i] >= 0) {
+                const int chunk = vt_lds[i] >> 16, within = vt_lds[i] & 0xffff;
+                const unsigned short* a = reinterpret_cast<const unsigned short*>(&vreg[i][0]);
+                const unsigned short* bb = reinterpret_cast<const unsigned short*>(&vreg[i][1]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<unsigned*>(Vs + v_swz2<KB2>(vt_col[i] + e, chunk) + within) = (unsigned)a[e] | ((unsigned)bb[e] << 16);
+            }
+        }
+    };
+
+    f32x4 oacc[DVF][2];
+#pragma unroll
+    for (int i = 0; i < DVF; ++i) { oacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    // one 64-key half: S^T = K Q^T, online softmax, O^T += V^T P^T.  MASKED is compiled separately so that the common
+    // path carries no select instructions (the compiler if-converts a runtime test into 48 v_cndmask per half).
+    auto do_half = [&](const unsigned char* Ks, const unsigned char* Vs, int hf, int key0, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        f32x4 s[4][2];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) { s[kf][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kf][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const V8 ka = *reinterpret_cast<const V8*>(Ks + koff[ks] + (hf * 64 + kf * 16) * KROW);
+                s[kf][0] = Tag::mfma16(ka, qf[0][ks], s[kf][0]);
+                s[kf][1] = Tag::mfma16(ka, qf[1][ks], s[kf][1]);
+            }
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key0 + kf * 16 + g * 4 + r >= Ltot) { s[kf][0][r] = -INFINITY; s[kf][1][r] = -INFINITY; }
+        }
+        V8 pf[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kf][f][r]);
+            mx = mve_max_xor32(mve_max_xor16(mx));
+            const float mxs = mx * p.scale_log2e;
+            if (__any(mxs > m_run[f])) {                  // some query's running maximum grows: rescale (exact)
+                const float m_new = fmaxf(m_run[f], mxs);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+                m_run[f] = m_new;
+                if constexpr (!ONES) l_run[f] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DVF; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[i][f][r] *= alpha;
+            }
+            const float mr = m_run[f];
+            float psum = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                f32x8 e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = __builtin_amdgcn_exp2f(s[2 * kk][f][r] * p.scale_log2e - mr);
+                    e[4 + r] = __builtin_amdgcn_exp2f(s[2 * kk + 1][f][r] * p.scale_log2e - mr);
+                }
+                if constexpr (!ONES) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) psum += e[r];
+                }
+                pf[f][kk] = __builtin_convertvector(e, V8);
+            }
+            if constexpr (!ONES) l_run[f] += psum;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < DVF; ++i) {
+                const V8 va = *reinterpret_cast<const V8*>(Vs + voff[hf * 2 + kk] + i * 16 * VROW);
+                oacc[i][0] = Tag::mfma16(va, pf[0][kk], oacc[i][0]);
+                oacc[i][1] = Tag::mfma16(va, pf[1][kk], oacc[i][1]);
+            }
+        }
+    };
+
+    const int n_tiles = (Ltot + KB2 - 1) / KB2;
+    dma_k(0, 0);
+    load_v(0);
+    __syncthreads();          // V^T zero / ones fill complete
+    store_v(0);
+    __syncthreads();          // tile 0 visible (the barrier drains the LDS-DMA)
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < n_tiles) { dma_k(t + 1, cur ^ 1); load_v(t + 1); }
+        const unsigned char* Ks = Kbuf + cur * K_BYTES;
+        const unsigned char* Vs = Vbuf + cur * V_BYTES;
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const int key0 = t * KB2 + hf * 64;
+            if (key0 + 64 <= Ltot) {
+                do_half(Ks, Vs, hf, key0, std::false_type{});
+            } else if (key0 < Ltot) {
+                do_half(Ks, Vs, hf, key0, std::true_type{});
+            }
+        }
+        if (t + 1 < n_tiles) store_v(cur ^ 1);
+        __syncthreads();
+    }
+
+    typedef T T4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        float l;
+        if constexpr (ONES) {
+            l = __shfl(oacc[DVF - 1][f][L_R], L_G * 16 + l16, 64);    // row D of O^T is sum_j P for query l16
+        } else {
+            l = l_run[f];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
+        const float inv = 1.0f / l;
+        const int q = q_base + f * 16 + l16;
+        if (q < p.Lq) {
+            T* orow = reinterpret_cast<T*>(p.O) + ((size_t)b * p.Lq + q) * p.ldo + h * D;
+#pragma unroll
+            for (int i = 0; i < DVF; ++i) {
+                const int dv = i * 16 + g * 4;
+                if (dv < D) {
+                    T4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[r] = Tag::from_f32(oacc[i][f][r] * inv);
+                    *reinterpret_cast<T4*>(orow + dv) = pk;
+                }
+            }
+        }
+    }
+}
+
+int attn_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MVE_ATTN_VARIANT");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
+
 template <class Tag, int D>
 int launch(const AttnParams& p, hipStream_t s) {
     const unsigned grid = (unsigned)(((p.Lq + QB - 1) / QB) * p.heads * p.B);
-    k_attention<Tag, D><<<grid, NT, 0, s>>>(p);
+    if (attn_variant() == 1) k_attention<Tag, D><<<grid, NT, 0, s>>>(p);
+    else if (p.Lk2 > 0) k_attention2<Tag, D, true><<<grid, NT, 0, s>>>(p);
+    else k_attention2<Tag, D, false><<<grid, NT, 0, s>>>(p);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

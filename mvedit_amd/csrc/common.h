@@ -101,6 +101,17 @@ struct BF16Tag {
      : (dtype) == MVE_BF16 ? FN<BF16Tag>(__VA_ARGS__)                  \
                            : (mve_set_error("unsupported dtype %d", (int)(dtype)), MVE_ERR_ARG))
 
+// max over lanes {l, l^16} / {l, l^32} with gfx950's VALU half-row swaps (v_permlane16_swap / v_permlane32_swap)
+// instead of ds_bpermute: no LDS round trip in the middle of a softmax dependency chain.
+__device__ __forceinline__ float mve_max_xor16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float mve_max_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // XCD-aware bijective block remap (MI355X: 8 XCDs, block b lands on XCD b%8).
 // Consecutive *logical* tiles share operand panels; give each XCD a contiguous
 // chunk of the logical grid so those panels hit one L2.
