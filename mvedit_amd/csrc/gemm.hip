@@ -33,62 +33,16 @@
 
 #include <stdlib.h>
 
+#include "gemm_shared.h"
+
 namespace {
 
 constexpr int BM = 128;
-constexpr int BK = 64;           // elements
-constexpr int NT = 256;
-constexpr int ROW_BYTES = BK * 2;  // 128 B per tile row
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
-
-struct ConvGeom {
-    // virtual input (after optional upsample) Hv x Wv, source tensors Hs x Ws
-    int Hs, Ws, Hv, Wv, Ho, Wo;
-    int C1, C2;        // channels of source 1 / source 2 (C2 = 0: no concat)
-    int stride;        // 1 or 2
-    int ups;           // 0 or 1 (nearest 2x)
-    int chunk64;       // 1: K order is (channel slab of 64, tap, channel in slab)
-};
-
-struct GemmParams {
-    const void* A;     // dense A [M][lda]  or conv source 1 (NHWC)
-    const void* A2;    // conv source 2 (concat) or null
-    const void* W;     // [N][K]
-    void* out;         // [M][ldc] (or [M][ldc] with N/2 valid columns for GEGLU)
-    const float* bias;       // [N] or null
-    const float* rowvec;     // [M/rows_per_vec][ldrv] f32 (time embedding), or null
-    const void* residual;    // [M][ldr] 16-bit or null
-    int M, N, K;
-    int lda, ldw, ldc, ldr, ldrv;   // row strides (elements) of A, W, out, residual, rowvec
-    int rows_per_vec;
-    int geglu;         // 1: out[m][i] = v[2i] * gelu(v[2i+1])
-    int out_f32;       // 1: out is float
-    float out_scale;   // multiplies the final value (1/output_scale_factor)
-    ConvGeom g;
-};
-
-__device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// address of the 16-byte source chunk of im2col element (row = output pixel (cb,cy,cx), tap, channel `cin`)
-template <class T>
-__device__ __forceinline__ const T* conv_src(const GemmParams& p, int cb, int cy, int cx, int tap, int cin, bool kin) {
-    const int dy = tap / 3, dx = tap - dy * 3;
-    const int yi = cy + dy, xi = cx + dx;
-    const bool ok = kin && yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv;
-    if (!ok) return nullptr;
-    const bool second = cin >= p.g.C1;
-    const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
-    const int cs = second ? p.g.C2 : p.g.C1;
-    const int ch = second ? cin - p.g.C1 : cin;
-    const int ys = yi >> p.g.ups, xs = xi >> p.g.ups;
-    return src + (((size_t)cb * p.g.Hs + ys) * p.g.Ws + xs) * cs + ch;
-}
+// defined in gemm_rs.hip (variant 2: role-split 256-row tiles)
+}  // namespace
+int mve_gemm_rs_launch(int dtype, int mode, const void* params, void* stream);
+namespace {
 
 template <class Tag, int BN, int MODE, int VARIANT>   // MODE 0: dense A, 1: conv3x3 gather; VARIANT 0: register staged, 1: LDS-DMA
 __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
@@ -341,7 +295,7 @@ int gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MVE_GEMM_VARIANT");
-        v = (e && e[0] == '0') ? 0 : 1;
+        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     }
     return v;
 }
@@ -364,7 +318,9 @@ int launch_v(const GemmParams& p, hipStream_t s) {
 
 template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
-    return gemm_variant() == 0 ? launch_v<Tag, MODE, 0>(p, s) : launch_v<Tag, MODE, 1>(p, s);
+    const int v = gemm_variant();
+    if (v == 2 && p.M >= 256 && p.N >= 64) return mve_gemm_rs_launch(Tag::dtype, MODE, &p, s);
+    return v == 0 ? launch_v<Tag, MODE, 0>(p, s) : launch_v<Tag, MODE, 1>(p, s);
 }
 
 int check_common(const GemmParams& p, const char* who) {

@@ -1,0 +1,63 @@
+// Definitions shared by the GEMM / implicit-GEMM conv kernels (gemm.hip: 128-row tiles; gemm_rs.hip: role-split
+// 256-row tiles).  Everything is in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;           // elements
+constexpr int NT = 256;
+constexpr int ROW_BYTES = BK * 2;  // 128 B per tile row
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+struct ConvGeom {
+    // virtual input (after optional upsample) Hv x Wv, source tensors Hs x Ws
+    int Hs, Ws, Hv, Wv, Ho, Wo;
+    int C1, C2;        // channels of source 1 / source 2 (C2 = 0: no concat)
+    int stride;        // 1 or 2
+    int ups;           // 0 or 1 (nearest 2x)
+    int chunk64;       // 1: K order is (channel slab of 64, tap, channel in slab)
+};
+
+struct GemmParams {
+    const void* A;     // dense A [M][lda]  or conv source 1 (NHWC)
+    const void* A2;    // conv source 2 (concat) or null
+    const void* W;     // [N][K]
+    void* out;         // [M][ldc] (or [M][ldc] with N/2 valid columns for GEGLU)
+    const float* bias;       // [N] or null
+    const float* rowvec;     // [M/rows_per_vec][ldrv] f32 (time embedding), or null
+    const void* residual;    // [M][ldr] 16-bit or null
+    int M, N, K;
+    int lda, ldw, ldc, ldr, ldrv;   // row strides (elements) of A, W, out, residual, rowvec
+    int rows_per_vec;
+    int geglu;         // 1: out[m][i] = v[2i] * gelu(v[2i+1])
+    int out_f32;       // 1: out is float
+    float out_scale;   // multiplies the final value (1/output_scale_factor)
+    ConvGeom g;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// address of the 16-byte source chunk of im2col element (row = output pixel (cb,cy,cx), tap, channel `cin`)
+template <class T>
+__device__ __forceinline__ const T* conv_src(const GemmParams& p, int cb, int cy, int cx, int tap, int cin, bool kin) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int yi = cy + dy, xi = cx + dx;
+    const bool ok = kin && yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv;
+    if (!ok) return nullptr;
+    const bool second = cin >= p.g.C1;
+    const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
+    const int cs = second ? p.g.C2 : p.g.C1;
+    const int ch = second ? cin - p.g.C1 : cin;
+    const int ys = yi >> p.g.ups, xs = xi >> p.g.ups;
+    return src + (((size_t)cb * p.g.Hs + ys) * p.g.Ws + xs) * cs + ch;
+}
+
+
+}  // namespace
