@@ -241,6 +241,49 @@ MVE_API int mve_unet_forward(void* handle, int phase, const void* d_sample, int 
 /* op i of the cached plan: class, flops, label; returns 1 if the op belongs to unet_enc, 2 for unet_dec */
 MVE_API int mve_unet_op_info(void* handle, int i, int* cls, double* flops, char* label, int label_len);
 
+/* =========================================================================
+ * 4. NeRF render path (float32 throughout, as in the reference).
+ * ========================================================================= */
+
+/* iNGPDecoder.point_decode (lib/models/decoders/ingp_decoder.py:106-120): tinycudann HashGrid (Smoothstep, 2 features
+ * per level, log2_hashmap_size 19) -> MLP(2L -> hidden -> 4, ReLU) -> sigma = exp(h0 + blob(x)), rgb = sigmoid(h1..3)*(1+2s)-s.
+ * level_* are HOST arrays [n_levels] (scale, resolution, row offset, row count per level; see oracle/nerf_oracle.py:grid_meta
+ * for tiny-cuda-nn's formulas); d_table: [rows][2] f32; d_w1: [hidden][2L], d_w2: [4][hidden] (torch Linear layout).
+ * d_rgbs may be NULL (point_density_decode). n_levels in {12, 14, 16}. */
+MVE_API int mve_hashgrid_mlp_decode(const float* d_xyz, uint32_t M, const float* d_table, int n_levels,
+                                    const float* level_scale, const uint32_t* level_res, const uint32_t* level_offset,
+                                    const uint32_t* level_size, const float* d_w1, const float* d_b1, const float* d_w2,
+                                    const float* d_b2, int hidden, float bound, float blob_density, float blob_radius,
+                                    float sigmoid_saturation, float* d_sigmas, float* d_rgbs, void* stream);
+
+/* VolumeRenderer.forward, eval branch (lib/models/decoders/base_volume_renderer.py:264-329) as ONE launch:
+ * near/far from the aabb, occupancy-grid march (cascade count 1, no contraction, noise 0), hash-grid + MLP decode and
+ * compositing per ray, with the reference's termination rules.  Outputs [N], [N], [N,3]; d_n_samples [N] optional. */
+MVE_API int mve_nerf_render_rays(const float* d_rays_o, const float* d_rays_d, uint32_t N, const uint8_t* d_bitfield,
+                                 uint32_t grid_size, const float* d_aabb, float bound, float min_near, float dt_gamma,
+                                 uint32_t max_steps, float T_thresh, const float* d_table, int n_levels,
+                                 const float* level_scale, const uint32_t* level_res, const uint32_t* level_offset,
+                                 const uint32_t* level_size, const float* d_w1, const float* d_b1, const float* d_w2,
+                                 const float* d_b2, int hidden, float blob_density, float blob_radius,
+                                 float sigmoid_saturation, float* d_weights_sum, float* d_depth, float* d_image,
+                                 int32_t* d_n_samples, void* stream);
+
+/* get_ray_directions + get_rays(norm=True) (lib/core/utils/geometry_utils.py:18-55): intrinsics [V,4] (fx,fy,cx,cy),
+ * poses [V,3,4] c2w -> rays_o, rays_d [V*h*w,3]; d_dir_norm [V*h*w] = |camera-space direction| (1/r -> 1/z factor), optional. */
+MVE_API int mve_camera_rays(const float* d_intrinsics, const float* d_poses, int n_views, int h, int w, float* d_rays_o,
+                            float* d_rays_d, float* d_dir_norm, void* stream);
+
+/* depth_to_normal (geometry_utils.py:119-148, format 'opengl') fused with the tail of BaseNeRF.render
+ * (lib/models/autoencoders/base_nerf.py:549-553): depth is 1/z; with d_alpha (element stride alpha_stride) the depth is
+ * first divided by clamp(alpha,1e-6) and d_normal = normal_fg*alpha + normal_bg*(1-alpha).  normal_bg3: host [3] or NULL. */
+MVE_API int mve_depth_to_normal(const float* d_depth, const float* d_alpha, int alpha_stride, const float* d_intrinsics,
+                                int n_views, int h, int w, const float* normal_bg3, float* d_normal_fg, float* d_normal,
+                                void* stream);
+
+/* normalize_depth (geometry_utils.py:151-168): depths, alphas [V][hw] -> out [V][hw] */
+MVE_API int mve_normalize_depth(const float* d_depths, const float* d_alphas, int n_views, int hw, float far_depth,
+                                float alpha_clip, float eps, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,7 @@ COMMON_FLAGS = [
 # index buffers are compared bit-for-bit with the C oracle.
 EXTRA_FLAGS = {
     'raymarching.hip': ['-ffp-contract=off'],
+    'nerf.hip': ['-ffp-contract=off'],
     'raster.hip': ['-ffp-contract=off'],
 }
 

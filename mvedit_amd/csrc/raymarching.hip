@@ -15,41 +15,11 @@
 // file is compiled with -ffp-contract=off so that index buffers (ray offsets,
 // counts, Morton codes, bitfields) and marched positions are bit-exact against
 // oracle/raymarching_oracle.c.
-#include "common.h"
-#include <float.h>
+#include "raymarch_core.h"
 
 namespace {
 
 constexpr int kBlock = 256;              // 4 waves
-constexpr float kSqrt3 = 1.7320508075688772f;
-
-// ---------------------------------------------------------------------------
-// integer helpers (bit exact)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {
-    // 10 low bits of v -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
-__device__ __forceinline__ uint32_t morton_encode(uint32_t x, uint32_t y, uint32_t z) {
-    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
-}
-__device__ __forceinline__ uint32_t gather3(uint32_t x) {
-    x &= 0x49249249u;
-    x = (x | (x >> 2)) & 0xC30C30C3u;
-    x = (x | (x >> 4)) & 0x0F00F00Fu;
-    x = (x | (x >> 8)) & 0xFF0000FFu;
-    x = (x | (x >> 16)) & 0x0000FFFFu;
-    return x;
-}
-
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
-
-struct float3p { float x, y, z; };   // 12-byte packed load/store (one dwordx3 per lane)
-struct float2p { float x, y; };
 
 // ---------------------------------------------------------------------------
 // wave / block exclusive scan of one int per thread (kBlock threads)
@@ -84,108 +54,6 @@ __device__ __forceinline__ int block_excl_scan(int v, int* block_total, int* lds
     __syncthreads();
     return base + incl - v;
 }
-
-// ---------------------------------------------------------------------------
-// The DDA shared by both marchers.
-// ---------------------------------------------------------------------------
-struct MarchParams {
-    const uint8_t* grid;
-    float bound;
-    int contract;
-    float dt_gamma;
-    uint32_t max_steps;
-    uint32_t C, H;
-};
-
-struct GridWalker {
-    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float rH, H3, Hf, Cf, dt_min, dt_max, bound, dt_gamma;
-    uint32_t H;
-    int contract;
-    const uint8_t* grid;
-
-    __device__ __forceinline__ void init(const MarchParams& p, const float* o, const float* d) {
-        const float3p O = *reinterpret_cast<const float3p*>(o);
-        const float3p D = *reinterpret_cast<const float3p*>(d);
-        ox = O.x; oy = O.y; oz = O.z;
-        dx = D.x; dy = D.y; dz = D.z;
-        rdx = 1 / dx; rdy = 1 / dy; rdz = 1 / dz;
-        H = p.H;
-        Hf = (float)p.H;
-        Cf = (float)p.C;
-        rH = 1 / (float)p.H;
-        H3 = (float)(p.H * p.H * p.H);
-        dt_min = 2 * kSqrt3 / p.max_steps;
-        dt_max = 2 * kSqrt3 * p.bound / p.H;
-        bound = p.bound;
-        dt_gamma = p.dt_gamma;
-        contract = p.contract;
-        grid = p.grid;
-    }
-
-    __device__ __forceinline__ float step_len(float t) const { return clampf(t * dt_gamma, dt_min, dt_max); }
-
-    __device__ __forceinline__ int cascade_of(float x, float y, float z, float dt) const {
-        int e_pos, e_dt;
-        const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-        frexpf(mx, &e_pos);
-        const int l_pos = (int)fminf(Cf - 1, fmaxf(0, e_pos));
-        const float md = (float)(dt * Hf * 0.5);   // double multiply by the literal, as in the reference
-        frexpf(md, &e_dt);
-        const int l_dt = (int)fminf(Cf - 1, fmaxf(0, e_dt));
-        return max(l_pos, l_dt);
-    }
-
-    // March from t; calls sink(cx,cy,cz,t_after,dt) for every occupied sample until
-    // `budget` samples were produced or t >= far.  Returns #samples.
-    template <class Sink>
-    __device__ __forceinline__ uint32_t walk(float t, float far, uint32_t budget, Sink&& sink) const {
-        uint32_t n = 0;
-        while (t < far && n < budget) {
-            const float x = clampf(ox + t * dx, -bound, bound);
-            const float y = clampf(oy + t * dy, -bound, bound);
-            const float z = clampf(oz + t * dz, -bound, bound);
-            float dt = step_len(t);
-            const int level = cascade_of(x, y, z, dt);
-            const float mip_bound = fminf(scalbnf(1.0f, level), bound);
-            const float mip_rbound = 1 / mip_bound;
-
-            float cx = x, cy = y, cz = z;
-            const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-            const bool warped = contract && mag > 1;
-            if (warped) {
-                const float s = (2 - 1 / mag) / mag;   // L-inf contraction
-                cx *= s; cy *= s; cz *= s;
-            }
-            const float top = (float)(H - 1);
-            const int nx = (int)clampf((float)(0.5 * (cx * mip_rbound + 1) * H), 0.0f, top);
-            const int ny = (int)clampf((float)(0.5 * (cy * mip_rbound + 1) * H), 0.0f, top);
-            const int nz = (int)clampf((float)(0.5 * (cz * mip_rbound + 1) * H), 0.0f, top);
-
-            const uint32_t cell = (uint32_t)(level * H3 + morton_encode(nx, ny, nz));
-            const bool occ = grid[cell >> 3] & (1u << (cell & 7u));
-
-            if (occ) {
-                t += dt;
-                sink(cx, cy, cz, t, dt);
-                ++n;
-            } else if (warped) {
-                t += dt;
-            } else {
-                // skip to the exit face of this voxel
-                const float tx = (((nx + 0.5f + 0.5f * copysignf(1.0f, dx)) * rH * 2 - 1) * mip_bound - cx) * rdx;
-                const float ty = (((ny + 0.5f + 0.5f * copysignf(1.0f, dy)) * rH * 2 - 1) * mip_bound - cy) * rdy;
-                const float tz = (((nz + 0.5f + 0.5f * copysignf(1.0f, dz)) * rH * 2 - 1) * mip_bound - cz) * rdz;
-                const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-                do {
-                    dt = step_len(t);
-                    t += dt;
-                } while (t < tt);
-            }
-        }
-        return n;
-    }
-};
 
 // ---------------------------------------------------------------------------
 // kernels
@@ -292,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_march_count(MarchParams p, const flo
         w.init(p, rays_o + 3ull * n, rays_d + 3ull * n);
         float t = nears[n];
         t += w.step_len(t) * noises[n];
-        cnt = (int)w.walk(t, fars[n], p.max_steps, [](float, float, float, float, float) {});
+        cnt = (int)w.walk(t, fars[n], p.max_steps, [](float, float, float, float, float) { return true; });
         rays[2ull * n + 1] = cnt;
     }
     int total;
@@ -350,6 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_march_write(MarchParams p, const flo
         *px++ = float3p{cx, cy, cz};
         *pd++ = dir;
         *pt++ = float2p{tn, dt};
+        return true;
     });
 }
 
@@ -377,6 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_march_infer(MarchParams p, uint32_t 
         *px++ = float3p{cx, cy, cz};
         *pd++ = dir;
         *pt++ = float2p{tn, dt};
+        return true;
     });
 }
 

@@ -1,0 +1,85 @@
+"""Generates tests/golden/reference_py.npz by EXECUTING the reference's own pure-torch helpers in this
+container (they cannot travel to the GPU box, the vectors can):
+
+  lib/core/utils/geometry_utils.py : get_ray_directions, get_rays, depth_to_normal, normalize_depth
+      (the module imports mcubes / skimage, which are not installed, so the four function definitions are
+       extracted from the file with `ast` and executed verbatim in a namespace holding torch / F / np)
+  lib/core/utils/camera_utils.py   : look_at, random_surround_views (same extraction)
+  lib/ops/edge_dilation.py         : edge_dilation (imported as a module: it only needs torch)
+
+Nothing is copied into the repo; the reference sources are read where they lie under /root/reference.
+Run from the repo root (needs /root/reference):  python tests/golden/make_reference_py_golden.py
+"""
+import ast
+import importlib.util
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_py.npz')
+
+
+def extract(path, names):
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = dict(torch=torch, F=F, np=np, math=math)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), path, 'exec'), ns)
+    return [ns[n] for n in names]
+
+
+def main():
+    get_ray_directions, get_rays, depth_to_normal, normalize_depth = extract(
+        os.path.join(REF, 'lib/core/utils/geometry_utils.py'),
+        ['get_ray_directions', 'get_rays', 'depth_to_normal', 'normalize_depth'])
+    look_at, random_surround_views = extract(os.path.join(REF, 'lib/core/utils/camera_utils.py'),
+                                             ['look_at', 'random_surround_views'])
+    spec = importlib.util.spec_from_file_location('ref_edge_dilation', os.path.join(REF, 'lib/ops/edge_dilation.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    out = {}
+    torch.manual_seed(0)
+    poses = random_surround_views(3.7, 8, -0.3, 0.6, use_linspace=True)           # lib/apis/adapter3d.py:991-994
+    out['poses'] = poses.numpy()
+    h = w = 24
+    f = h / (2 * math.tan(math.radians(15)))
+    intr = torch.tensor([[f, f * 1.1, w / 2 + 0.7, h / 2 - 0.3]] * 8, dtype=torch.float32)
+    intr[:, 0] *= torch.linspace(0.9, 1.1, 8)
+    out['intrinsics'] = intr.numpy()
+    dirs = get_ray_directions(h, w, intr[None], norm=False)
+    rays_o, rays_d = get_rays(dirs, poses[None, :, :3], norm=True)
+    out['directions'] = dirs[0].numpy()
+    out['rays_o'] = rays_o[0].numpy()
+    out['rays_d'] = rays_d[0].numpy()
+    g = torch.Generator().manual_seed(1)
+    depth = 0.2 + 0.3 * torch.rand(8, h, w, generator=g)
+    depth[0, :4] = 0.0                                                             # background: clamp(min=1e-6) path
+    out['depth_in'] = depth.numpy()
+    out['normal'] = depth_to_normal(depth, dirs[0]).numpy()
+    alphas = torch.rand(8, h, w, 1, generator=g)
+    alphas[1, 5:9] = 0.0
+    out['alphas_in'] = alphas.numpy()
+    out['depth_norm'] = normalize_depth(depth * alphas.squeeze(-1), alphas).numpy()
+    # edge dilation: a texture atlas with a ragged valid region
+    img = torch.rand(2, 3, 40, 48, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(40), torch.arange(48), indexing='ij')
+    mask = (((yy - 20) ** 2 + (xx - 22) ** 2) < 150) | ((yy > 30) & (xx % 7 < 3))
+    mask = mask[None, None].float().expand(2, 1, -1, -1).clone()
+    mask[1] = (torch.rand(1, 40, 48, generator=g) > 0.8).float()
+    img = img * mask
+    out['dil_img'] = img.numpy()
+    out['dil_mask'] = mask.numpy()
+    out['dil_out_r3_i7'] = mod.edge_dilation(img, mask, radius=3, iters=7).numpy()
+    out['dil_out_r1_i2'] = mod.edge_dilation(img, mask, radius=1, iters=2).numpy()
+    np.savez_compressed(OUT, **out)
+    print('wrote', OUT, os.path.getsize(OUT), 'bytes;', {k: v.shape for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,149 @@
+"""NeRF render path: hash-grid + MLP decode, fused eval renderer, ray generation, depth->normal, depth normalisation.
+
+not gpu : the oracle's pure-torch geometry helpers against vectors produced by EXECUTING the reference's own functions
+          (tests/golden/reference_py.npz, see tests/golden/make_reference_py_golden.py); hash-grid invariants.
+gpu     : HIP kernels vs the oracle on identical inputs.
+          marched samples are bit-exact by construction (same DDA as test_raymarching), so the fused renderer is compared
+          per ray with float tolerances only: 2e-5 relative on decoded sigma/rgb (fma vs mul-add, BLAS summation order),
+          1e-4 absolute on composited alpha/rgb/depth (sums of <= ~300 such terms, __expf vs expf).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as NO
+from oracle import raymarching as ORM
+from scene import camera_rays as scene_rays, sphere_density_grid
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'reference_py.npz')
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_oracle_geometry_matches_reference_functions():
+    g = np.load(GOLD)
+    h, w = g['directions'].shape[1:3]
+    dirs = NO.get_ray_directions(h, w, g['intrinsics'])
+    np.testing.assert_allclose(dirs, g['directions'], rtol=1e-6, atol=1e-7)
+    ro, rd = NO.get_rays(dirs, g['poses'][:, :3], norm=True)
+    np.testing.assert_allclose(ro, g['rays_o'], rtol=0, atol=0)
+    np.testing.assert_allclose(rd, g['rays_d'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(NO.depth_to_normal(g['depth_in'], g['directions']), g['normal'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(NO.normalize_depth(g['depth_in'] * g['alphas_in'][..., 0], g['alphas_in']), g['depth_norm'],
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_hashgrid_invariants():
+    meta, rows = NO.grid_meta(12, 16, 320)
+    assert [m[1] for m in meta][0] == 16 and [m[1] for m in meta][-1] == 320           # base and max resolution
+    assert meta[0][3] == 4096 and meta[-1][3] == 1 << 19 and rows == sum(m[3] for m in meta)
+    meta14, _ = NO.grid_meta(14, 16, 512)
+    assert meta14[-1][1] in (512, 513)          # float32 exp2f round-off decides, exactly as it does inside tiny-cuda-nn
+    p = NO.make_nerf_params(12, 320, seed=3, table_scale=1.0)
+    # at a grid vertex of the dense base level the interpolation returns that vertex' features exactly
+    scale, res, off, size = meta[0]
+    v = np.array([[3, 5, 7]], np.float32)
+    x = ((v - 0.5) / scale).astype(np.float32)                                           # pos = x*scale + 0.5 = v  (frac = 0)
+    enc = NO.hashgrid_encode(x, p['table'], 12, 320)
+    idx = int(v[0, 0] + v[0, 1] * res + v[0, 2] * res * res) % size
+    np.testing.assert_allclose(enc[0, :2], p['table'][off + idx], rtol=1e-5, atol=1e-6)
+    # continuity across a cell face (Smoothstep is C1)
+    xs = np.stack([np.linspace(0.3, 0.31, 50, dtype=np.float32), np.full(50, 0.4, np.float32), np.full(50, 0.6, np.float32)], 1)
+    e = NO.hashgrid_encode(xs, p['table'], 12, 320)
+    assert np.abs(np.diff(e, axis=0)).max() < 0.3
+    s, c = NO.point_decode(np.random.default_rng(0).uniform(-1, 1, (100, 3)).astype(np.float32), p)
+    assert s.shape == (100,) and c.shape == (100, 3) and (s > 0).all() and (c > -0.0011).all() and (c < 1.0011).all()
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _decoder(n_levels, max_res, seed=7, table_scale=0.5):
+    from mvedit_amd.nerf import INGPDecoderParams
+    p = NO.make_nerf_params(n_levels, max_res, seed=seed, table_scale=table_scale)
+    p['b1'] = np.random.default_rng(seed).normal(0, 0.1, p['b1'].shape).astype(np.float32)
+    p['b2'] = np.array([1.5, 0.1, -0.2, 0.3], np.float32)
+    dec = INGPDecoderParams(p['table'], p['w1'], p['b1'], p['w2'], p['b2'], n_levels, max_res)
+    return p, dec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_levels,max_res', [(12, 320), (14, 512)])
+def test_gpu_point_decode(lib, n_levels, max_res):
+    p, dec = _decoder(n_levels, max_res)
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (20000, 3)).astype(np.float32)
+    x[:8] = [[-1, -1, -1], [1, 1, 1], [0, 0, 0], [1, -1, 0.5], [0.999999, 0.3, -0.7], [-1, 1, 1], [0.25, 0.25, 0.25], [1, 0, 0]]
+    s_o, c_o = NO.point_decode(x, p)
+    s_h, c_h = dec.point_decode(torch.from_numpy(x))
+    np.testing.assert_allclose(s_h.cpu().numpy(), s_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(c_h.cpu().numpy(), c_o, rtol=2e-5, atol=2e-6)
+    s_d, none = dec.point_decode(torch.from_numpy(x), density_only=True)
+    assert none is None and torch.equal(s_d, s_h)
+    assert dec.point_decode(torch.zeros(0, 3))[0].numel() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt_gamma', [0.0, 1.0 / 256])
+def test_gpu_fused_renderer_matches_reference_loop(lib, dt_gamma):
+    """Oracle = the reference's host loop (march_rays -> point_decode -> composite_rays -> compaction); HIP = one launch."""
+    p, dec = _decoder(12, 320, table_scale=2.0)
+    H = 64
+    grid = sphere_density_grid(H, radius=0.55)
+    bits = ORM.packbits(grid, 0.5)
+    o, d = scene_rays(2, 48, seed=3)
+    ws_o, dep_o, img_o, n_samples = NO.render_rays_eval(o, d, bits, H, p, dt_gamma=dt_gamma, max_steps=512)
+    dec.max_steps = 512
+    ws_h, dep_h, img_h, cnt = dec.render_rays(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(bits), H, dt_gamma,
+                                              return_counts=True)
+    assert n_samples > 20000
+    np.testing.assert_allclose(ws_h.cpu().numpy(), ws_o, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(img_h.cpu().numpy(), img_o, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(dep_h.cpu().numpy(), dep_o, rtol=0, atol=1e-4)
+    hit = ws_o > 0
+    assert hit.mean() > 0.1 and (cnt.cpu().numpy()[~hit] == 0).all()
+    # the reference loop marches whole n_step chunks and discards what lies past a ray's termination inside a chunk, so it
+    # decodes at least as many samples as the fused walk, which stops exactly at the terminating sample
+    assert 0.9 * n_samples <= int(cnt.sum().item()) <= n_samples
+
+
+@pytest.mark.gpu
+def test_gpu_camera_rays_normals_and_depth_normalisation(lib):
+    from mvedit_amd import nerf
+    g = np.load(GOLD)
+    h, w = g['directions'].shape[1:3]
+    intr, poses = torch.from_numpy(g['intrinsics']).cuda(), torch.from_numpy(g['poses']).cuda()
+    ro, rd, dn = nerf.camera_rays(intr, poses, h, w)
+    assert torch.equal(ro.cpu().view(8, h, w, 3), torch.from_numpy(g['rays_o']))
+    np.testing.assert_allclose(rd.cpu().numpy().reshape(8, h, w, 3), g['rays_d'], rtol=1e-5, atol=1e-6)   # vs the reference's own output
+    np.testing.assert_allclose(dn.cpu().numpy(), np.linalg.norm(g['directions'], axis=-1), rtol=1e-6)
+    nfg, _ = nerf.depth_to_normal(torch.from_numpy(g['depth_in']).cuda(), intr)
+    np.testing.assert_allclose(nfg.cpu().numpy(), g['normal'], rtol=0, atol=5e-5)                          # reference depth_to_normal
+    dnorm = nerf.normalize_depth(torch.from_numpy(g['depth_in'] * g['alphas_in'][..., 0]).cuda(), torch.from_numpy(g['alphas_in']).cuda())
+    np.testing.assert_allclose(dnorm.cpu().numpy(), g['depth_norm'], rtol=1e-5, atol=1e-6)                 # reference normalize_depth
+
+
+@pytest.mark.gpu
+def test_gpu_nerf_render_seam(lib):
+    """BaseNeRF.render(return_rgba, compute_normal) end to end on 6 surround views."""
+    from mvedit_amd.nerf import NeRFRenderer
+    p, dec = _decoder(12, 320, table_scale=2.0)
+    H = 64
+    bits = ORM.packbits(sphere_density_grid(H, radius=0.5), 0.5)
+    g = np.load(GOLD)
+    S = 40
+    f = S / (2 * np.tan(np.deg2rad(15)))
+    intr = np.tile(np.array([[f, f, S / 2, S / 2]], np.float32), (6, 1))
+    poses = g['poses'][:6, :3]
+    rgba_o, depth_o, normal_o, nfg_o = NO.nerf_render(p, bits, H, S, S, intr, poses, dt_gamma_scale=0.5, max_steps=512)
+    dec.max_steps = 512
+    nr = NeRFRenderer(grid_size=H)
+    cfg = dict(return_rgba=True, compute_normal=True, dt_gamma_scale=0.5)
+    rgba, depth, normal, nfg = nr.render(dec, None, torch.from_numpy(bits).cuda()[None], S, S, torch.from_numpy(intr).cuda()[None],
+                                         torch.from_numpy(poses).cuda()[None], cfg=cfg)
+    assert rgba.shape == (1, 6, S, S, 4) and depth.shape == (1, 6, S, S) and normal.shape == (1, 6, S, S, 3)
+    # ray directions differ from the oracle's by float summation order (<= 1 ulp), which can move a handful of samples across a
+    # cell boundary: compare robustly -- 99.5 % of pixels within 1e-3, mean abs error tiny
+    for got, ref, name in ((rgba, rgba_o, 'rgba'), (depth, depth_o, 'depth'), (normal, normal_o, 'normal')):
+        err = np.abs(got[0].cpu().numpy() - ref)
+        assert (err < 1e-3).mean() > 0.995 and err.mean() < 1e-4, (name, err.max(), err.mean())
+    assert (rgba_o[..., 3] > 0.5).mean() > 0.05

@@ -56,6 +56,26 @@ def main():
         t = timeit(lambda: ops.layernorm(x, g, b))
         res.append(dict(op='layernorm', M=B * HW, C=C, ms=t * 1e3, gbps=2 * x.numel() * 2 / t / 1e9))
         print(res[-1], flush=True)
+    # fused NeRF eval renderer: BASELINE render batch (6 views x 512^2 rays), 128^3 occupancy sphere, 12-level hash grid
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import numpy as np
+    from scene import camera_rays, sphere_density_grid
+    from mvedit_amd import raymarching as G
+    from mvedit_amd.nerf import INGPDecoderParams, grid_meta
+    rng = np.random.default_rng(7)
+    _, rows = grid_meta(12, 16, 320)
+    dec = INGPDecoderParams(rng.uniform(-1e-4, 1e-4, (rows, 2)).astype(np.float32), rng.uniform(-.3, .3, (64, 24)).astype(np.float32),
+                            np.zeros(64, np.float32), rng.uniform(-.3, .3, (4, 64)).astype(np.float32), np.array([2.0, 0, 0, 0], np.float32))
+    bits = G.packbits(torch.from_numpy(sphere_density_grid(128, radius=0.5)).cuda(), 0.5)
+    o, d = camera_rays(6, 512, seed=1, jitter=False)
+    o_t, d_t = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    ws, dep, img, cnt = dec.render_rays(o_t, d_t, bits, 128, return_counts=True)
+    n_samples = int(cnt.sum().item())
+    t = timeit(lambda: dec.render_rays(o_t, d_t, bits, 128), warm=1, it=3)
+    nbytes = o.shape[0] * 52 + n_samples * 768          # 52 B/ray + 768 B of hash-table gathers per sample
+    res.append(dict(op='nerf_render_rays(fused)', rays=o.shape[0], samples=n_samples, ms=t * 1e3, views_per_s=6 / t,
+                    msamples_per_s=n_samples / t / 1e6, algorithmic_gbps=nbytes / t / 1e9))
+    print(res[-1], flush=True)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'microbench.json'), 'w'), indent=1)
 
