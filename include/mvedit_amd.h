@@ -140,6 +140,7 @@ MVE_API int mve_compact_alive(const int32_t* d_rays_alive, uint32_t n_alive, int
 #define MVE_GEMM_GEGLU   1   /* W rows interleaved (value,gate): out[m][i] = v[2i]*gelu(v[2i+1]), out width N/2 */
 #define MVE_GEMM_OUT_F32 2   /* out is float32 instead of `dtype` */
 #define MVE_CONV_W_CHUNK64 4 /* conv weight is [Cout][Cin/64][3][3][64] (needs C1, C2 multiples of 64) */
+#define MVE_GEMM_NO_SPLITK 8 /* never split K even if a workspace is given */
 
 /* out[m][n] = out_scale * ( sum_k A[m][k]*W[n][k] + bias[n] + rowvec[m/rows_per_vec][n] + residual[m][n] )
  * A: [M][lda] dtype, W: [N][ldw] dtype (torch Linear / 1x1-conv layout; ldw > K selects a column block),
@@ -147,7 +148,15 @@ MVE_API int mve_compact_alive(const int32_t* d_rays_alive, uint32_t n_alive, int
  * embedding of ResnetBlock2D); residual: [M][ldr] dtype or NULL.  N, K, lda, ldw, ldr multiples of 8. */
 MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int ldw, void* d_out, int ldc,
                      int M, int N, int K, const float* d_bias, const float* d_rowvec, int ldrv, int rows_per_vec,
-                     const void* d_residual, int ldr, int flags, float out_scale, void* stream);
+                     const void* d_residual, int ldr, int flags, float out_scale, void* d_workspace,
+                     size_t workspace_bytes, int rows_per_image, void* stream);
+
+/* Split-K: at the deep UNet levels one image contributes only a few output tiles while K = 9*1280..9*2560; K is then cut
+ * into slices that run concurrently and are summed in a fixed order by a second launch.  The slice count depends on
+ * (rows_per_image, N, K) only -- never on the batch -- so results are bit-identical however views are chunked or
+ * partitioned across GPUs.  It needs an fp32 scratch of mve_gemm_workspace_bytes(...) bytes (0 = this shape never
+ * splits; conv: M = B*Ho*Wo, K = 9*(C1+C2), rows_per_image = Ho*Wo); d_workspace NULL or rows_per_image 0 = no split. */
+MVE_API size_t mve_gemm_workspace_bytes(int M, int N, int K, int rows_per_image);
 
 /* 3x3 convolution, padding 1, as an implicit GEMM over NHWC input(s):
  *   input = concat_channels(x1[B,Hs,Ws,C1], x2[B,Hs,Ws,C2]) (C2 = 0: single input), optionally
@@ -158,7 +167,7 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int l
 MVE_API int mve_conv3x3(int dtype, const void* d_x1, int C1, const void* d_x2, int C2, int B, int Hs, int Ws,
                         int stride, int upsample, const void* d_W, int Cout, void* d_out, int ldc,
                         const float* d_bias, const float* d_rowvec, int ldrv, const void* d_residual, int ldr,
-                        int flags, float out_scale, void* stream);
+                        int flags, float out_scale, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Scaled-dot-product attention over packed projections (no head permutes):
  *   Q row (b,i) at d_Q + (b*Lq+i)*ldq, head h at column h*head_dim; same for K/V with Lk, O with Lq.

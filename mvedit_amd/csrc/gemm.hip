@@ -60,7 +60,6 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     constexpr int SMEM = SMEM0;
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
-    typedef T T4 __attribute__((ext_vector_type(4)));
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
@@ -69,7 +68,11 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
 
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const unsigned tile = mve_xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    // split-K: the K slices of one output tile are adjacent logical blocks (same XCD, concurrently resident)
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    const unsigned lin = mve_xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n * S));
+    const int kslice = lin % S;
+    const unsigned tile = lin / S;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -111,11 +114,16 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     }
 
     // conv, tap-major K order: running (tap, cin) of this thread's chunk
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt_begin = (int)((long long)nk_all * kslice / S), kt_end = (int)((long long)nk_all * (kslice + 1) / S);
     const int Ctot = p.g.C1 + p.g.C2;
-    int tap = 0, cin = lc * 8;
+    int tap = 0, cin = 0;
     if constexpr (MODE == 1) {
-        if (!p.g.chunk64)
-            while (cin >= Ctot) { cin -= Ctot; ++tap; }
+        if (!p.g.chunk64) {
+            const int k0 = kt_begin * BK + lc * 8;
+            tap = k0 / Ctot;
+            cin = k0 - tap * Ctot;
+        }
     }
     const T* zero = reinterpret_cast<const T*>(g_zero_page);
 
@@ -186,15 +194,14 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
-    if constexpr (VARIANT == 0) { load_tile(0); store_tile(0); }
-    else dma_tile(0, 0);
+    if constexpr (VARIANT == 0) { load_tile(kt_begin); store_tile(0); }
+    else dma_tile(kt_begin, 0);
     __syncthreads();
 
     const int frow = lane & 15, fchunk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) {
             if constexpr (VARIANT == 0) load_tile(kt + 1);
             else dma_tile(kt + 1, cur ^ 1);
         }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
                 for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf[j], xf[i], acc[j][i]);
         }
         if constexpr (VARIANT == 0) {
-            if (kt + 1 < nk) store_tile(cur ^ 1);
+            if (kt + 1 < kt_end) store_tile(cur ^ 1);
         }
         __syncthreads();   // variant 1: the compiler drains the in-flight LDS-DMA (vmcnt(0)) ahead of this barrier
     }
@@ -248,47 +255,48 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-                if (p.bias) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                if (p.rowvec) {
-                    const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.ldrv + n;
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                if (p.geglu) {
-                    T4 pk;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = Tag::from_f32(v[2 * e] * gelu_erf(v[2 * e + 1]));
-                    *reinterpret_cast<T4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1)) = pk;
+                if (p.splitk > 1) {      // raw fp32 partial tile of this K slice; the reducer applies the epilogue
+                    float* pp = p.partial + ((size_t)kslice * p.M + m) * p.N + n;
+                    *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(pp + 4) = f32x4{v[4], v[5], v[6], v[7]};
                     continue;
                 }
-                if (p.residual) {
-                    const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-                if (p.out_f32) {
-                    float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
-                    *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                } else {
-                    V8 pk;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
-                    *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = pk;
-                }
+                gemm_epilogue_store<Tag>(p, m, n, v);
             }
             __syncthreads();
         }
     }
+}
+
+// split-K reducer: out = epilogue( sum_s partial[s] ), 8 columns per thread
+template <class Tag>
+__global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
+    const size_t chunks_n = p.N / 8;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)p.M * chunks_n) return;
+    const int m = (int)(i / chunks_n), n = (int)(i - (size_t)m * chunks_n) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.splitk; ++s) {        // fixed order: deterministic
+        const float* pp = p.partial + ((size_t)s * p.M + m) * p.N + n;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(pp), hi = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[4 + e] += hi[e]; }
+    }
+    gemm_epilogue_store<Tag>(p, m, n, v);
+}
+
+// Split K at the deep UNet levels, where one image contributes only a few output tiles (8x8 / 16x16 latents) but K is
+// 9*1280..9*2560.  The slice count is a function of (rows per image, N, K) ONLY -- never of the batch -- so that a view gets
+// bit-identical results whether it is denoised alone, in a chunk, or on another GPU (batch / partition invariance).
+int choose_splitk(int rows_per_image, int N, int K) {
+    if (rows_per_image <= 0) return 1;
+    const int bn = (N % 160 == 0) ? 160 : (N % 128 == 0 ? 128 : (N <= 64 ? 64 : 128));
+    const long long t1 = (long long)mve_cdiv(rows_per_image, BM) * mve_cdiv(N, bn);      // tiles of ONE image
+    const int nk = (K + BK - 1) / BK;
+    long long s = 64 / t1;
+    if (s > nk / 8) s = nk / 8;        // at least 8 K tiles (512 k) per slice
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
 }
 
 int gemm_variant() {
@@ -308,18 +316,22 @@ int launch_v(const GemmParams& p, hipStream_t s) {
     else if (p.N % 128 == 0) bn = 128;
     else if (p.N <= 64) bn = 64;
     const unsigned tiles_m = mve_cdiv(p.M, BM), tiles_n = mve_cdiv(p.N, bn);
-    const unsigned grid = tiles_m * tiles_n;
+    const unsigned grid = tiles_m * tiles_n * (p.splitk > 1 ? p.splitk : 1);
     if (bn == 160) k_gemm<Tag, 160, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
     else if (bn == 128) k_gemm<Tag, 128, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
     else k_gemm<Tag, 64, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
     MVE_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
+        MVE_LAUNCH_CHECK();
+    }
     return MVE_OK;
 }
 
 template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int v = gemm_variant();
-    if (v == 2 && p.M >= 256 && p.N >= 64) return mve_gemm_rs_launch(Tag::dtype, MODE, &p, s);
+    if (v == 2 && p.splitk <= 1 && p.M >= 256 && p.N >= 64) return mve_gemm_rs_launch(Tag::dtype, MODE, &p, s);
     return v == 0 ? launch_v<Tag, MODE, 0>(p, s) : launch_v<Tag, MODE, 1>(p, s);
 }
 
@@ -340,9 +352,15 @@ int check_common(const GemmParams& p, const char* who) {
 
 extern "C" {
 
+size_t mve_gemm_workspace_bytes(int M, int N, int K, int rows_per_image) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int sk = choose_splitk(rows_per_image, N, K);
+    return sk > 1 ? (size_t)sk * M * N * sizeof(float) : 0;
+}
+
 int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
              const float* bias, const float* rowvec, int ldrv, int rows_per_vec, const void* residual, int ldr, int flags,
-             float out_scale, void* stream) {
+             float out_scale, void* workspace, size_t workspace_bytes, int rows_per_image, void* stream) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
@@ -355,6 +373,11 @@ int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* ou
     int rc = check_common(p, "gemm");
     if (rc) return rc;
     MVE_CHECK(A && lda % 8 == 0 && lda >= K, MVE_ERR_ARG, "gemm: bad A/lda (%d)", lda);
+    p.splitk = 1;
+    if (workspace && !(flags & MVE_GEMM_NO_SPLITK)) {
+        const int sk = choose_splitk(rows_per_image, N, K);
+        if (sk > 1 && workspace_bytes >= (size_t)sk * M * N * sizeof(float)) { p.splitk = sk; p.partial = (float*)workspace; }
+    }
     if (dtype == MVE_F16) return launch_gemm<F16Tag, 0>(p, (hipStream_t)stream);
     if (dtype == MVE_BF16) return launch_gemm<BF16Tag, 0>(p, (hipStream_t)stream);
     mve_set_error("gemm: unsupported dtype %d", dtype);
@@ -363,7 +386,8 @@ int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* ou
 
 int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int Hs, int Ws, int stride,
                 int upsample, const void* W, int Cout, void* out, int ldc, const float* bias, const float* rowvec,
-                int ldrv, const void* residual, int ldr, int flags, float out_scale, void* stream) {
+                int ldrv, const void* residual, int ldr, int flags, float out_scale, void* workspace, size_t workspace_bytes,
+                void* stream) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     MVE_CHECK(stride == 1 || stride == 2, MVE_ERR_ARG, "conv3x3: stride must be 1 or 2");
@@ -391,6 +415,11 @@ int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B
     p.out_scale = out_scale;
     int rc = check_common(p, "conv3x3");
     if (rc) return rc;
+    p.splitk = 1;
+    if (workspace && !(flags & MVE_GEMM_NO_SPLITK)) {
+        const int sk = choose_splitk(p.g.Ho * p.g.Wo, p.N, p.K);
+        if (sk > 1 && workspace_bytes >= (size_t)sk * p.M * p.N * sizeof(float)) { p.splitk = sk; p.partial = (float*)workspace; }
+    }
     if (dtype == MVE_F16) return launch_gemm<F16Tag, 1>(p, (hipStream_t)stream);
     if (dtype == MVE_BF16) return launch_gemm<BF16Tag, 1>(p, (hipStream_t)stream);
     mve_set_error("conv3x3: unsupported dtype %d", dtype);

@@ -46,7 +46,6 @@ __global__ __launch_bounds__(NT2, 2) void k_gemm_rs(const GemmParams p) {
     static_assert(2 * CS_BYTES <= NSTAGE * STAGE, "epilogue staging must fit in the pipeline LDS");
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
-    typedef T T4 __attribute__((ext_vector_type(4)));
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
 
@@ -235,43 +234,7 @@ __global__ __launch_bounds__(NT2, 2) void k_gemm_rs(const GemmParams p) {
             const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-            if (p.bias) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-            }
-            if (p.rowvec) {
-                const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.ldrv + n;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-            }
-            if (p.geglu) {
-                T4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = Tag::from_f32(v[2 * e] * gelu_erf(v[2 * e + 1]));
-                *reinterpret_cast<T4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1)) = pk;
-                continue;
-            }
-            if (p.residual) {
-                const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-            if (p.out_f32) {
-                float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
-                *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
-                V8 pk;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
-                *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = pk;
-            }
+            gemm_epilogue_store<Tag>(p, m, n, v);
         }
         __syncthreads();
     }

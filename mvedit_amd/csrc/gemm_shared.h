@@ -37,6 +37,8 @@ struct GemmParams {
     int geglu;         // 1: out[m][i] = v[2i] * gelu(v[2i+1])
     int out_f32;       // 1: out is float
     float out_scale;   // multiplies the final value (1/output_scale_factor)
+    int splitk;        // > 1: K is cut into `splitk` slices, each block writes an fp32 partial tile to `partial`
+    float* partial;    // [splitk][M][N] fp32 workspace (split-K only)
     ConvGeom g;
 };
 
@@ -59,5 +61,51 @@ __device__ __forceinline__ const T* conv_src(const GemmParams& p, int cb, int cy
     return src + (((size_t)cb * p.g.Hs + ys) * p.g.Ws + xs) * cs + ch;
 }
 
+
+// The fused epilogue on 8 consecutive output columns (n % 8 == 0) of row m: bias, per-image row vector (time embedding),
+// GEGLU, residual, output scale, storage-dtype (or fp32) store.  Shared by the GEMM kernels and the split-K reducer.
+template <class Tag>
+__device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, int n, float (&v)[8]) {
+    typedef typename Tag::T T;
+    typedef typename Tag::V8 V8;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    if (p.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if (p.rowvec) {
+        const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.ldrv + n;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if (p.geglu) {
+        T4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = Tag::from_f32(v[2 * e] * gelu_erf(v[2 * e + 1]));
+        *reinterpret_cast<T4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1)) = pk;
+        return;
+    }
+    if (p.residual) {
+        const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+    if (p.out_f32) {
+        float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        V8 pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
+        *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = pk;
+    }
+}
 
 }  // namespace

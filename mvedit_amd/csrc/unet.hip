@@ -24,9 +24,10 @@
 
 extern "C" {
 int mve_gemm(int, const void*, int, const void*, int, void*, int, int, int, int, const float*, const float*, int, int,
-             const void*, int, int, float, void*);
+             const void*, int, int, float, void*, size_t, int, void*);
 int mve_conv3x3(int, const void*, int, const void*, int, int, int, int, int, int, const void*, int, void*, int,
-                const float*, const float*, int, const void*, int, int, float, void*);
+                const float*, const float*, int, const void*, int, int, float, void*, size_t, void*);
+size_t mve_gemm_workspace_bytes(int, int, int, int);
 int mve_attention(int, const void*, int, const void*, int, const void*, int, const void*, int, const void*, int, void*, int,
                   int, int, int, int, int, int, float, void*);
 size_t mve_groupnorm_workspace_bytes(int, int, int, int);
@@ -506,14 +507,19 @@ struct Builder {
         pl.flops[cls] += flops;
     }
 
+    int rows_img = 0;        // rows per image of the level being emitted (split-K granularity); 0: never split
     void gemm(Ref A, int lda, Ref W, int ldw, Ref out, int ldc, int M, int N, int K, Ref bias, Ref rowvec, int ldrv,
               int rpv, Ref res, int ldr, int flags, const char* what) {
+        const int rimg = rows_img;
         const int d = dt;
         live(A, what); live(out, what); live(res, what); live(rowvec, what);
+        const size_t skb = mve_gemm_workspace_bytes(M, N, K, rimg);
+        Ref sk = skb ? ws(skb) : Ref();
         op(OC_LINEAR, 2.0 * M * N * K, what, [=](const Run& r) {
             return mve_gemm(d, r.p(A), lda, r.p(W), ldw, r.p(out), ldc, M, N, K, (const float*)r.p(bias), (const float*)r.p(rowvec),
-                            ldrv, rpv, r.p(res), ldr, flags, 1.0f, r.stream);
+                            ldrv, rpv, r.p(res), ldr, flags, 1.0f, r.p(sk), skb, rimg, r.stream);
         });
+        rel(sk);
     }
     void conv(Ref x, int C1, int Bn, int H, int W, int stride, int ups, Ref Wt, int Cout, Ref out, Ref bias, Ref rowvec,
               int ldrv, Ref res, int flags, const char* what) {
@@ -522,10 +528,13 @@ struct Builder {
         const int Ho = (Hv - 1) / stride + 1, Wo = (Wv - 1) / stride + 1;
         live(x, what); live(out, what); live(res, what); live(rowvec, what);
         const int fl = flags | (C1 % 64 == 0 ? MVE_CONV_W_CHUNK64 : 0);   // must mirror load_param's packing rule
+        const size_t skb = mve_gemm_workspace_bytes(Bn * Ho * Wo, Cout, 9 * C1, Ho * Wo);
+        Ref sk = skb ? ws(skb) : Ref();
         op(OC_CONV, 2.0 * Bn * Ho * Wo * (double)Cout * 9 * C1, what, [=](const Run& r) {
             return mve_conv3x3(d, r.p(x), C1, nullptr, 0, Bn, H, W, stride, ups, r.p(Wt), Cout, r.p(out), Cout,
-                               (const float*)r.p(bias), (const float*)r.p(rowvec), ldrv, r.p(res), Cout, fl, 1.0f, r.stream);
+                               (const float*)r.p(bias), (const float*)r.p(rowvec), ldrv, r.p(res), Cout, fl, 1.0f, r.p(sk), skb, r.stream);
         });
+        rel(sk);
     }
     void gn(Ref x1, int C1, Ref x2, int C2, int Bn, int HW, float eps, Ref g, Ref b, int silu, Ref out, const char* what) {
         const int d = dt, G = c.groups;
@@ -557,6 +566,7 @@ struct Builder {
     // ResnetBlock2D.  x [M,C1] (+ skip [M,C2]) -> new buffer [M,Cout]
     Ref resnet(const std::string& name, Ref x, int C1, Ref skip, int C2, int Cout, int H, int W) {
         const int M = B * H * W, Cin = C1 + C2, e = 2;
+        rows_img = H * W;
         Ref h0 = ws((size_t)M * Cin * e);
         gn(x, C1, skip, C2, B, H * W, c.eps, wt(name + ".norm1.g"), wt(name + ".norm1.b"), 1, h0, "resnet.norm1+silu");
         Ref h1 = ws((size_t)M * Cout * e);
@@ -583,6 +593,7 @@ struct Builder {
     // Transformer2DModel.  x [M,C] -> new buffer [M,C]
     Ref transformer(const std::string& name, Ref x, int C, int heads, int layers, int H, int W) {
         const int M = B * H * W, e = 2, hd = C / heads;
+        rows_img = H * W;
         const int nb = B / pl.n_img, L = H * W * pl.n_img;     // cross-image attention: [n*b, L, C] seen as [b, n*L, C]
         Ref n0 = ws((size_t)M * C * e);
         gn(x, C, Ref(), 0, B, H * W, 1e-6f, wt(name + ".norm.g"), wt(name + ".norm.b"), 0, n0, "transformer.norm");

@@ -29,7 +29,15 @@ def _chk16(*ts):
             assert t.is_cuda and t.stride(-1) == 1 and t.dtype in (torch.float16, torch.bfloat16), (t.dtype, t.shape)
 
 
-def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, out=None, out_scale=1.0):
+NO_SPLITK = 8
+
+
+def _splitk_ws(M, N, K, device, rows_per_image):
+    nbytes = _lib.raw('mve_gemm_workspace_bytes')(M, N, K, int(rows_per_image)) if rows_per_image else 0
+    return (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes) if nbytes else (None, 0)
+
+
+def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, out=None, out_scale=1.0, rows_per_image=0):
     """a [M,K], w [N,K] -> [M,N] (or [M,N/2] with GEGLU).  bias/rowvec fp32."""
     _chk16(a, w, residual)
     M, K = a.shape
@@ -38,16 +46,18 @@ def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, o
     n_out = N // 2 if flags & GEGLU else N
     if out is None:
         out = torch.empty(M, n_out, dtype=torch.float32 if flags & OUT_F32 else a.dtype, device=a.device)
+    ws, ws_bytes = _splitk_ws(M, N, K, a.device, rows_per_image)
     with torch.cuda.device(a.device):
         _lib.call('mve_gemm', dt(a), _lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(out), out.stride(0),
                   M, N, K, _lib.ptr(bias), _lib.ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
                   int(rows_per_vec), _lib.ptr(residual),
-                  residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _s(a))
+                  residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _lib.ptr(ws), ws_bytes,
+                  int(rows_per_image), _s(a))
     return out
 
 
 def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec=None, residual=None, flags=0,
-            out_scale=1.0):
+            out_scale=1.0, splitk=True):
     """x1 [B*H*W, C1] (+ x2 [B*H*W, C2]) NHWC, w [Cout,3,3,C1+C2] -> ([B*Ho*Wo, Cout], Ho, Wo).
     With flags & W_CHUNK64 the weight is [Cout, (C1+C2)/64, 3, 3, 64] (see pack_conv_weight)."""
     _chk16(x1, x2, w, residual)
@@ -58,11 +68,12 @@ def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec
     Hv, Wv = (H * 2, W * 2) if upsample else (H, W)
     Ho, Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
     out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32 if flags & OUT_F32 else x1.dtype, device=x1.device)
+    ws, ws_bytes = _splitk_ws(B * Ho * Wo, Cout, 9 * (C1 + C2), x1.device, Ho * Wo if splitk else 0)
     with torch.cuda.device(x1.device):
         _lib.call('mve_conv3x3', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x2), C2, B, H, W, stride, int(bool(upsample)),
                   _lib.ptr(w), Cout, _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(rowvec),
                   rowvec.stride(0) if rowvec is not None else 0, _lib.ptr(residual),
-                  residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _s(x1))
+                  residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _lib.ptr(ws), ws_bytes, _s(x1))
     return out, Ho, Wo
 
 

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_version_and_error_plumbing(lib):
     assert lib.raw('mve_version')() == 1
     # argument validation fails loudly without touching a GPU
-    rc = lib.raw('mve_gemm')(1, None, 8, None, 8, None, 8, 16, 12, 8, None, None, 0, 0, None, 0, 0, ctypes.c_float(1.0), None)
+    rc = lib.raw('mve_gemm')(1, None, 8, None, 8, None, 8, 16, 12, 8, None, None, 0, 0, None, 0, 0, ctypes.c_float(1.0), None, 0, 0, None)
     assert rc == -1 and 'multiples of 8' in lib.last_error()
     rc = lib.raw('mve_attention')(1, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 8, None, 0, None, 0,
                                   ctypes.c_void_p(16), 8, 1, 4, 4, 0, 8, 48, ctypes.c_float(1.0), None)

@@ -237,3 +237,38 @@ def test_boundary_helpers(lib):
     assert torch.allclose(ops.silu(a.cuda()).float().cpu(), F.silu(a.float()).half().float(), atol=2e-3)
     u, tx = rnd((2, 4, 8, 8), torch.float32, 4), rnd((2, 4, 8, 8), torch.float32, 5)
     assert torch.allclose(ops.cfg_combine(u.cuda(), tx.cuda(), 7.0).cpu(), 7.0 * tx + (1 - 7.0) * u, atol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_splitk_small_m_big_k(lib, dtype):
+    """Deep UNet levels at small batch: M = B*64 rows, K = 9*1280.  The K range is cut into concurrent slices whose fp32
+    partials are summed in a fixed order; results must match the unsplit kernel to rounding and be deterministic."""
+    from mvedit_amd import ops, _lib
+    M, N, K = 512, 1280, 11520
+    ws = _lib.raw('mve_gemm_workspace_bytes')
+    assert ws(M, N, K, 64) > 0 and ws(262144, 320, 2880, 4096) == 0 and ws(M, N, K, 0) == 0
+    assert ws(8 * M, N, K, 64) == 8 * ws(M, N, K, 64)          # the slice count does not depend on the batch
+    a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    bias, res = rnd((N,), torch.float32, 3), rnd((M, N), dtype, 4)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    o1 = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), rows_per_image=64)
+    o0 = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda())
+    check('gemm split-K', o1, ref, dtype)
+    check('gemm no split', o0, ref, dtype)
+    assert torch.equal(o1, ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), rows_per_image=64))
+    # batch invariance: the first image's rows are bit-identical when it is processed alone
+    assert torch.equal(o1[:64], ops.gemm(a[:64].cuda(), w.cuda(), bias=bias.cuda(), residual=res[:64].cuda(), rows_per_image=64))
+    # conv at 8x8, batch 2 (M = 128): tap-major and slab-major weight layouts, K slices start mid-way through the taps
+    B, H, C = 2, 8, 1280
+    x = rnd((B, C, H, H), dtype, 5)
+    wc = rnd((C, C, 3, 3), dtype, 6, (9 * C) ** -0.5)
+    refc = to_nhwc(conv_ref(x, wc, bias))
+    for chunk64 in (False, True):
+        w_k, wflag = ops.pack_conv_weight(wc, chunk64)
+        out, _, _ = ops.conv3x3(to_nhwc(x).cuda(), w_k.cuda(), B, H, H, bias=bias.cuda(), flags=wflag, splitk=True)
+        check('conv split-K', out, refc, dtype, f'chunk64={chunk64}')
+    # GEGLU through the reducer
+    wv, wg = rnd((640, K), dtype, 7, K ** -0.5), rnd((640, K), dtype, 8, K ** -0.5)
+    w_il = torch.stack([wv, wg], 1).reshape(1280, K).contiguous()
+    out = ops.gemm(a.cuda(), w_il.cuda(), flags=ops.GEGLU, rows_per_image=64)
+    check('geglu split-K', out, (a.float() @ wv.float().t()) * F.gelu(a.float() @ wg.float().t()), dtype)
