@@ -293,6 +293,30 @@ MVE_API int mve_depth_to_normal(const float* d_depth, const float* d_alpha, int 
 MVE_API int mve_normalize_depth(const float* d_depths, const float* d_alphas, int n_views, int hw, float far_depth,
                                 float alpha_clip, float eps, float* d_out, void* stream);
 
+/* =========================================================================
+ * 5. Texture-space ops of the mesh path.
+ * ========================================================================= */
+
+/* edge_dilation (lib/ops/edge_dilation.py:5-47): img [n,c,h,w] f32, mask [n,1,h,w] f32 -> dilated img (and mask) after
+ * `iters` rounds of nearest-valid-texel fill inside a (2*round(radius)+1)^2 window.  *_tmp: ping-pong scratch of the same
+ * sizes (may be NULL when iters <= 1).  Inputs are not modified. */
+MVE_API int mve_edge_dilation(const float* d_img, const float* d_mask, int n, int c, int h, int w, float radius, int iters,
+                              float* d_img_out, float* d_mask_out, float* d_img_tmp, float* d_mask_tmp, void* stream);
+
+/* =========================================================================
+ * 6. Mesh rasterisation (output convention of nvdiffrast as used at
+ *    lib/models/decoders/mesh_renderer/base_mesh_renderer.py:240-252; coverage rules specified in oracle/raster_oracle.c).
+ * ========================================================================= */
+
+/* pos: [B][V][4] clip-space f32, tri: [F][3] i32 -> rast [B][H][W][4] = (u, v, z/w, triangle_id+1), 0 where empty.
+ * Row 0 is y_ndc = -1 (OpenGL orientation).  d_workspace: >= mve_rasterize_workspace_bytes(B,H,W,F). */
+MVE_API size_t mve_rasterize_workspace_bytes(int B, int H, int W, int F);
+MVE_API int mve_rasterize(const float* d_pos, int B, int V, const int32_t* d_tri, int F, int H, int W, float* d_rast,
+                          void* d_workspace, size_t workspace_bytes, void* stream);
+/* dr.interpolate: attr [Battr][Vattr][A] (Battr 1 broadcasts), tri [F][3] indexes attr; out [B][H][W][A], 0 where empty */
+MVE_API int mve_interpolate(const float* d_attr, int Battr, int Vattr, int A, const float* d_rast, int B, int H, int W,
+                            const int32_t* d_tri, int F, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -176,3 +176,73 @@ int mve_cfg_combine(const float* uncond, const float* text, float guidance_scale
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Texture-seam dilation (lib/ops/edge_dilation.py:5-47 of the reference).  One launch per iteration:
+//   mask_out = maxpool_k(mask);  every pixel with mask_out - mask > 0.5 copies the image value of the valid
+//   pixel of its k x k window that maximises  mask * (d_max - d + 1),  d = Euclidean offset length, first
+//   maximum in row-major window order on ties (torch.argmax over the F.unfold axis).
+// The reference materialises the 49-fold unfolded mask (and gathers through it); here each pixel scans its
+// window in registers: 2 reads + 1 write of the image per iteration instead of ~50.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void k_edge_dilate(const float* __restrict__ img, const float* __restrict__ mask, int n, int c,
+                                                     int h, int w, int r, float* __restrict__ img_out, float* __restrict__ mask_out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t hw = (size_t)h * w;
+    if (i >= (size_t)n * hw) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h), b = (int)(i / hw);
+    const float* mk = mask + (size_t)b * hw;
+    const float m0 = mk[(size_t)y * w + x];
+    float mmax = -INFINITY;            // F.max_pool2d pads with -inf
+    float best = -INFINITY;
+    int by = y, bx = x;
+    const float dmax = sqrtf((float)(2 * r * r));
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+            const float mv = in ? mk[(size_t)yy * w + xx] : 0.0f;          // F.unfold pads with zeros
+            if (in) mmax = fmaxf(mmax, mv);
+            const float score = mv * (dmax - sqrtf((float)(dx * dx + dy * dy)) + 1.0f);
+            if (score > best) { best = score; by = yy; bx = xx; }       // strict >: first maximum wins
+        }
+    const bool fill = (mmax - m0) > 0.5f;
+    mask_out[i] = mmax;
+    // an all-invalid window (best == 0 at the first, out-of-image-or-zero entry) cannot be a fill pixel, so by/bx are in range
+    for (int ch = 0; ch < c; ++ch) {
+        const float* src = img + ((size_t)b * c + ch) * hw;
+        img_out[((size_t)b * c + ch) * hw + (size_t)y * w + x] = fill ? src[(size_t)by * w + bx] : src[(size_t)y * w + x];
+    }
+}
+
+}  // namespace
+
+extern "C" int mve_edge_dilation(const float* d_img, const float* d_mask, int n, int c, int h, int w, float radius, int iters,
+                                 float* d_img_out, float* d_mask_out, float* d_img_tmp, float* d_mask_tmp, void* stream) {
+    MVE_CHECK(d_img && d_mask && d_img_out && d_mask_out, MVE_ERR_ARG, "edge_dilation: null pointer");
+    const size_t npix = (size_t)n * h * w;
+    hipStream_t s = (hipStream_t)stream;
+    const int r = (int)lrintf(radius);          // Python round(): half to even, as lrintf in the default rounding mode
+    if (npix == 0) return MVE_OK;
+    if (r == 0 || iters <= 0) {
+        MVE_HIP(hipMemcpyAsync(d_img_out, d_img, npix * c * sizeof(float), hipMemcpyDeviceToDevice, s));
+        MVE_HIP(hipMemcpyAsync(d_mask_out, d_mask, npix * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return MVE_OK;
+    }
+    MVE_CHECK(iters == 1 || (d_img_tmp && d_mask_tmp), MVE_ERR_ARG, "edge_dilation: ping-pong buffers required for iters > 1");
+    const float* src_i = d_img;
+    const float* src_m = d_mask;
+    for (int it = 0; it < iters; ++it) {
+        // ping-pong so that the LAST iteration lands in the caller's output buffers
+        const bool to_out = ((iters - 1 - it) % 2) == 0;
+        float* dst_i = to_out ? d_img_out : d_img_tmp;
+        float* dst_m = to_out ? d_mask_out : d_mask_tmp;
+        k_edge_dilate<<<mve_cdiv(npix, 256), 256, 0, s>>>(src_i, src_m, n, c, h, w, r, dst_i, dst_m);
+        MVE_LAUNCH_CHECK();
+        src_i = dst_i;
+        src_m = dst_m;
+    }
+    return MVE_OK;
+}

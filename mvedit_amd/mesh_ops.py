@@ -1,0 +1,86 @@
+"""Mirrors of the reference's texture-space helpers used by the mesh path (lib/ops/edge_dilation.py)."""
+import torch
+
+from . import _lib
+
+
+def edge_dilation(img, mask, radius=3, iters=7):
+    """Same signature and result as lib.ops.edge_dilation.edge_dilation: img (n,c,h,w), mask (n,1,h,w) -> dilated img."""
+    if radius == 0 or iters == 0:
+        return img
+    assert img.is_cuda and mask.is_cuda and img.dim() == 4 and mask.shape[1] == 1
+    dtype = img.dtype
+    x = img.float().contiguous()
+    m = mask.float().contiguous()
+    n, c, h, w = x.shape
+    out, mout = torch.empty_like(x), torch.empty_like(m)
+    tmp, mtmp = (torch.empty_like(x), torch.empty_like(m)) if iters > 1 else (None, None)
+    with torch.cuda.device(x.device):
+        _lib.call('mve_edge_dilation', _lib.ptr(x), _lib.ptr(m), n, c, h, w, float(radius), int(iters), _lib.ptr(out),
+                  _lib.ptr(mout), _lib.ptr(tmp), _lib.ptr(mtmp), _lib.stream_ptr(x.device))
+    return out.to(dtype)
+
+
+def rasterize(pos, tri, resolution):
+    """dr.rasterize(glctx, pos, tri, (h, w)) -> rast [B,h,w,4] = (u, v, z/w, triangle_id+1).  pos [B,V,4] clip space, tri [F,3] int32."""
+    h, w = resolution
+    pos = pos.float().contiguous()
+    tri = tri.to(torch.int32).contiguous()
+    B, V, _ = pos.shape
+    F = tri.shape[0]
+    rast = torch.empty(B, h, w, 4, dtype=torch.float32, device=pos.device)
+    nbytes = _lib.raw('mve_rasterize_workspace_bytes')(B, h, w, F)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pos.device)
+    with torch.cuda.device(pos.device):
+        _lib.call('mve_rasterize', _lib.ptr(pos), B, V, _lib.ptr(tri), F, h, w, _lib.ptr(rast), _lib.ptr(ws), nbytes,
+                  _lib.stream_ptr(pos.device))
+    return rast
+
+
+def interpolate(attr, rast, tri):
+    """dr.interpolate(attr, rast, tri)[0]: attr [1 or B, V, A] -> [B,h,w,A]."""
+    attr = attr.float().contiguous()
+    tri = tri.to(torch.int32).contiguous()
+    B, h, w, _ = rast.shape
+    out = torch.empty(B, h, w, attr.shape[-1], dtype=torch.float32, device=rast.device)
+    with torch.cuda.device(rast.device):
+        _lib.call('mve_interpolate', _lib.ptr(attr), attr.shape[0], attr.shape[1], attr.shape[2], _lib.ptr(rast.contiguous()), B, h, w,
+                  _lib.ptr(tri), tri.shape[0], _lib.ptr(out), _lib.stream_ptr(rast.device))
+    return out
+
+
+class MeshRenderer:
+    """Geometry half of the reference's MeshRenderer.forward (base_mesh_renderer.py:207-300) for one mesh:
+    vertex transform, rasterise, interpolated inverse depth and camera-space normals, alpha.  Texturing (dr.texture with
+    mip-maps), shading_fun re-shading and dr.antialias are not implemented yet (next rows of SURVEY section 8)."""
+
+    def __init__(self, near=0.1, far=10, ssaa=1):
+        self.near, self.far, self.ssaa = near, far, ssaa
+
+    def project(self, v, poses, intrinsics, h, w):
+        """v [V,3], poses [b,3,4] c2w (OpenCV), intrinsics [b,4] -> (v_cam [b,V,3], v_clip [b,V,4]); :222-237."""
+        r_c2w = torch.cat([poses[:, :3, :1], -poses[:, :3, 1:3]], dim=-1)         # opencv -> opengl
+        proj = poses.new_zeros(poses.shape[0], 4, 4)
+        proj[:, 0, 0] = 2 * intrinsics[:, 0] / w
+        proj[:, 0, 2] = -2 * intrinsics[:, 2] / w + 1
+        proj[:, 1, 1] = -2 * intrinsics[:, 1] / h
+        proj[:, 1, 2] = -2 * intrinsics[:, 3] / h + 1
+        proj[:, 2, 2] = -(self.far + self.near) / (self.far - self.near)
+        proj[:, 2, 3] = -(2 * self.far * self.near) / (self.far - self.near)
+        proj[:, 3, 2] = -1
+        v_cam = (v[None] - poses[:, None, :3, 3]) @ r_c2w
+        v_clip = torch.nn.functional.pad(v_cam, (0, 1), value=1.0) @ proj.transpose(-1, -2)
+        return v_cam, v_clip, r_c2w
+
+    def __call__(self, v, f, vn, fn, poses, intrinsics, h, w, normal_bg=(0.5, 0.5, 1.0)):
+        if self.ssaa > 1:
+            h, w, intrinsics = h * self.ssaa, w * self.ssaa, intrinsics * self.ssaa
+        v_cam, v_clip, r_c2w = self.project(v.float(), poses.float(), intrinsics.float(), h, w)
+        rast = rasterize(v_clip, f, (h, w))
+        fg = rast[..., 3] > 0
+        depth = 1 / interpolate(-v_cam[..., 2:3].contiguous(), rast, f)[..., 0]
+        depth = depth.masked_fill(~fg, 0)
+        normal = torch.nn.functional.normalize(interpolate(vn[None], rast, fn), dim=-1)
+        rot_normal = (normal @ r_c2w[:, None]) / 2 + 0.5
+        rot_normal[~fg] = rot_normal.new_tensor(normal_bg)
+        return dict(rast=rast, alpha=fg.float()[..., None], depth=depth, normal=rot_normal)

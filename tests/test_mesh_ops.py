@@ -1,0 +1,93 @@
+"""Texture-space ops of the mesh path against outputs of the REFERENCE's own functions
+(tests/golden/reference_py.npz, produced by executing lib/ops/edge_dilation.py in make_reference_py_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'reference_py.npz')
+
+
+@pytest.mark.gpu
+def test_edge_dilation_matches_reference_output(lib):
+    from mvedit_amd.mesh_ops import edge_dilation
+    g = np.load(GOLD)
+    img, mask = torch.from_numpy(g['dil_img']).cuda(), torch.from_numpy(g['dil_mask']).cuda()
+    out = edge_dilation(img, mask, radius=3, iters=7)
+    assert torch.equal(out.cpu(), torch.from_numpy(g['dil_out_r3_i7'])), 'bit-exact: the op only copies texels'
+    out = edge_dilation(img, mask, radius=1, iters=2)
+    assert torch.equal(out.cpu(), torch.from_numpy(g['dil_out_r1_i2']))
+    assert edge_dilation(img, mask, radius=0) is img
+    # atlas-sized input (BASELINE: 1024^2 albedo): idempotent once the mask is full, valid texels never change
+    big = torch.rand(1, 3, 1024, 1024, device='cuda')
+    m = (torch.rand(1, 1, 1024, 1024, device='cuda') > 0.6).float()
+    d = edge_dilation(big * m, m, 3, 7)
+    assert torch.equal((d * m), big * m)
+    assert (d.amax(1, keepdim=True) > 0).float().mean() > 0.99
+
+
+def _clip_positions(v, n_views, S, seed=0):
+    """Project with the reference's conventions (base_mesh_renderer.py:222-237) in numpy float32."""
+    from oracle import nerf_oracle  # noqa: F401  (shared golden poses)
+    g = np.load(GOLD)
+    poses = g['poses'][:n_views, :3].astype(np.float32)
+    f = S / (2 * np.tan(np.deg2rad(15)))
+    intr = np.tile(np.array([[f, f, S / 2, S / 2]], np.float32), (n_views, 1))
+    return poses, intr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,subdiv', [(64, 2), (256, 4), (512, 5)])
+def test_rasterize_bit_exact_vs_oracle(lib, S, subdiv):
+    from mvedit_amd.mesh_ops import MeshRenderer, rasterize, interpolate
+    from oracle import raster as OR
+    from scene import icosphere
+    v, f = icosphere(subdiv, 0.6)
+    v = v + np.random.default_rng(0).normal(0, 0.004, v.shape).astype(np.float32)     # break symmetry / create thin slivers
+    poses, intr = _clip_positions(v, 3, S)
+    mr = MeshRenderer(near=0.01, far=100)
+    v_cam, v_clip, _ = mr.project(torch.from_numpy(v).cuda(), torch.from_numpy(poses).cuda(), torch.from_numpy(intr).cuda(), S, S)
+    rast_h = rasterize(v_clip, torch.from_numpy(f).cuda(), (S, S))
+    rast_o = OR.rasterize(v_clip.cpu().numpy(), f, (S, S))
+    ids_h, ids_o = rast_h[..., 3].cpu().numpy(), rast_o[..., 3]
+    assert (ids_h == ids_o).all(), f'triangle-id buffer differs at {(ids_h != ids_o).sum()} pixels'
+    assert (rast_h.cpu().numpy() == rast_o).all(), 'u, v, z/w must be bit-exact too (same float ops, no contraction)'
+    cover = (ids_o > 0).mean()
+    assert 0.05 < cover < 0.6
+    # interpolation of arbitrary attributes (own index buffer), broadcast and per-view
+    rng = np.random.default_rng(1)
+    attr = rng.normal(size=(1, v.shape[0], 5)).astype(np.float32)
+    np.testing.assert_allclose(interpolate(torch.from_numpy(attr).cuda(), rast_h, torch.from_numpy(f).cuda()).cpu().numpy(),
+                               OR.interpolate(attr, rast_o, f), rtol=1e-6, atol=1e-6)
+    out = interpolate(v_cam[..., 2:3].contiguous(), rast_h, torch.from_numpy(f).cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, OR.interpolate(v_cam[..., 2:3].cpu().numpy(), rast_o, f), rtol=1e-6, atol=1e-6)
+    # a triangle far larger than the small-box limit (swept by a whole block) in front of everything, plus degenerate input
+    big = np.array([[[-0.9, -0.9, -0.5, 1], [0.9, -0.8, -0.5, 1], [0.0, 0.9, -0.5, 1], [0, 0, 0, 0], [0.5, 0.5, 0.2, -1]]], np.float32)
+    tri = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 4], [1, 1, 2]], np.int32)
+    r_h = rasterize(torch.from_numpy(big).cuda(), torch.from_numpy(tri).cuda(), (200, 300)).cpu().numpy()
+    r_o = OR.rasterize(big, tri, (200, 300))
+    assert (r_h == r_o).all() and (r_o[..., 3] == 1).sum() > 10000 and (r_o[..., 3] > 1).sum() == 0
+
+
+@pytest.mark.gpu
+def test_mesh_renderer_geometry_seam(lib):
+    """Rendering the icosphere with the reference's camera conventions: depth = 1/z of the front surface, outward normals."""
+    from mvedit_amd.mesh_ops import MeshRenderer
+    from scene import icosphere
+    v, f = icosphere(4, 0.6)
+    vn = v / np.linalg.norm(v, axis=-1, keepdims=True)
+    S = 128
+    poses, intr = _clip_positions(v, 4, S)
+    mr = MeshRenderer(near=0.01, far=100)
+    t = lambda a: torch.from_numpy(a).cuda()
+    out = mr(t(v), t(f), t(vn.astype(np.float32)), t(f), t(poses), t(intr), S, S)
+    alpha, depth, normal = out['alpha'][..., 0], out['depth'], out['normal']
+    # silhouette: a sphere of radius 0.6 seen from 3.7 -> angular radius asin(0.6/3.7); fov 30 deg
+    frac = np.pi * (np.tan(np.arcsin(0.6 / 3.7)) / np.tan(np.deg2rad(15))) ** 2 / 4
+    assert abs(alpha.mean().item() - frac) < 0.01
+    c = S // 2
+    assert abs(1 / depth[:, c, c].mean().item() - (3.7 - 0.6)) < 0.02                 # centre pixel sees the nearest point
+    # camera-space normal at the centre points at the camera: (0,0,1) -> colour (0.5, 0.5, 1.0)
+    np.testing.assert_allclose(normal[:, c, c].mean(0).cpu().numpy(), [0.5, 0.5, 1.0], atol=0.03)
+    assert torch.equal(normal[alpha == 0], normal.new_tensor([0.5, 0.5, 1.0]).expand(int((alpha == 0).sum()), 3))
