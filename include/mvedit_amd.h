@@ -317,6 +317,26 @@ MVE_API int mve_rasterize(const float* d_pos, int B, int V, const int32_t* d_tri
 MVE_API int mve_interpolate(const float* d_attr, int Battr, int Vattr, int A, const float* d_rast, int B, int H, int W,
                             const int32_t* d_tri, int F, float* d_out, void* stream);
 
+/* Multi-view texture back-projection, the device part of MeshRenderer.bake_multiview
+ * (lib/models/decoders/mesh_renderer/base_mesh_renderer.py:507-603).  Bilinear filter with wrap addressing; the reference's
+ * default 'linear-mipmap-linear' (nvdiffrast) is not reproduced -- see DESIGN.md.
+ *   splat_visibility : sum of bilinear footprint weights of every foreground pixel (texc [n,h,w,2] uv, rast [n,h,w,4]) per
+ *                      texel = d sum(texture(ones, texc)) / d ones (:547-552); d_vis_u64 [n][map][map] 2^-32 fixed point.
+ *   view_weight      : clamp(-normal.dir, 0)^pow * alpha from the 1/z depth map, then the 5x5 min-pool (:554-566);
+ *                      d_tmp and d_out are [n,h,w] f32.
+ *   bake_accumulate  : per texel and view, fetch (rgb, view weight) at the texel's projected position (v_img [n,V,2] =
+ *                      clip.xy/w*0.5+0.5 interpolated over the UV-space raster tex_rast [map,map,4] with faces d_f) and
+ *                      add (rgb*weight, weight), weight = view_weight * visibility, into d_accum [map,map,4] (:568-582).
+ *   bake_finalize    : albedo = sum / max(weight, 1e-8) -> [3][map][map] (ready for mve_edge_dilation). */
+MVE_API int mve_splat_visibility(const float* d_texc, const float* d_rast, int n, int h, int w, int map_size, void* d_vis_u64,
+                                 void* stream);
+MVE_API int mve_view_weight(const float* d_depth, const float* d_alpha, const float* d_intrinsics, int n, int h, int w,
+                            float cos_weight_pow, float* d_tmp, float* d_out, void* stream);
+MVE_API int mve_bake_accumulate(const float* d_tex_rast, const int32_t* d_f, int F, const float* d_v_img, int V,
+                                const float* d_images, const float* d_w_img, const void* d_vis_u64, int n, int h, int w,
+                                int map_size, float* d_accum, void* stream);
+MVE_API int mve_bake_finalize(const float* d_accum, int map_size, float* d_albedo_chw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,3 +227,207 @@ int mve_interpolate(const float* d_attr, int Battr, int Vattr, int A, const floa
 }
 
 }  // extern "C"
+
+// =========================================================================================================
+// Multi-view texture back-projection (MeshRenderer.bake_multiview, base_mesh_renderer.py:507-603).
+//
+// The reference obtains per-texel visibility as the gradient of dr.texture(ones, texc) w.r.t. the texture, i.e. the sum of
+// the texture-filter footprint weights of every screen pixel that samples the texel.  For the bilinear filter that is a
+// scatter-add of the four bilinear weights of each foreground pixel, which is what k_splat_visibility does -- in 2^-32
+// fixed point through 64-bit integer atomics, so the result does not depend on the order the atomics land (deterministic).
+// The reference's default filter is 'linear-mipmap-linear' (nvdiffrast, unavailable here); the mip pyramid is NOT
+// reproduced: both the visibility splat and the image fetch use the plain bilinear filter with wrap addressing
+// (nvdiffrast's default boundary mode).  DESIGN.md lists this as a known deviation.
+// =========================================================================================================
+namespace {
+
+__device__ __forceinline__ int wrapi(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+
+// bilinear taps of texture coordinate (u,v) on an n_x x n_y grid with texel centres at (i + 0.5)/n
+__device__ __forceinline__ void bilinear_taps(float u, float v, int nx, int ny, int (&ix)[2], int (&iy)[2], float (&wx)[2], float (&wy)[2]) {
+    const float x = u * (float)nx - 0.5f, y = v * (float)ny - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    wx[1] = x - fx; wx[0] = 1.0f - wx[1];
+    wy[1] = y - fy; wy[0] = 1.0f - wy[1];
+    ix[0] = wrapi((int)fx, nx); ix[1] = wrapi((int)fx + 1, nx);
+    iy[0] = wrapi((int)fy, ny); iy[1] = wrapi((int)fy + 1, ny);
+}
+
+__global__ __launch_bounds__(RB) void k_splat_visibility(const float* __restrict__ texc /*[n,h,w,2]*/, const float* __restrict__ rast,
+                                                         size_t npix_total, size_t npix_view, int map, unsigned long long* __restrict__ acc) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= npix_total) return;
+    if (!(rast[4 * i + 3] > 0.0f)) return;
+    const size_t view = i / npix_view;
+    int ix[2], iy[2];
+    float wx[2], wy[2];
+    bilinear_taps(texc[2 * i], texc[2 * i + 1], map, map, ix, iy, wx, wy);
+    unsigned long long* a = acc + view * (size_t)map * map;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double wgt = (double)(wx[k] * wy[j]);
+            atomicAdd(a + (size_t)iy[j] * map + ix[k], (unsigned long long)(wgt * 4294967296.0 + 0.5));
+        }
+}
+
+// cos weight of a view pixel: clamp(-n.dir, 0)^pow * alpha with n = depth_to_normal(depth, normalised dirs, 'opencv')*2-1
+// (base_mesh_renderer.py:559-564)
+__global__ __launch_bounds__(RB) void k_view_cos_weight(const float* __restrict__ depth, const float* __restrict__ alpha,
+                                                        const float* __restrict__ intr, int nb, int h, int w, float pw, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= (size_t)nb * h * w) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h), v = (int)(i / ((size_t)w * h));
+    const float fx = intr[4 * v], fy = intr[4 * v + 1], cx = intr[4 * v + 2], cy = intr[4 * v + 3];
+    auto dirn = [&](int xx, int yy, float (&d)[3]) {
+        const float dx = ((float)xx + 0.5f - cx) / fx, dy = ((float)yy + 0.5f - cy) / fy;
+        const float n = fmaxf(sqrtf(dx * dx + dy * dy + 1.0f), 1e-12f);
+        d[0] = dx / n; d[1] = dy / n; d[2] = 1.0f / n;
+    };
+    auto point = [&](int xx, int yy, float (&p)[3]) {
+        float d[3];
+        dirn(xx, yy, d);
+        const float inv = 1.0f / fmaxf(depth[((size_t)v * h + yy) * w + xx], 1e-6f);
+        p[0] = d[0] * inv; p[1] = d[1] * inv; p[2] = d[2] * inv;
+    };
+    const int xr = x < w - 1 ? x : w - 2, xl = x > 0 ? x - 1 : 0, yd = y < h - 1 ? y : h - 2, yu = y > 0 ? y - 1 : 0;
+    float a[3], b[3], right[3], left[3], up[3], down[3];
+    point(xr + 1, y, a); point(xr, y, b);
+    for (int k = 0; k < 3; ++k) right[k] = a[k] - b[k];
+    point(xl + 1, y, a); point(xl, y, b);
+    for (int k = 0; k < 3; ++k) left[k] = -(a[k] - b[k]);
+    point(x, yu + 1, a); point(x, yu, b);
+    for (int k = 0; k < 3; ++k) up[k] = -(a[k] - b[k]);
+    point(x, yd + 1, a); point(x, yd, b);
+    for (int k = 0; k < 3; ++k) down[k] = a[k] - b[k];
+    float s[3] = {0.f, 0.f, 0.f};
+    auto acc_cross = [&](const float (&p)[3], const float (&q)[3]) {
+        const float c0 = p[1] * q[2] - p[2] * q[1], c1 = p[2] * q[0] - p[0] * q[2], c2 = p[0] * q[1] - p[1] * q[0];
+        const float n = fmaxf(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), 1e-12f);
+        s[0] += c0 / n; s[1] += c1 / n; s[2] += c2 / n;
+    };
+    acc_cross(right, up); acc_cross(up, left); acc_cross(left, down); acc_cross(down, right);
+    const float n = fmaxf(sqrtf(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]), 1e-12f);
+    // opencv format: no sign flip; the reference maps to [0,1] and back (x/2+0.5)*2-1
+    float nn[3];
+    for (int k = 0; k < 3; ++k) nn[k] = (s[k] / n / 2 + 0.5f) * 2 - 1;
+    float d[3];
+    dirn(x, y, d);
+    const float c = fmaxf(-(nn[0] * d[0] + nn[1] * d[1] + nn[2] * d[2]), 0.0f);
+    out[i] = powf(c, pw) * alpha[i];
+}
+
+// -max_pool2d(-x, 5, stride 1, padding 2): minimum over the in-image part of the 5x5 window
+__global__ __launch_bounds__(RB) void k_minpool5(const float* __restrict__ in, int nb, int h, int w, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= (size_t)nb * h * w) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h);
+    const float* img = in + (i / ((size_t)w * h)) * (size_t)w * h;
+    float m = INFINITY;
+    for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) m = fminf(m, img[(size_t)yy * w + xx]);
+        }
+    out[i] = m;
+}
+
+// per texel: for every view of the batch fetch (image rgb, view weight) at the texel's projected position and accumulate
+// sum(rgb * weight), sum(weight) with weight = view_weight * visibility     (base_mesh_renderer.py:566-582)
+__global__ __launch_bounds__(RB) void k_bake_accumulate(const float* __restrict__ tex_rast, const int32_t* __restrict__ f, int F,
+                                                        const float* __restrict__ v_img /*[n,V,2]*/, int V, const float* __restrict__ images /*[n,h,w,3]*/,
+                                                        const float* __restrict__ w_img /*[n,h,w]*/, const unsigned long long* __restrict__ vis /*[n,map,map]*/,
+                                                        int n, int h, int w, int map, float* __restrict__ accum /*[map,map,4]*/) {
+    const size_t t = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (t >= (size_t)map * map) return;
+    const f32x4 r = reinterpret_cast<const f32x4*>(tex_rast)[t];
+    const int id = (int)r[3] - 1;
+    f32x4 acc = reinterpret_cast<f32x4*>(accum)[t];
+    for (int v = 0; v < n; ++v) {
+        float cu = 0.f, cv = 0.f;                           // dr.interpolate gives 0 on empty texels
+        if (id >= 0 && id < F) {
+            const float* vi = v_img + (size_t)v * V * 2;
+            const int i0 = f[3 * id], i1 = f[3 * id + 1], i2 = f[3 * id + 2];
+            const float bw = 1.0f - r[0] - r[1];
+            cu = r[0] * vi[2 * i0] + r[1] * vi[2 * i1] + bw * vi[2 * i2];
+            cv = r[0] * vi[2 * i0 + 1] + r[1] * vi[2 * i1 + 1] + bw * vi[2 * i2 + 1];
+        }
+        int ix[2], iy[2];
+        float wx[2], wy[2];
+        bilinear_taps(cu, cv, w, h, ix, iy, wx, wy);
+        const float* img = images + (size_t)v * h * w * 3;
+        const float* wi = w_img + (size_t)v * h * w;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, cw = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float wt = wx[k] * wy[j];
+                const size_t p = (size_t)iy[j] * w + ix[k];
+                c0 += wt * img[3 * p]; c1 += wt * img[3 * p + 1]; c2 += wt * img[3 * p + 2];
+                cw += wt * wi[p];
+            }
+        const float visib = (float)((double)vis[(size_t)v * map * map + t] * (1.0 / 4294967296.0));
+        const float weight = cw * visib;
+        acc[0] += c0 * weight; acc[1] += c1 * weight; acc[2] += c2 * weight; acc[3] += weight;
+    }
+    reinterpret_cast<f32x4*>(accum)[t] = acc;
+}
+
+__global__ __launch_bounds__(RB) void k_bake_finalize(const float* __restrict__ accum, size_t ntex, float* __restrict__ albedo_chw) {
+    const size_t t = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (t >= ntex) return;
+    const f32x4 a = reinterpret_cast<const f32x4*>(accum)[t];
+    const float d = fmaxf(a[3], 1e-8f);
+    albedo_chw[t] = a[0] / d; albedo_chw[ntex + t] = a[1] / d; albedo_chw[2 * ntex + t] = a[2] / d;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mve_splat_visibility(const float* d_texc, const float* d_rast, int n, int h, int w, int map_size, void* d_vis_u64, void* stream) {
+    const size_t total = (size_t)n * h * w;
+    if (total == 0) return MVE_OK;
+    MVE_CHECK(d_texc && d_rast && d_vis_u64 && map_size > 0, MVE_ERR_ARG, "splat_visibility: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    MVE_HIP(hipMemsetAsync(d_vis_u64, 0, (size_t)n * map_size * map_size * 8, s));
+    k_splat_visibility<<<mve_cdiv(total, RB), RB, 0, s>>>(d_texc, d_rast, total, (size_t)h * w, map_size, (unsigned long long*)d_vis_u64);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_view_weight(const float* d_depth, const float* d_alpha, const float* d_intrinsics, int n, int h, int w, float cos_weight_pow,
+                    float* d_tmp, float* d_out, void* stream) {
+    const size_t total = (size_t)n * h * w;
+    if (total == 0) return MVE_OK;
+    MVE_CHECK(d_depth && d_alpha && d_intrinsics && d_tmp && d_out && h >= 2 && w >= 2, MVE_ERR_ARG, "view_weight: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    k_view_cos_weight<<<mve_cdiv(total, RB), RB, 0, s>>>(d_depth, d_alpha, d_intrinsics, n, h, w, cos_weight_pow, d_tmp);
+    MVE_LAUNCH_CHECK();
+    k_minpool5<<<mve_cdiv(total, RB), RB, 0, s>>>(d_tmp, n, h, w, d_out);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_bake_accumulate(const float* d_tex_rast, const int32_t* d_f, int F, const float* d_v_img, int V, const float* d_images,
+                        const float* d_w_img, const void* d_vis_u64, int n, int h, int w, int map_size, float* d_accum, void* stream) {
+    if (n == 0 || map_size == 0) return MVE_OK;
+    MVE_CHECK(d_tex_rast && d_f && d_v_img && d_images && d_w_img && d_vis_u64 && d_accum, MVE_ERR_ARG, "bake_accumulate: null pointer");
+    k_bake_accumulate<<<mve_cdiv((size_t)map_size * map_size, RB), RB, 0, (hipStream_t)stream>>>(
+        d_tex_rast, d_f, F, d_v_img, V, d_images, d_w_img, (const unsigned long long*)d_vis_u64, n, h, w, map_size, d_accum);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_bake_finalize(const float* d_accum, int map_size, float* d_albedo_chw, void* stream) {
+    if (map_size == 0) return MVE_OK;
+    MVE_CHECK(d_accum && d_albedo_chw, MVE_ERR_ARG, "bake_finalize: null pointer");
+    const size_t ntex = (size_t)map_size * map_size;
+    k_bake_finalize<<<mve_cdiv(ntex, RB), RB, 0, (hipStream_t)stream>>>(d_accum, ntex, d_albedo_chw);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+}  // extern "C"

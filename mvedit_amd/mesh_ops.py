@@ -84,3 +84,78 @@ class MeshRenderer:
         rot_normal = (normal @ r_c2w[:, None]) / 2 + 0.5
         rot_normal[~fg] = rot_normal.new_tensor(normal_bg)
         return dict(rast=rast, alpha=fg.float()[..., None], depth=depth, normal=rot_normal)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def bake_multiview(self, meshes, images, alphas, poses, intrinsics, map_size=1024, cos_weight_pow=8.0, base_weight=0.0,
+                       render_bs=8, return_debug=False):
+        """Texture back-projection with the reference's signature (base_mesh_renderer.py:507-603).
+
+        meshes: a list with ONE object exposing v [V,3], f [F,3], vt [Vt,2], ft [F,3] (and optionally albedo [h,w,3|4]);
+        images [1,n,h,w,3], alphas [1,n,h,w,1], poses [1,n,3|4,4], intrinsics [1,n,4].  Sets mesh.albedo [map,map,4] and
+        mesh.textureless = False, returns [mesh].  Bilinear (not mip-mapped) filtering -- see csrc/raster.hip."""
+        assert len(meshes) == 1, 'only support one mesh'
+        mesh = meshes[0]
+        images, alphas = images[0].float().contiguous(), alphas[0].float().contiguous()
+        n, h, w, _ = images.shape
+        dev = images.device
+        poses = poses[0].expand(n, -1, -1).float()
+        intrinsics = intrinsics[0].expand(n, -1).float().contiguous()
+        v, f = mesh.v.detach().float(), mesh.f.to(torch.int32).contiguous()
+        vt, ft = mesh.vt.float().contiguous(), mesh.ft.to(torch.int32).contiguous()
+        sp = _lib.stream_ptr(dev)
+
+        vt_clip = torch.cat([vt * 2 - 1, vt.new_tensor([[0., 1.]]).expand(vt.size(0), -1)], dim=-1)
+        tex_rast = rasterize(vt_clip[None], ft, (map_size, map_size))[0].contiguous()
+        valid = tex_rast[..., 3] > 0
+        accum = torch.zeros(map_size, map_size, 4, dtype=torch.float32, device=dev)
+        debug = dict(vis=[], wimg=[], tex_rast=tex_rast)
+
+        for i0 in range(0, n, render_bs):
+            sl = slice(i0, min(i0 + render_bs, n))
+            bs = sl.stop - sl.start
+            v_cam, v_clip, _ = self.project(v, poses[sl], intrinsics[sl], h, w)
+            rast = rasterize(v_clip, f, (h, w))
+            texc = interpolate(vt[None], rast, ft)
+            depth = 1 / interpolate(-v_cam[..., 2:3].contiguous(), rast, f)[..., 0]
+            depth = depth.masked_fill(~(rast[..., 3] > 0), 0).contiguous()
+            v_img = (v_clip[..., :2] / v_clip[..., 3:] * 0.5 + 0.5).contiguous()
+            vis = torch.empty(bs, map_size, map_size, dtype=torch.int64, device=dev)
+            tmp = torch.empty(bs, h, w, dtype=torch.float32, device=dev)
+            w_img = torch.empty_like(tmp)
+            img_b, alpha_b, intr_b = images[sl].contiguous(), alphas[sl].contiguous(), intrinsics[sl].contiguous()
+            with torch.cuda.device(dev):
+                _lib.call('mve_splat_visibility', _lib.ptr(texc), _lib.ptr(rast), bs, h, w, map_size, _lib.ptr(vis), sp)
+                _lib.call('mve_view_weight', _lib.ptr(depth), _lib.ptr(alpha_b), _lib.ptr(intr_b), bs, h, w, float(cos_weight_pow),
+                          _lib.ptr(tmp), _lib.ptr(w_img), sp)
+                _lib.call('mve_bake_accumulate', _lib.ptr(tex_rast), _lib.ptr(f), f.shape[0], _lib.ptr(v_img), v_img.shape[1],
+                          _lib.ptr(img_b), _lib.ptr(w_img), _lib.ptr(vis), bs, h, w, map_size, _lib.ptr(accum), sp)
+            if return_debug:
+                debug['vis'].append(vis)
+                debug['wimg'].append(w_img)
+
+        if base_weight > 0 and getattr(mesh, 'albedo', None) is not None:                     # :584-591
+            tex = mesh.albedo.float()
+            if tex.shape[0] != map_size or tex.shape[1] != map_size:
+                tex = torch.nn.functional.interpolate(tex.permute(2, 0, 1)[None], size=map_size, mode='bilinear')[0].permute(1, 2, 0)
+            wgt = (tex[..., 3:4] * valid[..., None] if tex.size(-1) == 4 else valid[..., None].float()) * (base_weight ** cos_weight_pow)
+            accum[..., :3] += tex[..., :3] * wgt
+            accum[..., 3:] += wgt
+
+        albedo = torch.empty(1, 3, map_size, map_size, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call('mve_bake_finalize', _lib.ptr(accum), map_size, _lib.ptr(albedo), sp)
+        albedo = edge_dilation(albedo, valid[None, None].float())[0].permute(1, 2, 0)
+        mesh.albedo = torch.cat([albedo.clamp(min=0, max=1), torch.ones_like(albedo[..., :1])], dim=-1)
+        mesh.textureless = False
+        if return_debug:
+            debug.update(accum=accum, valid=valid)
+            return [mesh], debug
+        return [mesh]
+
+
+class Mesh:
+    """Minimal stand-in for lib.models.decoders.mesh_renderer.mesh_utils.Mesh: the attributes the render/bake path touches."""
+
+    def __init__(self, v, f, vt=None, ft=None, vn=None, fn=None, albedo=None):
+        self.v, self.f, self.vt, self.ft, self.vn, self.fn, self.albedo = v, f, vt, ft, vn, fn, albedo
+        self.textureless = albedo is None

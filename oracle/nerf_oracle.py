@@ -182,8 +182,8 @@ def _normalize(v):
     return v / np.maximum(np.linalg.norm(v, axis=-1, keepdims=True), np.float32(1e-12))
 
 
-def depth_to_normal(depth, directions):
-    """geometry_utils.py:119-148 (format='opengl'); depth = 1/z."""
+def depth_to_normal(depth, directions, format='opengl'):
+    """geometry_utils.py:119-148; depth = 1/z."""
     xyz = directions / np.maximum(depth[..., None], np.float32(1e-6))
     dx = xyz[..., :, 1:, :] - xyz[..., :, :-1, :]
     dy = xyz[..., 1:, :, :] - xyz[..., :-1, :, :]
@@ -194,7 +194,10 @@ def depth_to_normal(depth, directions):
     n = _normalize(_normalize(np.cross(right, up)) + _normalize(np.cross(up, left)) + _normalize(np.cross(left, down))
                    + _normalize(np.cross(down, right)))
     n = n.astype(np.float32).copy()
-    n[..., 1:3] = -n[..., 1:3]
+    if format == 'opengl':
+        n[..., 1:3] = -n[..., 1:3]
+    else:
+        assert format == 'opencv'
     return (n / 2 + 0.5).astype(np.float32)
 
 

@@ -86,3 +86,21 @@ def icosphere(subdiv=3, radius=0.6):
             nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
         f = nf
     return (np.array(v) * radius).astype(np.float32), np.array(f, np.int32)
+
+
+def face_atlas(f, pad=0.08):
+    """One chart per triangle, two triangles per grid cell (what a UV unwrapper yields in the limit): vt [3F,2], ft [F,3]."""
+    F = f.shape[0]
+    cells = int(np.ceil(np.sqrt((F + 1) // 2)))
+    vt = np.zeros((3 * F, 2), np.float32)
+    lo, hi = pad, 1.0 - pad
+    for i in range(F):
+        c = i // 2
+        ox, oy = c % cells, c // cells
+        if i % 2 == 0:
+            tri = np.array([[lo, lo], [hi - pad, lo], [lo, hi - pad]], np.float32)
+        else:
+            tri = np.array([[hi, hi], [lo + pad, hi], [hi, lo + pad]], np.float32)
+        vt[3 * i:3 * i + 3] = (tri + np.array([ox, oy], np.float32)) / cells
+    ft = np.arange(3 * F, dtype=np.int32).reshape(F, 3)
+    return vt, ft
