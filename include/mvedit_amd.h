@@ -247,6 +247,20 @@ MVE_API int mve_unet_forward(void* handle, int phase, const void* d_sample, int 
                              const void* d_ctx, int B, int H, int W, int ctx_len, int num_cross_attn_imgs,
                              const void* const* down_residuals, const void* d_mid_residual, int residuals_nhwc,
                              void* d_out, void* d_workspace, size_t workspace_bytes, float* op_ms, void* stream);
+/* Attention-processor options of the reference, applied to every later plan/forward of this engine:
+ *   ip_tokens > 0 : IPAttnProcessor2_0 (lib/models/architecture/ip_adapter/attention_processor.py:301-396) -- the last ip_tokens rows of
+ *                   encoder_hidden_states are projected with `<block>.attn2.processor.to_k_ip/to_v_ip.weight` (loaded through
+ *                   mve_unet_load_param under those names) and attended to in a second softmax, added with ip_scale.
+ *   ref_mode      : ReferenceAttnProc (lib/models/architecture/diffusers.py:646-673) / ReferenceOnlyAttnProc
+ *                   (lib/pipelines/zero123plus.py:43-77).  1 = mode 'w': every self-attention layer stores its keys/values;
+ *                   2 = modes 'r' / 'm': every self-attention layer appends the stored tokens to its keys/values.  The first
+ *                   ref_skip batch items neither store nor read (is_cfg_guidance).  ref_H x ref_W is the latent size of the
+ *                   pass that wrote the store (mode 2 only).  d_ref_store is caller-owned device memory of at least
+ *                   mve_unet_ref_store_bytes(B, ref_H, ref_W, ref_skip) bytes that must stay valid between the two passes. */
+MVE_API int mve_unet_set_attention(void* handle, int ip_tokens, float ip_scale, int ref_mode, int ref_H, int ref_W, int ref_skip,
+                                   void* d_ref_store, size_t ref_store_bytes);
+MVE_API size_t mve_unet_ref_store_bytes(void* handle, int B, int ref_H, int ref_W, int ref_skip);
+
 /* op i of the cached plan: class, flops, label; returns 1 if the op belongs to unet_enc, 2 for unet_dec */
 MVE_API int mve_unet_op_info(void* handle, int i, int* cls, double* flops, char* label, int label_len);
 

@@ -19,6 +19,7 @@
 
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -117,7 +118,7 @@ struct Param {   // one engine-owned packed tensor (or a slice view of one)
 enum OpClass { OC_CONV = 0, OC_LINEAR = 1, OC_ATTN = 2, OC_NORM = 3, OC_OTHER = 4, OC_COUNT = 5 };
 
 struct Ref {
-    enum Kind { NUL, WS, WT, SAMPLE, TIMESTEPS, CTX, OUT, DOWNRES, MIDRES } kind = NUL;
+    enum Kind { NUL, WS, WT, SAMPLE, TIMESTEPS, CTX, OUT, DOWNRES, MIDRES, REFSTORE } kind = NUL;
     size_t off = 0;
     int idx = 0;
 };
@@ -126,6 +127,7 @@ struct Run {
     unsigned char* ws; unsigned char* wt;
     const void* sample; const float* timesteps; const void* ctx; void* out;
     const void* const* down_res; const void* mid_res;
+    unsigned char* ref_store;
     hipStream_t stream;
     void* p(const Ref& r) const {
         switch (r.kind) {
@@ -137,6 +139,7 @@ struct Run {
             case Ref::OUT: return out;
             case Ref::DOWNRES: return (void*)down_res[r.idx];
             case Ref::MIDRES: return (void*)mid_res;
+            case Ref::REFSTORE: return ref_store + r.off;
             default: return nullptr;
         }
     }
@@ -149,8 +152,27 @@ struct Op {
     std::function<int(const Run&)> fn;
 };
 
+// attention-processor options of the reference that change the op list
+//   ip_tokens > 0 : IPAttnProcessor2_0 (lib/models/architecture/ip_adapter/attention_processor.py:301-396): the last ip_tokens rows
+//                   of encoder_hidden_states go through to_k_ip/to_v_ip and a second softmax, added with ip_scale;
+//   ref_mode      : ReferenceAttnProc / ReferenceOnlyAttnProc (lib/models/architecture/diffusers.py:646-673,
+//                   lib/pipelines/zero123plus.py:43-77): 1 = 'w' (store the self-attention keys/values of every layer),
+//                   2 = 'r'/'m' (append the stored tokens to every self-attention's keys/values); ref_skip leading batch items
+//                   neither store nor read (is_cfg_guidance); ref_H x ref_W = latent size of the pass that wrote the store.
+struct AttnOpts {
+    int ip_tokens = 0; float ip_scale = 1.0f;
+    int ref_mode = 0, ref_H = 0, ref_W = 0, ref_skip = 0;
+    bool operator==(const AttnOpts& o) const {
+        return ip_tokens == o.ip_tokens && ip_scale == o.ip_scale && ref_mode == o.ref_mode && ref_H == o.ref_H && ref_W == o.ref_W &&
+               ref_skip == o.ref_skip;
+    }
+};
+
 struct Plan {
     int B = 0, H = 0, W = 0, n_img = 1, has_res = 0, io_dtype = 0, res_nhwc = 0, ctx_len = 0;
+    AttnOpts ao;
+    size_t ref_store_bytes = 0;
+    unsigned long long last_use = 0;
     std::vector<Op> ops;
     size_t enc_end = 0;        // ops[0, enc_end) = unet_enc
     size_t ws_bytes = 0;
@@ -206,8 +228,13 @@ struct Unet {
     size_t slab_bytes = 0;
     int sum_temb = 0, sum_kv = 0;
     std::map<std::string, int> temb_off, kv_off;   // resnet prefix -> column offset; attn2 prefix -> column offset
-    Plan plan;
-    bool plan_valid = false;
+    std::vector<std::unique_ptr<Plan>> plans;   // small LRU cache: 2-pass mode alternates write/read/decode plans every step
+    Plan* cur = nullptr;
+    unsigned long long tick = 0;
+    AttnOpts ao;
+    unsigned char* ref_store = nullptr;
+    size_t ref_store_bytes = 0;
+    int n_ip_loaded = 0, n_xf_layers = 0;
     std::string err;
 };
 
@@ -298,6 +325,8 @@ void layout_params(Unet& u) {
             u.sum_kv += 2 * x.c;
         }
     sb.add("ctx_kv.w", (size_t)u.sum_kv * c.ctx_dim, false);
+    sb.add("ip_kv.w", (size_t)u.sum_kv * c.ctx_dim, false);      // IP-Adapter to_k_ip / to_v_ip, same column layout (optional weights)
+    u.n_xf_layers = (int)u.kv_off.size();
     for (auto& x : xs) {
         const size_t C = x.c;
         sb.add(x.name + ".norm.g", C, true); need(x.name + ".norm.weight");
@@ -439,6 +468,13 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         MVE_CHECK(u.kv_off.count(b), MVE_ERR_ARG, "load_param: unknown attention block %s", b.c_str());
         const long long C = shape[0];
         rc = mat(P("ctx_kv.w"), ((size_t)u.kv_off[b] + (size_t)which * C) * c.ctx_dim, C, c.ctx_dim, c.ctx_dim);
+    } else if (ends_with(name, ".attn2.processor.to_k_ip.weight") || ends_with(name, ".attn2.processor.to_v_ip.weight")) {
+        const int which = name[name.size() - 11] == 'k' ? 0 : 1;
+        const std::string b = name.substr(0, name.size() - std::string(".attn2.processor.to_k_ip.weight").size());
+        MVE_CHECK(u.kv_off.count(b), MVE_ERR_ARG, "load_param: unknown attention block %s", b.c_str());
+        const long long C = shape[0];
+        rc = mat(P("ip_kv.w"), ((size_t)u.kv_off[b] + (size_t)which * C) * c.ctx_dim, C, c.ctx_dim, c.ctx_dim);
+        if (rc == MVE_OK && !u.loaded.count(name)) ++u.n_ip_loaded;
     } else if (ends_with(name, ".attn2.to_q.weight")) rc = mat(P(strip(name, ".attn2.to_q.weight") + ".q2.w"), 0, shape[0], shape[1], shape[1]);
     else if (ends_with(name, ".attn1.to_out.0.weight")) rc = mat(P(strip(name, ".attn1.to_out.0.weight") + ".o1.w"), 0, shape[0], shape[1], shape[1]);
     else if (ends_with(name, ".attn1.to_out.0.bias")) rc = vec(P(strip(name, ".attn1.to_out.0.bias") + ".o1.b"), 0, shape[0], 1);
@@ -479,8 +515,11 @@ struct Builder {
     const Config& c;
     int B, dt;
     int ld_temb, ld_kv;
-    Ref tproj, ctxkv;        // hoisted projections
+    Ref tproj, ctxkv, ipkv;  // hoisted projections
     int ctx_rows_per_img = 0, ctxB = 0;
+    int Lt = 0;              // text rows of the context (ctx_rows_per_img - ip_tokens)
+    int H0 = 0;              // latent height of this pass (reference-store geometry)
+    size_t ref_off = 0;      // running offset into the reference K/V store
 
     Builder(Unet& u_, Plan& p) : u(u_), pl(p), c(u_.cfg) {}
 
@@ -554,12 +593,23 @@ struct Builder {
             return mve_layernorm(d, r.p(x), C, r.p(y), C, M, C, (const float*)r.p(g), (const float*)r.p(b), 1e-5f, r.stream);
         });
     }
-    void attn(Ref q, int ldq, Ref k, int ldk, Ref v, int ldv, Ref o, int ldo, int Bn, int Lq, int Lk, int heads, int hd) {
+    void attn(Ref q, int ldq, Ref k, int ldk, Ref v, int ldv, Ref o, int ldo, int Bn, int Lq, int Lk, int heads, int hd,
+              Ref k2 = Ref(), int ldk2 = 0, Ref v2 = Ref(), int ldv2 = 0, int Lk2 = 0, const char* what = "attention") {
         const int d = dt;
-        live(q, "attention"); live(k, "attention"); live(v, "attention"); live(o, "attention");
-        op(OC_ATTN, 4.0 * Bn * heads * (double)Lq * Lk * hd, "attention", [=](const Run& r) {
-            return mve_attention(d, r.p(q), ldq, r.p(k), ldk, r.p(v), ldv, nullptr, 0, nullptr, 0, r.p(o), ldo, Bn, Lq, Lk, 0, heads, hd,
-                                 1.0f / sqrtf((float)hd), r.stream);
+        if (Bn <= 0) return;
+        live(q, what); live(k, what); live(v, what); live(o, what);
+        op(OC_ATTN, 4.0 * Bn * heads * (double)Lq * (Lk + Lk2) * hd, what, [=](const Run& r) {
+            return mve_attention(d, r.p(q), ldq, r.p(k), ldk, r.p(v), ldv, r.p(k2), ldk2, r.p(v2), ldv2, r.p(o), ldo, Bn, Lq, Lk, Lk2, heads,
+                                 hd, 1.0f / sqrtf((float)hd), r.stream);
+        });
+    }
+    // device-to-device 2-D copy (rows x width bytes) between pitched buffers
+    void copy2d(Ref dst, size_t dpitch, Ref src, size_t spitch, size_t width, size_t rows, const char* what) {
+        if (!rows || !width) return;
+        live(dst, what); live(src, what);
+        op(OC_OTHER, 0, what, [=](const Run& r) {
+            return hipMemcpy2DAsync(r.p(dst), dpitch, r.p(src), spitch, width, rows, hipMemcpyDeviceToDevice, r.stream) == hipSuccess
+                       ? MVE_OK : MVE_ERR_HIP;
         });
     }
 
@@ -609,7 +659,30 @@ struct Builder {
             gemm(n1, C, wt(b + ".qkv.w"), C, qkv, 3 * C, M, 3 * C, C, Ref(), Ref(), 0, 0, Ref(), 0, 0, "attn1.qkv");
             rel(n1);
             Ref a = ws((size_t)M * C * e);
-            attn(qkv, 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, nb, L, L, heads, hd);
+            const AttnOpts& ao = pl.ao;
+            if (ao.ref_mode == 0) {
+                attn(qkv, 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, nb, L, L, heads, hd);
+            } else {
+                // reference attention: the store holds, per self-attention layer in execution order, the keys|values
+                // [B - ref_skip][Lref][2C] of the pass that ran in 'w' mode (to_k / to_v act per token, so K(cat[x, ref]) =
+                // cat[K(x), K(ref)] and the projected rows can be stored instead of the layer input)
+                const int div = H0 / H;
+                const int Lref = ao.ref_mode == 1 ? L : (ao.ref_H / div) * (ao.ref_W / div);
+                const int skip = ao.ref_skip, nr = nb - skip;
+                Ref st; st.kind = Ref::REFSTORE; st.off = ref_off;
+                ref_off += (size_t)nr * Lref * 2 * C * e;
+                if (ao.ref_mode == 1) {
+                    attn(qkv, 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, nb, L, L, heads, hd);
+                    copy2d(st, (size_t)2 * C * e, at(qkv, ((size_t)skip * L * 3 * C + C) * e), (size_t)3 * C * e, (size_t)2 * C * e,
+                           (size_t)nr * L, "reference K,V -> store");
+                } else {
+                    attn(qkv, 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, skip, L, L, heads, hd);
+                    const size_t o = (size_t)skip * L * 3 * C * e;
+                    attn(at(qkv, o), 3 * C, at(qkv, o + (size_t)C * e), 3 * C, at(qkv, o + (size_t)2 * C * e), 3 * C,
+                         at(a, (size_t)skip * L * C * e), C, nr, L, L, heads, hd, st, 2 * C, at(st, (size_t)C * e), 2 * C, Lref,
+                         "attention (+reference tokens)");
+                }
+            }
             rel(qkv);
             Ref h2 = ws((size_t)M * C * e);
             gemm(a, C, wt(b + ".o1.w"), C, h2, C, M, C, C, wt(b + ".o1.b"), Ref(), 0, 0, h, C, 0, "attn1.to_out+residual");
@@ -622,7 +695,17 @@ struct Builder {
             rel(n2);
             Ref a2 = ws((size_t)M * C * e);
             const size_t ko = (size_t)u.kv_off[b] * e;
-            attn(q, C, at(ctxkv, ko), ld_kv, at(ctxkv, ko + (size_t)C * e), ld_kv, a2, C, nb, L, ctx_rows_per_img, heads, hd);
+            attn(q, C, at(ctxkv, ko), ld_kv, at(ctxkv, ko + (size_t)C * e), ld_kv, a2, C, nb, L, Lt, heads, hd);
+            if (ao.ip_tokens > 0) {     // hidden_states + scale * SDPA(q, to_k_ip(ip), to_v_ip(ip))  (attention_processor.py:366-383)
+                Ref aip = ws((size_t)M * C * e);
+                attn(q, C, at(ipkv, ko), ld_kv, at(ipkv, ko + (size_t)C * e), ld_kv, aip, C, nb, L, ao.ip_tokens, heads, hd, Ref(), 0, Ref(), 0,
+                     0, "attention (ip tokens)");
+                const int d = dt;
+                const float sc = ao.ip_scale;
+                const size_t nel = (size_t)M * C;
+                op(OC_OTHER, 0, "attn2 += scale * ip", [=](const Run& r) { return mve_axpy(d, r.p(a2), r.p(aip), sc, r.p(a2), nel, r.stream); });
+                rel(aip);
+            }
             rel(q);
             Ref h3 = ws((size_t)M * C * e);
             gemm(a2, C, wt(b + ".o2.w"), C, h3, C, M, C, C, wt(b + ".o2.b"), Ref(), 0, 0, h, C, 0, "attn2.to_out+residual");
@@ -646,7 +729,7 @@ struct Builder {
     int build(int B_, int H, int W, int n_img, int has_res, int io_dtype, int res_nhwc) {
         B = B_; dt = c.dtype;
         const int Bb = B_;   // lambdas below must not capture `this`
-        pl = Plan();
+        { const AttnOpts keep = pl.ao; pl = Plan(); pl.ao = keep; }
         pl.B = Bb; pl.H = H; pl.W = W; pl.n_img = n_img; pl.has_res = has_res; pl.io_dtype = io_dtype; pl.res_nhwc = res_nhwc;
         const int e = 2, n = c.n_levels, L = c.layers_per_block, T = c.temb_dim();
         const int d = dt;
@@ -710,8 +793,34 @@ struct Builder {
                 ctx_in = cm;
             }
         }
-        ctxkv = ws((size_t)ctxB * Lc * ld_kv * e);
-        gemm(ctx_in, c.ctx_dim, wt("ctx_kv.w"), c.ctx_dim, ctxkv, ld_kv, ctxB * Lc, ld_kv, c.ctx_dim, Ref(), Ref(), 0, 0, Ref(), 0, 0,
+        const AttnOpts ao = pl.ao;
+        Lt = Lc - ao.ip_tokens;
+        H0 = H;
+        ref_off = 0;
+        if (ao.ip_tokens > 0) {
+            MVE_CHECK(Lt > 0, MVE_ERR_ARG, "unet: context of %d rows cannot hold %d ip tokens", Lc, ao.ip_tokens);
+            MVE_CHECK(u.n_ip_loaded == 2 * u.n_xf_layers, MVE_ERR_STATE, "unet: IP-Adapter enabled but only %d of %d to_k_ip/to_v_ip weights loaded",
+                      u.n_ip_loaded, 2 * u.n_xf_layers);
+            // split [text | ip] rows of every item into two dense matrices (attention_processor.py:338-341)
+            const size_t rowb = (size_t)c.ctx_dim * e;
+            Ref ctx_text = ws((size_t)ctxB * Lt * rowb), ctx_ip = ws((size_t)ctxB * ao.ip_tokens * rowb);
+            copy2d(ctx_text, Lt * rowb, ctx_in, Lc * rowb, Lt * rowb, ctxB, "ctx text rows");
+            copy2d(ctx_ip, ao.ip_tokens * rowb, at(ctx_in, Lt * rowb), Lc * rowb, ao.ip_tokens * rowb, ctxB, "ctx ip rows");
+            ipkv = ws((size_t)ctxB * ao.ip_tokens * ld_kv * e);
+            gemm(ctx_ip, c.ctx_dim, wt("ip_kv.w"), c.ctx_dim, ipkv, ld_kv, ctxB * ao.ip_tokens, ld_kv, c.ctx_dim, Ref(), Ref(), 0, 0, Ref(), 0, 0,
+                 "ip-adapter K,V (all layers, one GEMM)");
+            rel(ctx_ip);
+            ctx_in = ctx_text;
+        }
+        if (ao.ref_mode) {
+            MVE_CHECK(n_img == 1, MVE_ERR_ARG, "unet: reference attention and cross-image attention are exclusive (adapter3d_mixin.py:194)");
+            MVE_CHECK(ao.ref_skip >= 0 && ao.ref_skip < Bb, MVE_ERR_ARG, "unet: ref_skip %d out of range", ao.ref_skip);
+            if (ao.ref_mode == 2)
+                MVE_CHECK(ao.ref_H > 0 && ao.ref_W > 0 && ao.ref_H % (1 << (n - 1)) == 0 && ao.ref_W % (1 << (n - 1)) == 0, MVE_ERR_ARG,
+                          "unet: bad reference latent size %dx%d", ao.ref_H, ao.ref_W);
+        }
+        ctxkv = ws((size_t)ctxB * Lt * ld_kv * e);
+        gemm(ctx_in, c.ctx_dim, wt("ctx_kv.w"), c.ctx_dim, ctxkv, ld_kv, ctxB * Lt, ld_kv, c.ctx_dim, Ref(), Ref(), 0, 0, Ref(), 0, 0,
              "cross-attention K,V (all layers, one GEMM)");
         // ---- conv_in + down path ---------------------------------------------------------------------------
         struct Skip { Ref r; int C, H, W; };
@@ -831,22 +940,41 @@ struct Builder {
             op(OC_OTHER, 0, "nhwc->nchw", [=](const Run& r) { return mve_nhwc_to_nchw(io_dtype, MVE_F32, r.p(o8), 8, Bb, oc, H, W, r.p(dst), r.stream); });
         }
         pl.ws_bytes = ar.peak + 256;
+        pl.ref_store_bytes = ref_off;
         if (!u.err.empty()) { mve_set_error("unet plan: %s", u.err.c_str()); u.err.clear(); return MVE_ERR_STATE; }
         return MVE_OK;
     }
 };
 
 int ensure_plan(Unet& u, int B, int H, int W, int n_img, int has_res, int io_dtype, int res_nhwc, int ctx_len) {
-    const Plan& p = u.plan;
-    if (u.plan_valid && p.B == B && p.H == H && p.W == W && p.n_img == n_img && p.has_res == has_res && p.io_dtype == io_dtype &&
-        p.res_nhwc == res_nhwc && p.ctx_len == ctx_len)
-        return MVE_OK;
-    Builder b(u, u.plan);
+    ++u.tick;
+    for (auto& pp : u.plans) {
+        const Plan& p = *pp;
+        if (p.B == B && p.H == H && p.W == W && p.n_img == n_img && p.has_res == has_res && p.io_dtype == io_dtype &&
+            p.res_nhwc == res_nhwc && p.ctx_len == ctx_len && p.ao == u.ao) {
+            pp->last_use = u.tick;
+            u.cur = pp.get();
+            return MVE_OK;
+        }
+    }
+    std::unique_ptr<Plan> np(new Plan());
+    np->ao = u.ao;
+    Builder b(u, *np);
     b.ctx_rows_per_img = ctx_len;
-    u.plan_valid = false;
+    u.cur = nullptr;
     const int rc = b.build(B, H, W, n_img, has_res, io_dtype, res_nhwc);
-    if (rc == MVE_OK) { u.plan.ctx_len = ctx_len; u.plan_valid = true; }
-    return rc;
+    if (rc != MVE_OK) return rc;
+    np->ctx_len = ctx_len;
+    np->last_use = u.tick;
+    if (u.plans.size() >= 8) {
+        size_t lru = 0;
+        for (size_t i = 1; i < u.plans.size(); ++i)
+            if (u.plans[i]->last_use < u.plans[lru]->last_use) lru = i;
+        u.plans.erase(u.plans.begin() + lru);
+    }
+    u.plans.push_back(std::move(np));
+    u.cur = u.plans.back().get();
+    return MVE_OK;
 }
 
 }  // namespace
@@ -924,9 +1052,9 @@ int mve_unet_plan(void* handle, int B, int H, int W, int ctx_len, int num_cross_
     Unet* u = (Unet*)handle;
     int rc = ensure_plan(*u, B, H, W, num_cross_attn_imgs, has_residuals, io_dtype, residuals_nhwc, ctx_len);
     if (rc) return rc;
-    if (workspace_bytes) *workspace_bytes = u->plan.ws_bytes;
-    if (n_ops) *n_ops = (int)u->plan.ops.size();
-    if (flops) for (int i = 0; i < OC_COUNT; ++i) flops[i] = u->plan.flops[i];
+    if (workspace_bytes) *workspace_bytes = u->cur->ws_bytes;
+    if (n_ops) *n_ops = (int)u->cur->ops.size();
+    if (flops) for (int i = 0; i < OC_COUNT; ++i) flops[i] = u->cur->flops[i];
     return MVE_OK;
 }
 
@@ -944,7 +1072,7 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
     const int has_res = (down_residuals && d_mid_residual) ? 1 : 0;
     int rc = ensure_plan(*u, B, H, W, num_cross_attn_imgs, has_res, io_dtype, residuals_nhwc, ctx_len);
     if (rc) return rc;
-    const Plan& pl = u->plan;
+    const Plan& pl = *u->cur;
     MVE_CHECK(d_workspace && workspace_bytes >= pl.ws_bytes, MVE_ERR_NOMEM, "unet_forward: workspace %zu < required %zu",
               workspace_bytes, pl.ws_bytes);
     MVE_CHECK(d_timesteps && d_ctx && (phase == 1 || d_out) && (phase == 2 || d_sample), MVE_ERR_ARG, "unet_forward: null pointer");
@@ -952,6 +1080,9 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
     r.ws = (unsigned char*)d_workspace; r.wt = u->slab;
     r.sample = d_sample; r.timesteps = d_timesteps; r.ctx = d_ctx; r.out = d_out;
     r.down_res = down_residuals; r.mid_res = d_mid_residual;
+    r.ref_store = u->ref_store;
+    MVE_CHECK(pl.ref_store_bytes == 0 || (u->ref_store && u->ref_store_bytes >= pl.ref_store_bytes), MVE_ERR_NOMEM,
+              "unet_forward: reference store %zu < required %zu bytes", u->ref_store_bytes, pl.ref_store_bytes);
     r.stream = (hipStream_t)stream;
     const size_t lo = phase == 2 ? pl.enc_end : 0, hi = phase == 1 ? pl.enc_end : pl.ops.size();
     std::vector<hipEvent_t> ev;
@@ -973,16 +1104,45 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
     return MVE_OK;
 }
 
+int mve_unet_set_attention(void* handle, int ip_tokens, float ip_scale, int ref_mode, int ref_H, int ref_W, int ref_skip,
+                           void* d_ref_store, size_t ref_store_bytes) {
+    MVE_CHECK(handle && ip_tokens >= 0 && ref_mode >= 0 && ref_mode <= 2 && ref_skip >= 0, MVE_ERR_ARG, "unet_set_attention: bad arguments");
+    Unet* u = (Unet*)handle;
+    u->ao.ip_tokens = ip_tokens; u->ao.ip_scale = ip_tokens ? ip_scale : 1.0f;
+    u->ao.ref_mode = ref_mode; u->ao.ref_skip = ref_mode ? ref_skip : 0;
+    u->ao.ref_H = ref_mode == 2 ? ref_H : 0; u->ao.ref_W = ref_mode == 2 ? ref_W : 0;
+    u->ref_store = (unsigned char*)d_ref_store; u->ref_store_bytes = ref_store_bytes;
+    return MVE_OK;
+}
+
+size_t mve_unet_ref_store_bytes(void* handle, int B, int ref_H, int ref_W, int ref_skip) {
+    if (!handle || B <= ref_skip) return 0;
+    const Config& c = ((Unet*)handle)->cfg;
+    std::vector<ResnetDesc> rs;
+    std::vector<XfDesc> xs;
+    enumerate(c, rs, xs);
+    size_t total = 0;
+    for (auto& x : xs) {
+        int lvl = 0;
+        if (x.name.compare(0, 12, "down_blocks.") == 0) lvl = atoi(x.name.c_str() + 12);
+        else if (x.name.compare(0, 10, "up_blocks.") == 0) lvl = c.n_levels - 1 - atoi(x.name.c_str() + 10);
+        else lvl = c.n_levels - 1;
+        const size_t L = (size_t)(ref_H >> lvl) * (ref_W >> lvl);
+        total += (size_t)x.layers * (B - ref_skip) * L * 2 * x.c * 2;
+    }
+    return total;
+}
+
 /* describe op i of the current plan: class (0 conv,1 linear,2 attention,3 norm,4 other), flops, label */
 int mve_unet_op_info(void* handle, int i, int* cls, double* flops, char* label, int label_len) {
     MVE_CHECK(handle, MVE_ERR_ARG, "unet_op_info: null handle");
     Unet* u = (Unet*)handle;
-    MVE_CHECK(u->plan_valid && i >= 0 && i < (int)u->plan.ops.size(), MVE_ERR_ARG, "unet_op_info: no such op %d", i);
-    const Op& o = u->plan.ops[i];
+    MVE_CHECK(u->cur && i >= 0 && i < (int)u->cur->ops.size(), MVE_ERR_ARG, "unet_op_info: no such op %d", i);
+    const Op& o = u->cur->ops[i];
     if (cls) *cls = o.cls;
     if (flops) *flops = o.flops;
     if (label && label_len > 0) { strncpy(label, o.what, (size_t)label_len - 1); label[label_len - 1] = 0; }
-    return (i < (int)u->plan.enc_end) ? 1 : 2;   // which phase the op belongs to
+    return (i < (int)u->cur->enc_end) ? 1 : 2;   // which phase the op belongs to
 }
 
 }  // extern "C"

@@ -12,9 +12,12 @@ images (`fuse_chunks=True`, the default): weights are streamed once per step ins
 every GEMM sees M = 2V*H*W rows.  The kernels are batch-invariant (a row's reduction order does not depend
 on the batch), so the result is bitwise identical to the chunked walk (tests/test_pipeline_mixin.py).
 """
+from copy import copy
+
 import torch
 
 from .. import ops
+from ..unet import unet_dec, unet_enc
 
 
 class Adapter3DMixin:
@@ -81,3 +84,135 @@ class Adapter3DMixin:
         if noise_pred.is_cuda:
             return ops.cfg_combine(noise_pred_uncond, noise_pred_text, guidance_scale).to(noise_pred.dtype)
         return guidance_scale * noise_pred_text + (1 - guidance_scale) * noise_pred_uncond
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # 2-pass mode (adapter3d_mixin.py:137-317): pass 1 runs encoder + decoder without the tile ControlNet and keeps the
+    # encoder state; pass 2 evaluates the tile (and depth) ControlNet on the fresh renders and re-runs the DECODER only.
+    # ------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _pair(latent, prompt_embeds):
+        """[b,4,2H,W] (reference image stacked on the view) -> UNet batch of 2b images; adapter3d_mixin.py:156-167."""
+        shp = latent.size()
+        if shp[2] != 2 * shp[3]:
+            return False, None, latent, latent, prompt_embeds, prompt_embeds
+        unet_in = latent.reshape(*shp[:2], 2, shp[3], shp[3]).permute(0, 2, 1, 3, 4).reshape(shp[0] * 2, shp[1], shp[3], shp[3])
+        embeds = prompt_embeds.unsqueeze(1).expand(-1, 2, -1, -1).reshape(-1, *prompt_embeds.shape[1:])
+        return True, dict(num_cross_attn_imgs=2), unet_in, latent[:, :, -shp[3]:], embeds, prompt_embeds
+
+    @staticmethod
+    def _pad_pair(down_res, mid_res):
+        """zero residuals for the reference rows (adapter3d_mixin.py:186-192)."""
+        down_res = [torch.stack([torch.zeros_like(r), r], dim=1).view(-1, *r.shape[1:]) for r in down_res]
+        mid_res = torch.stack([torch.zeros_like(mid_res), mid_res], dim=1).view(-1, *mid_res.shape[1:])
+        return down_res, mid_res
+
+    def _sub_controlnet(self, nets):
+        """MultiControlNetModel(self.controlnet.nets[a:b]) of the reference, without importing diffusers here."""
+        return type(self.controlnet)(nets)
+
+    def _maybe_fuse(self, *batch_lists):
+        """Concatenate the diff_bs chunks into one batch when shapes allow (see the module docstring)."""
+        lat = batch_lists[0]
+        if not (self.fuse_chunks and len(lat) > 1 and len({tuple(b.shape[1:]) for b in lat}) == 1):
+            return batch_lists
+        cat = lambda bs: None if bs is None else ([None] if bs[0] is None else [torch.cat(list(bs), dim=0)])
+        return tuple(cat(b) for b in batch_lists)
+
+    def get_noise_pred_p1(self, latent_batches, prompt_embeds_batches, t, guidance_scale, ctrl_depths_batches=None,
+                          depth_weight=None, extra_control_batches=None, cond_noisy_latent_batches=None,
+                          added_cond_kwargs_batches=None):
+        extra_control_batches = extra_control_batches or []
+        if added_cond_kwargs_batches is None:
+            fused = self._maybe_fuse(latent_batches, prompt_embeds_batches, ctrl_depths_batches, cond_noisy_latent_batches,
+                                     *extra_control_batches)
+            latent_batches, prompt_embeds_batches, ctrl_depths_batches, cond_noisy_latent_batches = fused[:4]
+            extra_control_batches = list(fused[4:])
+        n = len(latent_batches)
+        ctrl_depths_batches = ctrl_depths_batches or [None] * n
+        noise_pred, dec_args, dec_kwargs = [], [], []
+        for i in range(n):
+            latent, embeds, depths = latent_batches[i], prompt_embeds_batches[i], ctrl_depths_batches[i]
+            extra = [e[i] for e in extra_control_batches]
+            paired, cak, unet_in, cn_in, unet_embeds, cn_embeds = self._pair(latent, embeds)
+            ack = None if added_cond_kwargs_batches is None else {k: v[i] for k, v in added_cond_kwargs_batches.items()}
+            skip = 2 if depths is None else 1                       # nets[0] = tile (pass 2), nets[1] = depth
+            down_res = mid_res = None
+            nets = getattr(getattr(self, 'controlnet', None), 'nets', [])
+            if len(nets) > skip:
+                down_res, mid_res = self._sub_controlnet(nets[skip:])(
+                    cn_in, t, encoder_hidden_states=cn_embeds,
+                    controlnet_cond=extra if depths is None else [depths] + extra,
+                    conditioning_scale=[1.0] * len(extra) if depths is None else [depth_weight] + [1.0] * len(extra),
+                    guess_mode=False, added_cond_kwargs=ack, return_dict=False)
+                if paired:
+                    down_res, mid_res = self._pad_pair(down_res, mid_res)
+            enc_cak, dec_cak = cak, cak
+            if cond_noisy_latent_batches is not None:             # reference attention: write pass over the condition latents
+                assert cak is None
+                ref_enc, ref_dec = dict(), dict()
+                cond_state = unet_enc(self.unet, cond_noisy_latent_batches[i], t, encoder_hidden_states=unet_embeds,
+                                      added_cond_kwargs=ack, cross_attention_kwargs=dict(mode='w', ref_dict=ref_enc))
+                unet_dec(self.unet, *cond_state, encoder_hidden_states=unet_embeds,
+                         cross_attention_kwargs=dict(mode='w', ref_dict=ref_dec))
+                enc_cak, dec_cak = dict(mode='r', ref_dict=ref_enc), dict(mode='m', ref_dict=ref_dec)
+            state = unet_enc(self.unet, unet_in, t, encoder_hidden_states=unet_embeds, cross_attention_kwargs=enc_cak,
+                             added_cond_kwargs=ack)
+            dec_args.append(state)
+            dec_kwargs.append(dict(encoder_hidden_states=unet_embeds, cross_attention_kwargs=dec_cak,
+                                   down_block_additional_residuals=down_res, mid_block_additional_residual=mid_res))
+            out = unet_dec(self.unet, *dec_args[-1], **dec_kwargs[-1])
+            if paired:
+                out = out.view(latent.shape[0], 2, latent.shape[1], latent.shape[3], latent.shape[3])[:, 1]
+            noise_pred.append(out)
+        noise_pred = torch.cat(noise_pred, dim=0)
+        uncond, text = noise_pred.chunk(2)
+        return self._cfg(uncond, text, guidance_scale), dec_args, dec_kwargs
+
+    def get_noise_pred_p2(self, latent_batches, prompt_embeds_batches, dec_args, dec_kwargs, t, guidance_scale,
+                          ctrl_images_batches, tile_weight, ctrl_depths_batches=None, depth_weight=None,
+                          added_cond_kwargs_batches=None, guess_mode=False, adapter_scale=None, ctrl_text_embedding=True):
+        if len(dec_args) == 1 and len(latent_batches) > 1:       # pass 1 fused the chunks: fuse the same way
+            latent_batches, prompt_embeds_batches, ctrl_images_batches, ctrl_depths_batches = self._maybe_fuse(
+                latent_batches, prompt_embeds_batches, ctrl_images_batches, ctrl_depths_batches)
+        n = len(latent_batches)
+        ctrl_depths_batches = ctrl_depths_batches or [None] * n
+        noise_pred = []
+        for i in range(n):
+            latent, embeds, depths = latent_batches[i], prompt_embeds_batches[i], ctrl_depths_batches[i]
+            paired = latent.shape[2] == 2 * latent.shape[3]
+            cn_in = latent[:, :, -latent.shape[3]:] if paired else latent
+            ack = None if added_cond_kwargs_batches is None else {k: v[i] for k, v in added_cond_kwargs_batches.items()}
+            if ctrl_text_embedding:
+                cn_embeds, cn_ack = embeds, ack
+            else:                                                  # adapter3d_mixin.py:268-277
+                cn_embeds = self.negative_prompt_embeds.to(cn_in).expand(latent.shape[0], -1, -1)
+                neg = getattr(self, 'negative_added_cond_kwargs', None)
+                cn_ack = None if neg is None else {k: v.to(cn_in).expand(latent.shape[0], *[-1] * (v.dim() - 1)) for k, v in neg.items()}
+            down_res, mid_res = self._sub_controlnet(self.controlnet.nets[:1 if depths is None else 2])(
+                cn_in, t, encoder_hidden_states=cn_embeds,
+                controlnet_cond=[ctrl_images_batches[i]] if depths is None else [ctrl_images_batches[i], depths],
+                conditioning_scale=[tile_weight] if depths is None else [tile_weight, depth_weight],
+                guess_mode=guess_mode, added_cond_kwargs=cn_ack, return_dict=False)
+            if paired:
+                down_res, mid_res = self._pad_pair(down_res, mid_res)
+            kw = copy(dec_kwargs[i])
+            if kw['down_block_additional_residuals'] is not None:
+                down_res = [a + b for a, b in zip(down_res, kw['down_block_additional_residuals'])]
+            if kw['mid_block_additional_residual'] is not None:
+                mid_res = mid_res + kw['mid_block_additional_residual']
+            kw.update(down_block_additional_residuals=down_res, mid_block_additional_residual=mid_res)
+            out = unet_dec(self.unet, *dec_args[i], **kw)
+            if paired:
+                out = out.view(latent.shape[0], 2, latent.shape[1], latent.shape[3], latent.shape[3])[:, 1]
+            noise_pred.append(out)
+        noise_pred = torch.cat(noise_pred, dim=0)
+        uncond, cond = noise_pred.chunk(2)
+        if adapter_scale is not None:
+            return adapter_scale * (cond - uncond)
+        return self._cfg(uncond, cond, guidance_scale)
+
+    @staticmethod
+    def _cfg(uncond, text, guidance_scale):
+        if uncond.is_cuda:
+            return ops.cfg_combine(uncond, text, guidance_scale).to(uncond.dtype)
+        return guidance_scale * text + (1 - guidance_scale) * uncond

@@ -56,6 +56,8 @@ class UNet2DConditionEngine:
                   arr(c['transformer_layers']), c['cross_attention_dim'], c['norm_num_groups'], float(c['norm_eps']),
                   int(c['use_linear_projection']))
         self._ws = None
+        self._ip = (0, 1.0)          # IP-Adapter: (num_tokens, scale); see set_ip_adapter
+        self._ref_keep = None
         # the attributes the reference's pipelines / runner read from a diffusers model
         self.config = SimpleNamespace(in_channels=c['in_channels'], out_channels=c['out_channels'], sample_size=64,
                                       center_input_sample=False, addition_embed_type=None, **{
@@ -96,6 +98,38 @@ class UNet2DConditionEngine:
             if missing:
                 raise KeyError(f'{missing} UNet parameters missing from the state dict (first: {buf.value.decode()})')
         return self
+
+    # ------------------------------------------------------------------ attention processors
+    _REF_KEY = '__mvedit_amd_ref_store__'
+
+    def set_ip_adapter(self, num_tokens=16, scale=1.0):
+        """Install / remove (num_tokens=0) the IPAttnProcessor2_0 behaviour on every cross-attention
+        (lib/models/architecture/ip_adapter/ip_adapter.py:85-110, :154-160 `set_scale`).  The to_k_ip / to_v_ip weights arrive
+        through load_state_dict under their diffusers names `<block>.attn2.processor.to_{k,v}_ip.weight`."""
+        self._ip = (int(num_tokens), float(scale))
+
+    def _set_attention(self, cak, B, H, W):
+        """Translate the reference's cross_attention_kwargs (mode / ref_dict / is_cfg_guidance) into engine state.  The
+        reference fills ref_dict with one tensor per attention layer; here ref_dict receives ONE entry, the K/V store."""
+        cak = cak or {}
+        mode, ref_dict = cak.get('mode'), cak.get('ref_dict')
+        skip = 1 if cak.get('is_cfg_guidance') else 0
+        store, ref_mode, rH, rW = None, 0, 0, 0
+        if mode is not None and ref_dict is not None:
+            if mode == 'w':
+                nbytes = _lib.raw('mve_unet_ref_store_bytes')(self._h, B, H, W, skip)
+                store = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                ref_dict[self._REF_KEY] = (store, B, H, W, skip)
+                ref_mode = 1
+            elif mode in ('r', 'm'):
+                store, Bs, rH, rW, sk = ref_dict.pop(self._REF_KEY) if mode == 'r' else ref_dict[self._REF_KEY]
+                assert Bs == B and sk == skip, 'reference pass and read pass must have the same batch layout'
+                ref_mode = 2
+            else:
+                raise AssertionError(mode)
+        self._ref_keep = store
+        _lib.call('mve_unet_set_attention', self._h, self._ip[0], self._ip[1], ref_mode, rH, rW, skip, _lib.ptr(store),
+                  store.numel() if store is not None else 0)
 
     @property
     def weight_bytes(self):
@@ -172,6 +206,7 @@ class UNet2DConditionEngine:
             raise NotImplementedError('added_cond_kwargs (SDXL micro-conditioning) has no reference implementation '
                                       'in MVEdit (SURVEY.md F9)')
         n_img = int((cross_attention_kwargs or {}).get('num_cross_attn_imgs', 1))
+        self._set_attention(cross_attention_kwargs, sample.shape[0], sample.shape[2], sample.shape[3])
         res = self._run(0, sample, timestep, encoder_hidden_states, n_img, down_block_additional_residuals,
                         mid_block_additional_residual, out)
         if return_dict:
@@ -182,6 +217,7 @@ class UNet2DConditionEngine:
 
     def profile(self, sample, timestep, encoder_hidden_states, num_cross_attn_imgs=1):
         """-> (out, [(class, label, flops, ms)]) with HIP-event timing around every launch."""
+        self._set_attention(None, *[sample.shape[i] for i in (0, 2, 3)])
         out, ms = self._run(0, sample, timestep, encoder_hidden_states, num_cross_attn_imgs, None, None, None, profile=True)
         return out, [(c, lab, fl, m) for (ph, c, fl, lab), m in zip(self.op_table(), ms)]
 
@@ -191,6 +227,7 @@ class UNet2DConditionEngine:
         (emb, down_block_res_samples, sample) for a later dec()."""
         n_img = int((cross_attention_kwargs or {}).get('num_cross_attn_imgs', 1))
         B, _, H, W = sample.shape
+        self._set_attention(cross_attention_kwargs, B, H, W)
         # residual-carrying decode needs the same plan: decided at dec() time, so enc always plans with residual slots
         info = self.plan(B, H, W, encoder_hidden_states.shape[1], n_img, True, encoder_hidden_states.dtype)
         ws = workspace if workspace is not None else torch.empty(info['workspace_bytes'], dtype=torch.uint8, device=self.device)
@@ -198,7 +235,9 @@ class UNet2DConditionEngine:
         self._enc_dec(1, st, sample, encoder_hidden_states, None, None)
         return st
 
-    def dec(self, state, encoder_hidden_states, down_block_additional_residuals=None, mid_block_additional_residual=None):
+    def dec(self, state, encoder_hidden_states, down_block_additional_residuals=None, mid_block_additional_residual=None,
+            cross_attention_kwargs=None):
+        self._set_attention(cross_attention_kwargs, state.shape[0], state.shape[2], state.shape[3])
         return self._enc_dec(2, state, None, encoder_hidden_states, down_block_additional_residuals,
                              mid_block_additional_residual)
 
@@ -252,4 +291,5 @@ def unet_enc(unet, sample, timestep, encoder_hidden_states, cross_attention_kwar
 def unet_dec(unet, emb, down_block_res_samples, sample, encoder_hidden_states, cross_attention_kwargs=None,
              down_block_additional_residuals=None, mid_block_additional_residual=None):
     """lib/models/architecture/diffusers.py:102-164."""
-    return unet.dec(emb, encoder_hidden_states, down_block_additional_residuals, mid_block_additional_residual)
+    return unet.dec(emb, encoder_hidden_states, down_block_additional_residuals, mid_block_additional_residual,
+                    cross_attention_kwargs)

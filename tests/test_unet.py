@@ -225,3 +225,88 @@ def test_engine_fails_loudly_without_weights(lib):
         eng.load_state_dict(sd)
     with pytest.raises(lib.MveError, match='not loaded'):
         eng(x.half().cuda(), 1, ctx.half().cuda())
+
+
+# ------------------------------------------------------------------------------------------------ attention processors
+def _check(out, ref16, ref32, dtype=torch.float16):
+    l2_16, mx_16 = _rel(out, ref16)
+    l2_32, _ = _rel(out, ref32)
+    emu_l2, _ = _rel(ref16, ref32)
+    msg = f'vs fp16 oracle l2={l2_16:.2e} max={mx_16:.2e}; vs fp32 l2={l2_32:.2e}; emulated l2={emu_l2:.2e}'
+    print(msg)
+    assert l2_16 <= 3e-3 and mx_16 <= 6e-3, msg
+    assert l2_32 <= 1.05 * emu_l2 + 1e-4, msg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_img', [1, 2])
+def test_engine_ip_adapter(lib, n_img):
+    """IPAttnProcessor2_0 (attention_processor.py:301-396): the last 16 context rows use to_k_ip/to_v_ip in a second
+    softmax, added with `scale`; also under the cross-image wrapper (the two compose in the reference)."""
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg, dtype, B, S = U.SMALL, torch.float16, 2, 32
+    sd = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=8).items()}
+    sd.update({k: v.to(dtype).float() for k, v in U.make_ip_state_dict(cfg).items()})
+    x, ctx = inputs(cfg, B, S, seed=4, ctx_len=77 + 16)
+    x, ctx = x.to(dtype).float(), ctx.to(dtype).float()
+    ao = dict(ip_tokens=16, ip_scale=0.6)
+    with torch.no_grad():
+        ref32 = U.unet_forward(sd, cfg, x, 250, ctx, n_img, attn_opts=ao)
+        ref16 = U.unet_forward(sd, cfg, x, 250, ctx, n_img, attn_opts=ao, q=U.quantizer(dtype))
+        plain = U.unet_forward(sd, cfg, x, 250, ctx[:, :77], n_img)
+    assert _rel(ref32, plain)[0] > 0.02, 'the ip branch must matter in this test'
+    eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype)
+    eng.set_ip_adapter(16, 0.6)
+    cak = dict(num_cross_attn_imgs=n_img) if n_img > 1 else None
+    out = eng(x.to(dtype).cuda(), 250, ctx.to(dtype).cuda(), cross_attention_kwargs=cak)[0]
+    _check(out, ref16, ref32)
+    eng.set_ip_adapter(0)                                  # removing the adapter restores the plain processor
+    out0 = eng(x.to(dtype).cuda(), 250, ctx[:, :77].to(dtype).cuda(), cross_attention_kwargs=cak)[0]
+    assert _rel(out0, plain)[0] < 3e-3
+    # without the ip weights the engine refuses
+    eng2 = UNet2DConditionEngine.from_state_dict({k: v for k, v in sd.items() if 'processor' not in k}, cfg, dtype)
+    eng2.set_ip_adapter(16, 1.0)
+    from mvedit_amd._lib import MveError
+    with pytest.raises(MveError, match='to_k_ip'):
+        eng2(x.to(dtype).cuda(), 250, ctx.to(dtype).cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg_first,S_ref', [(False, 32), (True, 16)])
+def test_engine_reference_attention(lib, cfg_first, S_ref):
+    """ReferenceAttnProc 'w' then 'r' (diffusers.py:646-673); with is_cfg_guidance the first item neither writes nor reads
+    (zero123plus.py:59-76) and the condition latent may have another size than the sample."""
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg, dtype, B, S = U.SMALL, torch.float16, 3, 32
+    sd = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=9).items()}
+    x, ctx = inputs(cfg, B, S, seed=6)
+    xr, _ = inputs(cfg, B, S_ref, seed=7)
+    x, xr, ctx = x.to(dtype).float(), xr.to(dtype).float(), ctx.to(dtype).float()
+    skip = 1 if cfg_first else 0
+
+    def oracle(q):
+        d = {}
+        U.unet_forward(sd, cfg, xr, 300, ctx, attn_opts=dict(mode='w', ref_dict=d, ref_skip=skip), q=q)
+        assert len(d) > 0
+        out = U.unet_forward(sd, cfg, x, 300, ctx, attn_opts=dict(mode='r', ref_dict=d, ref_skip=skip), q=q)
+        assert len(d) == 0
+        return out
+    with torch.no_grad():
+        ref32, ref16 = oracle(None), oracle(U.quantizer(dtype))
+        plain = U.unet_forward(sd, cfg, x, 300, ctx)
+    assert _rel(ref32, plain)[0] > 0.02
+    eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype)
+    d = {}
+    kw = dict(is_cfg_guidance=True) if cfg_first else {}
+    eng(xr.to(dtype).cuda(), 300, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='w', ref_dict=d, **kw))
+    assert len(d) == 1
+    keep = dict(d)
+    out_m = eng(x.to(dtype).cuda(), 300, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='m', ref_dict=d, **kw))[0]
+    assert len(d) == 1
+    out = eng(x.to(dtype).cuda(), 300, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='r', ref_dict=d, **kw))[0]
+    assert len(d) == 0 and torch.equal(out, out_m)
+    _check(out, ref16, ref32)
+    if cfg_first:   # the unconditional item never sees the reference: equals the plain forward of that item
+        p0 = eng(x.to(dtype).cuda(), 300, ctx.to(dtype).cuda())[0]
+        assert torch.equal(out[:1], p0[:1]) and not torch.equal(out[1:], p0[1:])
+    del keep
