@@ -128,6 +128,29 @@ MVE_API int mve_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh
 MVE_API int mve_compact_alive(const int32_t* d_rays_alive, uint32_t n_alive, int32_t* d_out, int32_t* d_n_out,
                               void* d_scratch, void* stream);
 
+/* Train branch of VolumeRenderer.forward (lib/models/decoders/base_volume_renderer.py:222-243): keep the samples whose
+ * composited weight exceeds `threshold`, order preserving, and re-index rays[N][2] = (offset, count) accordingly.
+ * d_pref [M+1] receives the reference's `filt_inds` (exclusive prefix count of kept samples, pref[M] = total kept);
+ * d_n_out (device int32) the number kept; outputs are caller-allocated with room for M samples. */
+MVE_API size_t mve_cull_scratch_bytes(uint32_t M);
+MVE_API int mve_cull_samples(const float* d_weights, uint32_t M, float threshold, const int32_t* d_rays, uint32_t N,
+                             const float* d_xyzs, const float* d_dirs, const float* d_ts, float* d_out_xyzs, float* d_out_dirs,
+                             float* d_out_ts, int32_t* d_out_rays, int32_t* d_pref, int32_t* d_n_out, void* d_scratch,
+                             void* stream);
+
+/* Density-grid refresh, the device part of update_extra_state (base_volume_renderer.py:105-177).
+ *   density_grid_points : cell coords [N,3] int32 (NULL = every cell of the grid in meshgrid order) + uniform noise [N,3] in
+ *                         [0,1) (NULL = cell centres) -> Morton indices [N] and query points
+ *                         (coords - (H-1)/2) * 2*bound/H + noise*2*hw - hw,  hw = bound/H   (:129-135)
+ *   density_grid_update : tmp[indices] = min(sigmas, FLT_MAX); grid = where(grid >= 0 & tmp >= 0, max(grid*decay, tmp), grid);
+ *                         *d_mean = mean(clamp(grid, 0))  (:166-171).  tmp_grid must be pre-filled with -1 by the caller. */
+MVE_API int mve_density_grid_points(const int32_t* d_coords, const float* d_noise, uint32_t N, uint32_t grid_size, float bound,
+                                    float* d_xyzs, int32_t* d_indices, void* stream);
+MVE_API size_t mve_density_grid_scratch_bytes(uint32_t n_cells);
+MVE_API int mve_density_grid_update(float* d_density_grid, float* d_tmp_grid, uint32_t n_cells, const float* d_sigmas,
+                                    const int32_t* d_indices, uint32_t N, float decay, float* d_mean_density, void* d_scratch,
+                                    void* stream);
+
 /* =========================================================================
  * 2. UNet primitives (activations are NHWC = [B*H*W, C] row-major, 16-bit
  *    storage `dtype` in {MVE_F16, MVE_BF16}, fp32 accumulation everywhere).

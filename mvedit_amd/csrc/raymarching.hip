@@ -388,6 +388,103 @@ __global__ __launch_bounds__(kBlock) void k_alive_scatter(const int32_t* __restr
     if (keep) out[block_bases[blockIdx.x] + ex] = v;
 }
 
+// ---------------------------------------------------------------------------
+// train branch: cull samples whose composited weight is below a threshold and re-index the rays
+// (lib/models/decoders/base_volume_renderer.py:222-243: boolean-mask gathers + cumsum on the host side there)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cull_count(const float* __restrict__ weights, uint32_t M, float th,
+                                                       int32_t* __restrict__ block_sums) {
+    __shared__ int lds[kBlock / 64 + 1];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const int keep = (i < M && weights[i] > th) ? 1 : 0;
+    int tot;
+    (void)block_excl_scan<kBlock>(keep, &tot, lds);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(kBlock) void k_cull_scatter(const float* __restrict__ weights, uint32_t M, float th,
+                                                         const int32_t* __restrict__ block_bases, const int32_t* __restrict__ total,
+                                                         const float* __restrict__ xyzs, const float* __restrict__ dirs,
+                                                         const float* __restrict__ ts, float* __restrict__ o_xyzs,
+                                                         float* __restrict__ o_dirs, float* __restrict__ o_ts, int32_t* __restrict__ pref) {
+    __shared__ int lds[kBlock / 64 + 1];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const int keep = (i < M && weights[i] > th) ? 1 : 0;
+    int tot;
+    const int ex = block_excl_scan<kBlock>(keep, &tot, lds);
+    const int dst = block_bases[blockIdx.x] + ex;
+    if (i < M) pref[i] = dst;                 // = cumsum(mask)[i - 1], the reference's filt_inds[i]
+    if (i == 0) pref[M] = *total;
+    if (keep) {
+        reinterpret_cast<float3p*>(o_xyzs)[dst] = reinterpret_cast<const float3p*>(xyzs)[i];
+        reinterpret_cast<float3p*>(o_dirs)[dst] = reinterpret_cast<const float3p*>(dirs)[i];
+        reinterpret_cast<float2p*>(o_ts)[dst] = reinterpret_cast<const float2p*>(ts)[i];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_cull_rays(const int32_t* __restrict__ rays, uint32_t N, const int32_t* __restrict__ pref,
+                                                      int32_t* __restrict__ o_rays) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const int off = rays[2 * n], cnt = rays[2 * n + 1];
+    const int a = pref[off], b = pref[off + cnt];
+    o_rays[2 * n] = a;
+    o_rays[2 * n + 1] = b - a;
+}
+
+// ---------------------------------------------------------------------------
+// density-grid refresh (update_extra_state, base_volume_renderer.py:105-177)
+// ---------------------------------------------------------------------------
+// cell coordinates -> Morton index and jittered query position.  coords == nullptr: cell i of the full grid in
+// (x, y, z) meshgrid order, x slowest (custom_meshgrid 'ij').
+__global__ __launch_bounds__(kBlock) void k_grid_points(const int32_t* __restrict__ coords, const float* __restrict__ noise, uint32_t N,
+                                                        uint32_t H, float bound, float* __restrict__ xyzs, int32_t* __restrict__ indices) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    uint32_t c[3];
+    if (coords) { c[0] = (uint32_t)coords[3 * i]; c[1] = (uint32_t)coords[3 * i + 1]; c[2] = (uint32_t)coords[3 * i + 2]; }
+    else { c[0] = i / (H * H); c[1] = (i / H) % H; c[2] = i % H; }
+    indices[i] = (int32_t)morton_encode(c[0], c[1], c[2]);
+    const float half = bound / (float)H, cell = 2.0f * bound / (float)H, mid = ((float)H - 1.0f) / 2.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float x = ((float)c[k] - mid) * cell;
+        x += noise ? noise[3 * i + k] * (2.0f * half) - half : 0.0f;
+        xyzs[3 * i + k] = x;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_grid_scatter(const float* __restrict__ sigmas, const int32_t* __restrict__ indices, uint32_t N,
+                                                         float* __restrict__ tmp_grid) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < N) tmp_grid[indices[i]] = fminf(sigmas[i], 3.4028234663852886e38f);
+}
+// grid = where(grid >= 0 & tmp >= 0, max(grid * decay, tmp), grid); per-block partial sums of clamp(grid, 0) in fp64
+__global__ __launch_bounds__(kBlock) void k_grid_ema(float* __restrict__ grid, const float* __restrict__ tmp, uint32_t n, float decay,
+                                                     double* __restrict__ partial) {
+    __shared__ double red[kBlock / 64];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    double v = 0.0;
+    if (i < n) {
+        float g = grid[i];
+        const float t = tmp[i];
+        if (g >= 0.0f && t >= 0.0f) { g = fmaxf(g * decay, t); grid[i] = g; }
+        v = (double)fmaxf(g, 0.0f);
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) t += red[k];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ void k_grid_mean(const double* __restrict__ partial, uint32_t nblk, uint32_t n, float* __restrict__ mean) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double t = 0.0;
+        for (uint32_t k = 0; k < nblk; ++k) t += partial[k];
+        *mean = (float)(t / (double)n);
+    }
+}
+
 MarchParams make_params(const uint8_t* grid, float bound, int contract, float dt_gamma, uint32_t max_steps, uint32_t C,
                         uint32_t H) {
     MarchParams p;
@@ -558,6 +655,65 @@ int mve_compact_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out,
     k_scan_block_sums<<<1, 1024, 0, s>>>(bs, nblk, n_out);
     MVE_LAUNCH_CHECK();
     k_alive_scatter<<<nblk, kBlock, 0, s>>>(rays_alive, n_alive, bs, out);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+size_t mve_cull_scratch_bytes(uint32_t M) { return sizeof(int32_t) * ((size_t)mve_cdiv(M, kBlock) + 64); }
+
+int mve_cull_samples(const float* weights, uint32_t M, float threshold, const int32_t* rays, uint32_t N, const float* xyzs,
+                     const float* dirs, const float* ts, float* out_xyzs, float* out_dirs, float* out_ts, int32_t* out_rays,
+                     int32_t* pref /* [M + 1] */, int32_t* n_out, void* scratch, void* stream) {
+    MVE_CHECK(n_out && pref, MVE_ERR_ARG, "cull_samples: null n_out / pref");
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        MVE_HIP(hipMemsetAsync(n_out, 0, sizeof(int32_t), s));
+        MVE_HIP(hipMemsetAsync(pref, 0, sizeof(int32_t), s));
+    } else {
+        MVE_CHECK(weights && xyzs && dirs && ts && out_xyzs && out_dirs && out_ts && scratch, MVE_ERR_ARG, "cull_samples: null pointer");
+        const uint32_t nblk = mve_cdiv(M, kBlock);
+        int32_t* bs = (int32_t*)scratch;
+        k_cull_count<<<nblk, kBlock, 0, s>>>(weights, M, threshold, bs);
+        MVE_LAUNCH_CHECK();
+        k_scan_block_sums<<<1, 1024, 0, s>>>(bs, nblk, n_out);
+        MVE_LAUNCH_CHECK();
+        k_cull_scatter<<<nblk, kBlock, 0, s>>>(weights, M, threshold, bs, n_out, xyzs, dirs, ts, out_xyzs, out_dirs, out_ts, pref);
+        MVE_LAUNCH_CHECK();
+    }
+    if (N) {
+        MVE_CHECK(rays && out_rays, MVE_ERR_ARG, "cull_samples: null rays");
+        k_cull_rays<<<mve_cdiv(N, kBlock), kBlock, 0, s>>>(rays, N, pref, out_rays);
+        MVE_LAUNCH_CHECK();
+    }
+    return MVE_OK;
+}
+
+int mve_density_grid_points(const int32_t* coords, const float* noise, uint32_t N, uint32_t grid_size, float bound, float* xyzs,
+                            int32_t* indices, void* stream) {
+    if (N == 0) return MVE_OK;
+    MVE_CHECK(xyzs && indices && grid_size > 0, MVE_ERR_ARG, "density_grid_points: bad arguments");
+    MVE_CHECK(coords || (uint64_t)N == (uint64_t)grid_size * grid_size * grid_size, MVE_ERR_ARG,
+              "density_grid_points: without coords N must be grid_size^3");
+    k_grid_points<<<mve_cdiv(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(coords, noise, N, grid_size, bound, xyzs, indices);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+size_t mve_density_grid_scratch_bytes(uint32_t n_cells) { return sizeof(double) * ((size_t)mve_cdiv(n_cells, kBlock) + 8); }
+
+int mve_density_grid_update(float* density_grid, float* tmp_grid, uint32_t n_cells, const float* sigmas, const int32_t* indices,
+                            uint32_t N, float decay, float* mean_density, void* scratch, void* stream) {
+    MVE_CHECK(density_grid && tmp_grid && mean_density && scratch && n_cells > 0, MVE_ERR_ARG, "density_grid_update: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (N) {
+        MVE_CHECK(sigmas && indices, MVE_ERR_ARG, "density_grid_update: null sigmas / indices");
+        k_grid_scatter<<<mve_cdiv(N, kBlock), kBlock, 0, s>>>(sigmas, indices, N, tmp_grid);
+        MVE_LAUNCH_CHECK();
+    }
+    const uint32_t nblk = mve_cdiv(n_cells, kBlock);
+    k_grid_ema<<<nblk, kBlock, 0, s>>>(density_grid, tmp_grid, n_cells, decay, (double*)scratch);
+    MVE_LAUNCH_CHECK();
+    k_grid_mean<<<1, 64, 0, s>>>((const double*)scratch, nblk, n_cells, mean_density);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

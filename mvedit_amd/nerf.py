@@ -168,3 +168,68 @@ class NeRFRenderer:
             normal_fg, normal = depth_to_normal(depth, intr, out_image[0, ..., 3], normal_bg)
             return out_image, depth[None], normal[None], normal_fg[None]
         return out_image, depth[None]
+
+
+class VolumeRenderer:
+    """Mirror of the reference's VolumeRenderer for ONE scene with an iNGP decoder: the eval branch (fused, see
+    INGPDecoderParams.render_rays), the train-branch FORWARD (march -> density -> cull -> decode -> composite,
+    lib/models/decoders/base_volume_renderer.py:207-262) and `update_extra_state` (:105-177).
+    The backward of the train branch (hash-grid / MLP gradients) is SURVEY section 8(f) rank 1 and not part of this class."""
+
+    def __init__(self, decoder, weight_culling_th=1e-3):
+        self.decoder = decoder
+        self.bound, self.min_near, self.max_steps = decoder.bound, decoder.min_near, decoder.max_steps
+        self.weight_culling_th = weight_culling_th
+        self.training = False
+
+    def update_extra_state(self, density_grid, density_bitfield, iter_density, density_thresh=0.01, decay=0.9, S=128):
+        """density_grid [1, H^3] f32 and density_bitfield [1, H^3/8] u8 are updated IN PLACE; returns iter_density + 1 and the
+        threshold used.  Random draws (jitter, partial-update cells) come from torch's generator, as in the reference."""
+        from . import raymarching as rm
+        dec, dev = self.decoder, self.decoder.device
+        assert density_grid.shape[0] == 1 and density_grid.dtype == torch.float32 and density_grid.is_contiguous()
+        n_cells = density_grid.shape[-1]
+        H = int(round(n_cells ** (1.0 / 3.0)))
+        tmp = torch.full_like(density_grid, -1)
+        if iter_density < 16:                                         # full update, one launch over the whole grid
+            N, coords = n_cells, None
+        else:                                                         # partial update: N random cells + N occupied cells
+            N = n_cells // 4
+            coords = torch.randint(0, H, (N, 3), device=dev)
+            occ = torch.nonzero(density_grid[0] > 0).squeeze(-1)
+            occ = occ[torch.randint(0, occ.shape[0], [N], dtype=torch.long, device=dev)]
+            coords = torch.cat([coords.int(), rm.morton3D_invert(occ.int())], dim=0).contiguous()
+            N = coords.shape[0]
+        noise = torch.rand(N, 3, dtype=torch.float32, device=dev)
+        xyzs = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        indices = torch.empty(N, dtype=torch.int32, device=dev)
+        mean = torch.empty(1, dtype=torch.float32, device=dev)
+        scratch = torch.empty(_lib.raw('mve_density_grid_scratch_bytes')(n_cells), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call('mve_density_grid_points', _lib.ptr(coords), _lib.ptr(noise), N, H, self.bound, _lib.ptr(xyzs),
+                      _lib.ptr(indices), _lib.stream_ptr(dev))
+            sigmas, _ = dec.point_decode(xyzs, density_only=True)
+            _lib.call('mve_density_grid_update', _lib.ptr(density_grid), _lib.ptr(tmp), n_cells, _lib.ptr(sigmas), _lib.ptr(indices),
+                      N, float(decay), _lib.ptr(mean), _lib.ptr(scratch), _lib.stream_ptr(dev))
+        thresh = min(float(mean.item()), density_thresh)              # the reference reads the mean on the host too (:171-174)
+        rm.packbits(density_grid, thresh, density_bitfield)
+        return iter_density + 1, thresh
+
+    def forward(self, rays_o, rays_d, density_bitfield, grid_size, dt_gamma=0.0, perturb=False, noises=None):
+        """rays_o, rays_d [N,3] of one scene.  Returns the reference's result dict (weights, weights_sum, depth, image, rays,
+        ts; lists of one entry where the reference returns per-scene lists)."""
+        from . import raymarching as rm
+        dec = self.decoder
+        if not self.training:
+            ws, depth, image = dec.render_rays(rays_o, rays_d, density_bitfield, grid_size, dt_gamma)
+            return dict(weights=None, weights_sum=[ws], depth=[depth], image=[image], rays=None, normal=[None], ts=None)
+        nears, fars = rm.near_far_from_aabb(rays_o, rays_d, dec.aabb, self.min_near)
+        xyzs, dirs, ts, rays = rm.march_rays_train(rays_o, rays_d, self.bound, density_bitfield, 1, grid_size, nears, fars,
+                                                   perturb=perturb, dt_gamma=float(dt_gamma), max_steps=self.max_steps, noises=noises)
+        if self.weight_culling_th > 0:
+            sigmas, _ = dec.point_decode(xyzs, density_only=True)
+            weights, _, _, _ = rm.batch_composite_rays_train(sigmas, sigmas.new_zeros(sigmas.shape[0], 3), [ts], [rays], [ts.shape[0]])
+            xyzs, dirs, ts, rays = rm.cull_samples(weights, self.weight_culling_th, xyzs, dirs, ts, rays)
+        sigmas, rgbs = dec.point_decode(xyzs)
+        weights, weights_sum, depth, image = rm.batch_composite_rays_train(sigmas, rgbs, [ts], [rays], [ts.shape[0]])
+        return dict(weights=weights, weights_sum=weights_sum, depth=depth, image=image, rays=[rays], normal=None, ts=[ts])

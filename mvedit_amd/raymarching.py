@@ -298,3 +298,22 @@ def compact_alive(rays_alive, n_alive):
         _lib.call('mve_compact_alive', _lib.ptr(rays_alive), int(n_alive), _lib.ptr(out), _lib.ptr(n_out),
                   _lib.ptr(scratch), _s(rays_alive))
     return out, n_out
+
+
+def cull_samples(weights, threshold, xyzs, dirs, ts, rays):
+    """Train-branch weight culling (base_volume_renderer.py:222-243): keep samples with weight > threshold (order preserving)
+    and re-index rays.  -> xyzs', dirs', ts', rays' (new tensors)."""
+    weights = _gpu_f32(weights)
+    dev = weights.device
+    M, N = weights.shape[0], rays.shape[0]
+    o_xyzs, o_dirs, o_ts = torch.empty_like(xyzs), torch.empty_like(dirs), torch.empty_like(ts)
+    o_rays = torch.empty_like(rays)
+    pref = torch.empty(M + 1, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(_lib.raw('mve_cull_scratch_bytes')(M), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('mve_cull_samples', _lib.ptr(weights), M, float(threshold), _lib.ptr(rays), N, _lib.ptr(xyzs), _lib.ptr(dirs),
+                  _lib.ptr(ts), _lib.ptr(o_xyzs), _lib.ptr(o_dirs), _lib.ptr(o_ts), _lib.ptr(o_rays), _lib.ptr(pref), _lib.ptr(total),
+                  _lib.ptr(scratch), _s(weights))
+    k = int(total.item())      # the reference's boolean-mask indexing synchronises here as well
+    return o_xyzs[:k], o_dirs[:k], o_ts[:k], o_rays

@@ -230,3 +230,48 @@ def nerf_render(params, bitfield, grid_size, h, w, intrinsics, poses, dt_gamma_s
     normal_fg = depth_to_normal(depth_fg, directions)
     normal = normal_fg * rgba[..., 3:] + np.asarray(normal_bg, np.float32) * (1 - rgba[..., 3:])
     return rgba.astype(np.float32), depth.astype(np.float32), normal.astype(np.float32), normal_fg
+
+
+# ---------------------------------------------------------------------------------------------------
+# train branch forward and density-grid refresh (lib/models/decoders/base_volume_renderer.py:105-262)
+# ---------------------------------------------------------------------------------------------------
+def cull_samples(weights, th, xyzs, dirs, ts, rays):
+    """:222-243: boolean-mask gather + cumsum re-indexing of rays (offset, count)."""
+    mask = weights > np.float32(th)
+    filt = np.concatenate([[0], np.cumsum(mask)]).astype(np.int64)
+    start = filt[rays[:, 0]]
+    end = filt[rays[:, 0] + rays[:, 1]]
+    return xyzs[mask], dirs[mask], ts[mask], np.stack([start, end - start], axis=-1).astype(np.int32), filt.astype(np.int32)
+
+
+def density_grid_points(coords, noise, H, bound=1.0):
+    """:129-135 / :158-160: Morton index and jittered centre of each cell."""
+    coords = np.asarray(coords, np.int64)
+    xyzs = ((coords.astype(np.float32) - np.float32((H - 1) / 2)) * np.float32(2 * bound / H)).astype(np.float32)
+    hw = np.float32(bound / H)
+    xyzs = (xyzs + (noise * (np.float32(2) * hw) - hw)).astype(np.float32)
+    return xyzs, ORM.morton3D(coords.astype(np.int32))
+
+
+def density_grid_update(grid, sigmas, indices, decay=0.9):
+    """:140-141, :166-171 -> (new grid, mean of clamp(grid, 0))."""
+    tmp = np.full_like(grid, -1)
+    tmp[indices] = np.minimum(sigmas, np.finfo(np.float32).max)
+    valid = (grid >= 0) & (tmp >= 0)
+    out = np.where(valid, np.maximum(grid * np.float32(decay), tmp), grid).astype(np.float32)
+    return out, np.float32(np.maximum(out, 0).astype(np.float64).mean())
+
+
+def train_forward(rays_o, rays_d, bitfield, grid_size, params, noises, dt_gamma=0.0, bound=1.0, min_near=0.2, max_steps=1024,
+                  weight_culling_th=1e-3):
+    """VolumeRenderer.forward, self.training branch (:207-262) for one scene without normals."""
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = ORM.near_far_from_aabb(rays_o, rays_d, aabb, min_near)
+    xyzs, dirs, ts, rays = ORM.march_rays_train(rays_o, rays_d, bound, bitfield, 1, grid_size, nears, fars, noises, dt_gamma, max_steps)
+    if weight_culling_th > 0:
+        sig, _ = point_decode(xyzs, params, bound)
+        w, _, _, _ = ORM.composite_rays_train(sig, np.zeros((sig.shape[0], 3), np.float32), ts, rays)
+        xyzs, dirs, ts, rays, _ = cull_samples(w, weight_culling_th, xyzs, dirs, ts, rays)
+    sig, rgb = point_decode(xyzs, params, bound)
+    weights, ws, depth, image = ORM.composite_rays_train(sig, rgb, ts, rays)
+    return dict(weights=weights, weights_sum=ws, depth=depth, image=image, rays=rays, ts=ts, xyzs=xyzs)

@@ -147,3 +147,114 @@ def test_gpu_nerf_render_seam(lib):
         err = np.abs(got[0].cpu().numpy() - ref)
         assert (err < 1e-3).mean() > 0.995 and err.mean() < 1e-4, (name, err.max(), err.mean())
     assert (rgba_o[..., 3] > 0.5).mean() > 0.05
+
+
+@pytest.mark.gpu
+def test_gpu_cull_samples_bit_exact(lib):
+    """Weight culling + ray re-indexing (base_volume_renderer.py:222-243) is index arithmetic: bit-exact."""
+    from mvedit_amd import raymarching as rm
+    rng = np.random.default_rng(5)
+    N = 3000
+    cnt = rng.integers(0, 40, N).astype(np.int32)
+    cnt[rng.random(N) < 0.2] = 0
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+    M = int(cnt.sum())
+    rays = np.stack([off, cnt], -1).astype(np.int32)
+    w = rng.random(M).astype(np.float32) * 4e-3
+    w[rng.random(M) < 0.05] = 1e-3                         # exactly at the threshold: strict '>' drops them
+    xyzs, dirs = rng.normal(size=(M, 3)).astype(np.float32), rng.normal(size=(M, 3)).astype(np.float32)
+    ts = rng.random((M, 2)).astype(np.float32)
+    xo, do, to, ro, _ = NO.cull_samples(w, 1e-3, xyzs, dirs, ts, rays)
+    t = lambda a: torch.from_numpy(a).cuda()
+    xh, dh, th, rh = rm.cull_samples(t(w), 1e-3, t(xyzs), t(dirs), t(ts), t(rays))
+    assert 0.3 * M < xo.shape[0] < 0.9 * M
+    for a, b in ((xh, xo), (dh, do), (th, to), (rh, ro)):
+        assert a.shape == b.shape and (a.cpu().numpy() == b).all()
+    # nothing survives / everything survives / empty input
+    assert rm.cull_samples(t(w), 1.0, t(xyzs), t(dirs), t(ts), t(rays))[0].shape[0] == 0
+    allk = rm.cull_samples(t(w), -1.0, t(xyzs), t(dirs), t(ts), t(rays))
+    assert torch.equal(allk[0], t(xyzs)) and torch.equal(allk[3], t(rays))
+    e = rm.cull_samples(t(w[:0]), 1e-3, t(xyzs[:0]), t(dirs[:0]), t(ts[:0]), t(np.zeros((4, 2), np.int32)))
+    assert e[0].shape[0] == 0 and (e[3] == 0).all()
+
+
+@pytest.mark.gpu
+def test_gpu_train_branch_forward(lib):
+    """VolumeRenderer.forward, training branch without autograd (base_volume_renderer.py:207-262)."""
+    from mvedit_amd.nerf import VolumeRenderer
+    p, dec = _decoder(12, 320, table_scale=2.0)
+    H = 64
+    bits = ORM.packbits(sphere_density_grid(H, radius=0.55), 0.5)
+    o, d = scene_rays(1, 64, seed=4)
+    noises = np.random.default_rng(2).random(o.shape[0]).astype(np.float32)
+    ref = NO.train_forward(o, d, bits, H, p, noises, dt_gamma=1 / 256, max_steps=256)
+    dec.max_steps = 256
+    vr = VolumeRenderer(dec)
+    vr.training = True
+    out = vr.forward(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(bits), H, dt_gamma=1 / 256, noises=torch.from_numpy(noises))
+    M_o, M_h = ref['ts'].shape[0], out['ts'][0].shape[0]
+    assert M_o > 5000 and abs(M_o - M_h) <= 3, (M_o, M_h)        # a weight within float noise of 1e-3 may flip
+    # a flipped sample carries weight ~1e-3: per-ray tolerance 1.5e-3, tight on average
+    for k in ('weights_sum', 'depth', 'image'):
+        a, b = out[k][0].cpu().numpy(), ref[k]
+        assert np.abs(a - b).max() < 1.5e-3 and np.abs(a - b).mean() < 1e-5, k
+    assert (ref['weights_sum'] > 0.5).mean() > 0.1
+    vr.weight_culling_th = 0
+    out0 = vr.forward(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(bits), H, dt_gamma=1 / 256, noises=torch.from_numpy(noises))
+    assert out0['ts'][0].shape[0] > M_h
+    # every culled sample weighs < 1e-3, so the un-culled image stays close on average
+    assert np.abs(out0['image'][0].cpu().numpy() - ref['image']).mean() < 5e-3
+
+
+@pytest.mark.gpu
+def test_gpu_update_extra_state(lib):
+    """Density-grid refresh (base_volume_renderer.py:105-177): kernels against the oracle on given jitter, then the mirror's
+    full and partial updates for their invariants (the draws themselves come from torch's device RNG)."""
+    import ctypes
+    from mvedit_amd import _lib, raymarching as rm
+    from mvedit_amd.nerf import VolumeRenderer
+    p, dec = _decoder(12, 320, table_scale=2.0)
+    H = 32
+    n = H ** 3
+    rng = np.random.default_rng(9)
+    t = lambda a: torch.from_numpy(a).cuda()
+    for coords in (None, rng.integers(0, H, (5000, 3)).astype(np.int32)):
+        N = n if coords is None else coords.shape[0]
+        noise = rng.random((N, 3)).astype(np.float32)
+        cc = np.stack(np.meshgrid(*[np.arange(H)] * 3, indexing='ij'), -1).reshape(-1, 3) if coords is None else coords
+        x_o, idx_o = NO.density_grid_points(cc, noise, H)
+        xyzs, idx = torch.empty(N, 3, device='cuda'), torch.empty(N, dtype=torch.int32, device='cuda')
+        d_coords, d_noise = (t(coords) if coords is not None else None), t(noise)     # keep device inputs alive across the call
+        _lib.call('mve_density_grid_points', _lib.ptr(d_coords), _lib.ptr(d_noise), N, H, 1.0, _lib.ptr(xyzs), _lib.ptr(idx), None)
+        assert (idx.cpu().numpy() == idx_o).all()
+        np.testing.assert_allclose(xyzs.cpu().numpy(), x_o, rtol=0, atol=1e-7)
+        grid = rng.random(n).astype(np.float32) * 2
+        grid[rng.random(n) < 0.1] = -1
+        sig = (rng.random(N).astype(np.float32) * 3)
+        if coords is not None:                     # duplicate cells would make the scatter order matter: de-duplicate
+            _, first = np.unique(idx_o, return_index=True)
+            idx_o, sig = idx_o[first], sig[first]
+        g_o, mean_o = NO.density_grid_update(grid, sig, idx_o, 0.9)
+        g, tmp = t(grid.copy()), torch.full((n,), -1.0, device='cuda')
+        mean = torch.empty(1, device='cuda')
+        scratch = torch.empty(_lib.raw('mve_density_grid_scratch_bytes')(n), dtype=torch.uint8, device='cuda')
+        d_sig, d_idx = t(sig), t(idx_o.astype(np.int32))
+        _lib.call('mve_density_grid_update', _lib.ptr(g), _lib.ptr(tmp), n, _lib.ptr(d_sig), _lib.ptr(d_idx), sig.shape[0], 0.9,
+                  _lib.ptr(mean), _lib.ptr(scratch), None)
+        torch.cuda.synchronize()
+        assert (g.cpu().numpy() == g_o).all()
+        np.testing.assert_allclose(mean.item(), mean_o, rtol=1e-6)
+    vr = VolumeRenderer(dec)
+    grid = torch.zeros(1, n, device='cuda')
+    bitfield = torch.zeros(1, n // 8, dtype=torch.uint8, device='cuda')
+    it = 0
+    torch.manual_seed(0)
+    for it_expected in (1, 2):
+        it, th = vr.update_extra_state(grid, bitfield, it)
+        assert it == it_expected and 0 < th <= 0.01
+    assert (grid > 0).all()                                           # sigma = exp(...) > 0 everywhere after a full update
+    assert (bitfield.cpu().numpy() == ORM.packbits(grid[0].cpu().numpy(), th)).all()
+    before = grid.clone()
+    it, th = vr.update_extra_state(grid, bitfield, 16)                # partial update touches at most half of the cells
+    changed = (grid != before).float().mean().item()
+    assert it == 17 and (grid >= before * 0.9 - 1e-7).all() and 0.05 < changed
