@@ -374,6 +374,22 @@ MVE_API int mve_bake_accumulate(const float* d_tex_rast, const int32_t* d_f, int
                                 int map_size, float* d_accum, void* stream);
 MVE_API int mve_bake_finalize(const float* d_accum, int map_size, float* d_albedo_chw, void* stream);
 
+/* Remaining pieces of MeshRenderer.forward (base_mesh_renderer.py:207-395):
+ *   edge_opposites   : per triangle edge e = (tri[e], tri[(e+1)%3]) the vertex opposite to it in the one other triangle sharing the
+ *                      edge, -1 for boundary / non-manifold edges (what dr.antialias derives from the topology) -> opp [F,3];
+ *   antialias        : dr.antialias(color [B,h,w,C], rast, pos [B,V,4], tri) (:289-293) with the silhouette rules specified in
+ *                      oracle/raster_oracle.c; d_out must not alias d_color;
+ *   texture_bilinear : dr.texture(tex [Bt,th,tw,C] (Bt = 1 broadcasts), uv [n,h,w,2]) with the bilinear filter and wrap addressing;
+ *                      pixels with rast[...,3] == 0 are written as 0 when d_rast is given (:258-263);
+ *   box_downsample   : F.interpolate(mode='area', scale_factor=1/factor) on channel-last images (interpolate_hwc, :15-19, :380-383). */
+MVE_API size_t mve_edge_opposites_workspace_bytes(int F);
+MVE_API int mve_edge_opposites(const int32_t* d_tri, int F, int32_t* d_opp, void* d_workspace, size_t workspace_bytes, void* stream);
+MVE_API int mve_antialias(const float* d_color, int B, int H, int W, int C, const float* d_rast, const float* d_pos, int V,
+                          const int32_t* d_tri, int F, const int32_t* d_opp, float* d_out, void* stream);
+MVE_API int mve_texture_bilinear(const float* d_tex, int Bt, int th, int tw, int C, const float* d_uv, const float* d_rast, int n, int h,
+                                 int w, float* d_out, void* stream);
+MVE_API int mve_box_downsample(const float* d_x, int B, int H, int W, int C, int factor, float* d_y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

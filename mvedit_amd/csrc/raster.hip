@@ -431,3 +431,241 @@ int mve_bake_finalize(const float* d_accum, int map_size, float* d_albedo_chw, v
 }
 
 }  // extern "C"
+
+// =========================================================================================================
+// dr.antialias, dr.texture (bilinear) and the SSAA box filter of MeshRenderer.forward (base_mesh_renderer.py:258-263, :289-293,
+// :380-383).  The antialias rules are the ones specified in oracle/raster_oracle.c (nvdiffrast itself is unavailable).
+// =========================================================================================================
+namespace {
+
+constexpr unsigned long long EMPTY_KEY = ~0ull;
+
+__device__ __forceinline__ unsigned long long edge_key(int a, int b) {
+    const unsigned ua = (unsigned)a, ub = (unsigned)b;
+    return ua < ub ? ((unsigned long long)ua << 32 | ub) : ((unsigned long long)ub << 32 | ua);
+}
+__device__ __forceinline__ unsigned edge_hash(unsigned long long k, unsigned mask) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned)k & mask;
+}
+
+// open-addressing table keyed by the undirected edge; every slot counts its users and remembers the first two
+__global__ __launch_bounds__(RB) void k_edge_insert(const int32_t* __restrict__ tri, int F, unsigned mask, unsigned long long* __restrict__ keys,
+                                                    int* __restrict__ cnt, int* __restrict__ ent) {
+    const int i = blockIdx.x * RB + threadIdx.x;
+    if (i >= 3 * F) return;
+    const int f = i / 3, e = i - 3 * f;
+    const unsigned long long key = edge_key(tri[3 * f + e], tri[3 * f + (e + 1) % 3]);
+    unsigned h = edge_hash(key, mask);
+    for (;;) {
+        const unsigned long long old = atomicCAS(keys + h, EMPTY_KEY, key);
+        if (old == EMPTY_KEY || old == key) {
+            const int slot = atomicAdd(cnt + h, 1);
+            if (slot < 2) ent[2 * h + slot] = i;
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+__global__ __launch_bounds__(RB) void k_edge_opposites(const int32_t* __restrict__ tri, int F, unsigned mask,
+                                                       const unsigned long long* __restrict__ keys, const int* __restrict__ cnt,
+                                                       const int* __restrict__ ent, int32_t* __restrict__ opp) {
+    const int i = blockIdx.x * RB + threadIdx.x;
+    if (i >= 3 * F) return;
+    const int f = i / 3, e = i - 3 * f;
+    const unsigned long long key = edge_key(tri[3 * f + e], tri[3 * f + (e + 1) % 3]);
+    unsigned h = edge_hash(key, mask);
+    while (keys[h] != key) h = (h + 1) & mask;
+    int o = -1;
+    if (cnt[h] == 2) {
+        const int other = ent[2 * h] == i ? ent[2 * h + 1] : ent[2 * h];
+        o = tri[3 * (other / 3) + (other % 3 + 2) % 3];
+    }
+    opp[i] = o;
+}
+
+struct AAView { const float* rast; const float* pos; const int32_t* tri; const int32_t* opp; int V, F, H, W; };
+
+// the pair rule of oracle/raster_oracle.c:aa_pair, operation for operation
+__device__ __forceinline__ bool aa_pair(const AAView& a, int px, int py, int qx, int qy, bool& dst_is_p, float& wgt) {
+    const f32x4 rp = reinterpret_cast<const f32x4*>(a.rast)[(size_t)py * a.W + px];
+    const f32x4 rq = reinterpret_cast<const f32x4*>(a.rast)[(size_t)qy * a.W + qx];
+    const int ip = (int)rp[3] - 1, iq = (int)rq[3] - 1;
+    if (ip == iq) return false;
+    bool use_p;
+    if (ip < 0) use_p = false;
+    else if (iq < 0) use_p = true;
+    else if (rp[2] != rq[2]) use_p = rp[2] < rq[2];
+    else use_p = (py * a.W + px) < (qy * a.W + qx);
+    const int t = use_p ? ip : iq;
+    if (t < 0 || t >= a.F) return false;
+    const int ox = use_p ? px : qx, oy = use_p ? py : qy, nx = use_p ? qx : px, ny = use_p ? qy : py;
+    float sx[3], sy[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int vi = a.tri[3 * t + k];
+        if (vi < 0 || vi >= a.V) return false;
+        const f32x4 v = reinterpret_cast<const f32x4*>(a.pos)[vi];
+        if (v[3] <= 1e-6f) return false;
+        sx[k] = (v[0] / v[3] * 0.5f + 0.5f) * (float)a.W;
+        sy[k] = (v[1] / v[3] * 0.5f + 0.5f) * (float)a.H;
+    }
+    const float cx = (float)ox + 0.5f, cy = (float)oy + 0.5f;
+    const float dx = (float)(nx - ox), dy = (float)(ny - oy);
+    float best = 2.0f;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int ia = e, ib = (e + 1) % 3, ic = (e + 2) % 3;
+        const float ex = sx[ib] - sx[ia], ey = sy[ib] - sy[ia];
+        const int o = a.opp[3 * t + e];
+        if (o >= 0) {
+            if (o >= a.V) continue;
+            const f32x4 v = reinterpret_cast<const f32x4*>(a.pos)[o];
+            if (v[3] <= 1e-6f) continue;
+            const float oxs = (v[0] / v[3] * 0.5f + 0.5f) * (float)a.W, oys = (v[1] / v[3] * 0.5f + 0.5f) * (float)a.H;
+            const float sc = ex * (sy[ic] - sy[ia]) - ey * (sx[ic] - sx[ia]);
+            const float so = ex * (oys - sy[ia]) - ey * (oxs - sx[ia]);
+            if (!(sc * so >= 0.0f)) continue;
+        }
+        float s, tt;
+        if (dy == 0.0f) {
+            if (ey == 0.0f) continue;
+            s = (cy - sy[ia]) / ey;
+            tt = ((sx[ia] + s * ex) - cx) * dx;
+        } else {
+            if (ex == 0.0f) continue;
+            s = (cx - sx[ia]) / ex;
+            tt = ((sy[ia] + s * ey) - cy) * dy;
+        }
+        if (s >= 0.0f && s <= 1.0f && tt >= 0.0f && tt <= 1.0f && tt < best) best = tt;
+    }
+    if (best > 1.0f) return false;
+    if (best > 0.5f) { dst_is_p = !use_p; wgt = best - 0.5f; }
+    else if (best < 0.5f) { dst_is_p = use_p; wgt = 0.5f - best; }
+    else return false;
+    return true;
+}
+
+template <int C>
+__global__ __launch_bounds__(RB) void k_antialias(const float* __restrict__ color, int B, int H, int W, int Cdyn, const float* __restrict__ rast,
+                                                  const float* __restrict__ pos, int V, const int32_t* __restrict__ tri, int F,
+                                                  const int32_t* __restrict__ opp, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    const size_t npix = (size_t)H * W;
+    if (i >= (size_t)B * npix) return;
+    const int b = (int)(i / npix), y = (int)((i % npix) / W), x = (int)(i % W);
+    const int Cn = C > 0 ? C : Cdyn;
+    AAView a{rast + (size_t)b * npix * 4, pos + (size_t)b * V * 4, tri, opp, V, F, H, W};
+    const float* col = color + (size_t)b * npix * Cn;
+    const float* self = col + ((size_t)y * W + x) * Cn;
+    float* dst = out + i * Cn;
+    for (int c = 0; c < Cn; ++c) dst[c] = self[c];
+    const int ddx[4] = {-1, 1, 0, 0}, ddy[4] = {0, 0, -1, 1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qx = x + ddx[k], qy = y + ddy[k];
+        if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+        bool dst_is_p;
+        float w;
+        if (!aa_pair(a, x, y, qx, qy, dst_is_p, w) || !dst_is_p) continue;
+        const float* nb = col + ((size_t)qy * W + qx) * Cn;
+        for (int c = 0; c < Cn; ++c) dst[c] = dst[c] + w * (nb[c] - self[c]);
+    }
+}
+
+__global__ __launch_bounds__(RB) void k_texture_bilinear(const float* __restrict__ tex, int Bt, int th, int tw, int C,
+                                                         const float* __restrict__ uv, const float* __restrict__ rast, size_t npix_total,
+                                                         size_t npix_view, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= npix_total) return;
+    float* o = out + i * C;
+    if (rast && !(rast[4 * i + 3] > 0.0f)) { for (int c = 0; c < C; ++c) o[c] = 0.0f; return; }
+    const float* t = tex + (Bt > 1 ? (i / npix_view) * (size_t)th * tw * C : 0);
+    int ix[2], iy[2];
+    float wx[2], wy[2];
+    bilinear_taps(uv[2 * i], uv[2 * i + 1], tw, th, ix, iy, wx, wy);
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc += (wx[k] * wy[j]) * t[((size_t)iy[j] * tw + ix[k]) * C + c];
+        o[c] = acc;
+    }
+}
+
+// F.interpolate(mode='area', scale 1/f) on channel-last images: mean over f x f boxes
+__global__ __launch_bounds__(RB) void k_box_downsample(const float* __restrict__ x, int B, int H, int W, int C, int f, float* __restrict__ y) {
+    const int Ho = H / f, Wo = W / f;
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= (size_t)B * Ho * Wo * C) return;
+    const int c = (int)(i % C), xo = (int)((i / C) % Wo), yo = (int)((i / ((size_t)C * Wo)) % Ho), b = (int)(i / ((size_t)C * Wo * Ho));
+    float acc = 0.0f;
+    for (int dy = 0; dy < f; ++dy)
+        for (int dx = 0; dx < f; ++dx) acc += x[(((size_t)b * H + yo * f + dy) * W + xo * f + dx) * C + c];
+    y[i] = acc / (float)(f * f);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mve_edge_opposites_workspace_bytes(int F) {
+    size_t T = 16;
+    while (T < (size_t)12 * (F > 0 ? F : 1)) T <<= 1;
+    return T * (8 + 4 + 8) + 256;
+}
+
+int mve_edge_opposites(const int32_t* d_tri, int F, int32_t* d_opp, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (F == 0) return MVE_OK;
+    MVE_CHECK(d_tri && d_opp && d_workspace, MVE_ERR_ARG, "edge_opposites: null pointer");
+    MVE_CHECK(workspace_bytes >= mve_edge_opposites_workspace_bytes(F), MVE_ERR_NOMEM, "edge_opposites: workspace too small");
+    size_t T = 16;
+    while (T < (size_t)12 * F) T <<= 1;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* keys = (unsigned long long*)d_workspace;
+    int* cnt = (int*)(keys + T);
+    int* ent = cnt + T;
+    MVE_HIP(hipMemsetAsync(keys, 0xff, T * 8, s));
+    MVE_HIP(hipMemsetAsync(cnt, 0, T * 4, s));
+    k_edge_insert<<<mve_cdiv(3 * F, RB), RB, 0, s>>>(d_tri, F, (unsigned)(T - 1), keys, cnt, ent);
+    MVE_LAUNCH_CHECK();
+    k_edge_opposites<<<mve_cdiv(3 * F, RB), RB, 0, s>>>(d_tri, F, (unsigned)(T - 1), keys, cnt, ent, d_opp);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_antialias(const float* d_color, int B, int H, int W, int C, const float* d_rast, const float* d_pos, int V, const int32_t* d_tri,
+                  int F, const int32_t* d_opp, float* d_out, void* stream) {
+    const size_t total = (size_t)B * H * W;
+    if (total == 0 || C == 0) return MVE_OK;
+    MVE_CHECK(d_color && d_rast && d_pos && d_tri && d_opp && d_out && d_out != d_color, MVE_ERR_ARG, "antialias: bad arguments (out must not alias color)");
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 8) k_antialias<8><<<mve_cdiv(total, RB), RB, 0, s>>>(d_color, B, H, W, C, d_rast, d_pos, V, d_tri, F, d_opp, d_out);
+    else if (C == 4) k_antialias<4><<<mve_cdiv(total, RB), RB, 0, s>>>(d_color, B, H, W, C, d_rast, d_pos, V, d_tri, F, d_opp, d_out);
+    else k_antialias<0><<<mve_cdiv(total, RB), RB, 0, s>>>(d_color, B, H, W, C, d_rast, d_pos, V, d_tri, F, d_opp, d_out);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_texture_bilinear(const float* d_tex, int Bt, int th, int tw, int C, const float* d_uv, const float* d_rast, int n, int h, int w,
+                         float* d_out, void* stream) {
+    const size_t total = (size_t)n * h * w;
+    if (total == 0 || C == 0) return MVE_OK;
+    MVE_CHECK(d_tex && d_uv && d_out && th > 0 && tw > 0 && (Bt == 1 || Bt == n), MVE_ERR_ARG, "texture_bilinear: bad arguments");
+    k_texture_bilinear<<<mve_cdiv(total, RB), RB, 0, (hipStream_t)stream>>>(d_tex, Bt, th, tw, C, d_uv, d_rast, total, (size_t)h * w, d_out);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_box_downsample(const float* d_x, int B, int H, int W, int C, int factor, float* d_y, void* stream) {
+    MVE_CHECK(factor >= 1 && H % factor == 0 && W % factor == 0, MVE_ERR_ARG, "box_downsample: %dx%d not divisible by %d", H, W, factor);
+    const size_t total = (size_t)B * (H / factor) * (W / factor) * C;
+    if (total == 0) return MVE_OK;
+    MVE_CHECK(d_x && d_y, MVE_ERR_ARG, "box_downsample: null pointer");
+    k_box_downsample<<<mve_cdiv(total, RB), RB, 0, (hipStream_t)stream>>>(d_x, B, H, W, C, factor, d_y);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+}  // extern "C"

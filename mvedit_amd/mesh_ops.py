@@ -49,10 +49,60 @@ def interpolate(attr, rast, tri):
     return out
 
 
+def edge_opposites(tri):
+    """opp [F,3] int32: vertex opposite to edge e of every triangle in the adjacent triangle (-1: boundary / non-manifold)."""
+    tri = tri.to(torch.int32).contiguous()
+    F = tri.shape[0]
+    opp = torch.empty_like(tri)
+    nbytes = _lib.raw('mve_edge_opposites_workspace_bytes')(F)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=tri.device)
+    with torch.cuda.device(tri.device):
+        _lib.call('mve_edge_opposites', _lib.ptr(tri), F, _lib.ptr(opp), _lib.ptr(ws), nbytes, _lib.stream_ptr(tri.device))
+    return opp
+
+
+def antialias(color, rast, pos, tri, opp=None):
+    """dr.antialias(color, rast, pos, tri): color [B,h,w,C] -> same shape (rules: oracle/raster_oracle.c)."""
+    color, rast, pos = color.float().contiguous(), rast.contiguous(), pos.float().contiguous()
+    tri = tri.to(torch.int32).contiguous()
+    opp = edge_opposites(tri) if opp is None else opp
+    B, h, w, C = color.shape
+    out = torch.empty_like(color)
+    with torch.cuda.device(color.device):
+        _lib.call('mve_antialias', _lib.ptr(color), B, h, w, C, _lib.ptr(rast), _lib.ptr(pos), pos.shape[1], _lib.ptr(tri), tri.shape[0],
+                  _lib.ptr(opp), _lib.ptr(out), _lib.stream_ptr(color.device))
+    return out
+
+
+def texture(tex, uv, rast=None):
+    """dr.texture(tex [1|n,th,tw,C], uv [n,h,w,2]) with the bilinear filter, wrap addressing; background -> 0 when rast is given."""
+    tex, uv = tex.float().contiguous(), uv.float().contiguous()
+    n, h, w, _ = uv.shape
+    out = torch.empty(n, h, w, tex.shape[-1], dtype=torch.float32, device=uv.device)
+    with torch.cuda.device(uv.device):
+        _lib.call('mve_texture_bilinear', _lib.ptr(tex), tex.shape[0], tex.shape[1], tex.shape[2], tex.shape[3], _lib.ptr(uv),
+                  _lib.ptr(rast.contiguous()) if rast is not None else None, n, h, w, _lib.ptr(out), _lib.stream_ptr(uv.device))
+    return out
+
+
+def box_downsample(x, factor):
+    """interpolate_hwc(x, 1/factor) (mode='area') for x [..., H, W, C]."""
+    lead = x.shape[:-3]
+    H, W, C = x.shape[-3:]
+    x = x.float().contiguous()
+    y = torch.empty(*lead, H // factor, W // factor, C, dtype=torch.float32, device=x.device)
+    B = 1
+    for d in lead:
+        B *= d
+    with torch.cuda.device(x.device):
+        _lib.call('mve_box_downsample', _lib.ptr(x), B, H, W, C, int(factor), _lib.ptr(y), _lib.stream_ptr(x.device))
+    return y
+
+
 class MeshRenderer:
-    """Geometry half of the reference's MeshRenderer.forward (base_mesh_renderer.py:207-300) for one mesh:
-    vertex transform, rasterise, interpolated inverse depth and camera-space normals, alpha.  Texturing (dr.texture with
-    mip-maps), shading_fun re-shading and dr.antialias are not implemented yet (next rows of SURVEY section 8)."""
+    """The reference's MeshRenderer for one mesh (num_scenes = 1, as in every MVEdit pipeline):
+    forward (base_mesh_renderer.py:207-395) and bake_multiview (:507-603).  Texture fetches are bilinear (the reference's
+    default 'linear-mipmap-linear' pyramid is not reproduced); forward is inference-only (no autograd through the kernels)."""
 
     def __init__(self, near=0.1, far=10, ssaa=1):
         self.near, self.far, self.ssaa = near, far, ssaa
@@ -72,7 +122,8 @@ class MeshRenderer:
         v_clip = torch.nn.functional.pad(v_cam, (0, 1), value=1.0) @ proj.transpose(-1, -2)
         return v_cam, v_clip, r_c2w
 
-    def __call__(self, v, f, vn, fn, poses, intrinsics, h, w, normal_bg=(0.5, 0.5, 1.0)):
+    def render_geometry(self, v, f, vn, fn, poses, intrinsics, h, w, normal_bg=(0.5, 0.5, 1.0)):
+        """rasterise + depth + camera-space normals + alpha (the texture-free part of forward)."""
         if self.ssaa > 1:
             h, w, intrinsics = h * self.ssaa, w * self.ssaa, intrinsics * self.ssaa
         v_cam, v_clip, r_c2w = self.project(v.float(), poses.float(), intrinsics.float(), h, w)
@@ -83,7 +134,53 @@ class MeshRenderer:
         normal = torch.nn.functional.normalize(interpolate(vn[None], rast, fn), dim=-1)
         rot_normal = (normal @ r_c2w[:, None]) / 2 + 0.5
         rot_normal[~fg] = rot_normal.new_tensor(normal_bg)
-        return dict(rast=rast, alpha=fg.float()[..., None], depth=depth, normal=rot_normal)
+        return dict(rast=rast, alpha=fg.float()[..., None], depth=depth, normal=rot_normal, v_clip=v_clip, world_normal=normal)
+
+    def forward(self, meshes, poses, intrinsics, h, w, shading_fun=None, dilate_edges=0, normal_bg=(0.5, 0.5, 1.0), aa=True,
+                render_vc=False):
+        """Same signature / result as the reference: poses [1,b,3|4,4], intrinsics [1,b,4] ->
+        dict(rgba [1,b,h,w,4], depth [1,b,h,w], normal [1,b,h,w,3])."""
+        assert len(meshes) == 1 and poses.shape[0] == 1, 'one mesh per call (num_scenes = 1)'
+        mesh = meshes[0]
+        ssaa = self.ssaa
+        self.ssaa = 1                                               # render_geometry would scale again
+        try:
+            hh, ww, intr = h * ssaa, w * ssaa, intrinsics[0].float() * ssaa
+            f = mesh.f.to(torch.int32).contiguous()
+            fn = mesh.fn if getattr(mesh, 'fn', None) is not None else f
+            g = self.render_geometry(mesh.v.float(), f, mesh.vn.float(), fn, poses[0].float(), intr, hh, ww, normal_bg)
+        finally:
+            self.ssaa = ssaa
+        rast, alpha, depth, rot_normal = g['rast'], g['alpha'], g['depth'], g['normal']
+        fg = rast[..., 3] > 0
+        if getattr(mesh, 'vt', None) is not None and getattr(mesh, 'albedo', None) is not None:
+            texc = interpolate(mesh.vt[None], rast, mesh.ft)
+            albedo = texture(mesh.albedo[None, ..., :3], texc, rast)                  # background written as 0 (:262)
+        elif getattr(mesh, 'vc', None) is not None:
+            rgba = interpolate(mesh.vc.float()[None] if mesh.vc.dim() == 2 else mesh.vc.float(), rast, f)
+            alpha = alpha * rgba[..., 3:4]
+            albedo = rgba[..., :3] * alpha
+        else:
+            albedo = torch.zeros_like(rot_normal)
+        if shading_fun is not None:                                                   # :271-281
+            xyz = interpolate(mesh.v.float()[None], rast, f)
+            rgb = shading_fun(world_pos=xyz[fg], albedo=albedo[fg], world_normal=g['world_normal'][fg], fg_mask=fg[None])
+            albedo = torch.zeros_like(albedo)
+            albedo[fg] = rgb.float()
+        rgba = torch.cat([albedo, alpha], dim=-1)
+        if dilate_edges > 0:
+            x = rgba.permute(0, 3, 1, 2)
+            rgba = edge_dilation(x, x[:, 3:], dilate_edges).permute(0, 2, 3, 1)
+        if aa:
+            packed = antialias(torch.cat([rgba, depth[..., None], rot_normal], dim=-1), rast, g['v_clip'], f)
+            rgba, depth, rot_normal = packed[..., :4], packed[..., 4], packed[..., 5:8]
+        if ssaa > 1:
+            rgba = box_downsample(rgba, ssaa)
+            depth = box_downsample(depth[..., None], ssaa)[..., 0]
+            rot_normal = box_downsample(rot_normal, ssaa)
+        return dict(rgba=rgba[None], depth=depth[None], normal=rot_normal[None])
+
+    __call__ = forward
 
     # ---------------------------------------------------------------------------------------------------------------
     def bake_multiview(self, meshes, images, alphas, poses, intrinsics, map_size=1024, cos_weight_pow=8.0, base_weight=0.0,
@@ -156,6 +253,6 @@ class MeshRenderer:
 class Mesh:
     """Minimal stand-in for lib.models.decoders.mesh_renderer.mesh_utils.Mesh: the attributes the render/bake path touches."""
 
-    def __init__(self, v, f, vt=None, ft=None, vn=None, fn=None, albedo=None):
-        self.v, self.f, self.vt, self.ft, self.vn, self.fn, self.albedo = v, f, vt, ft, vn, fn, albedo
+    def __init__(self, v, f, vt=None, ft=None, vn=None, fn=None, albedo=None, vc=None):
+        self.v, self.f, self.vt, self.ft, self.vn, self.fn, self.albedo, self.vc = v, f, vt, ft, vn, fn, albedo, vc
         self.textureless = albedo is None

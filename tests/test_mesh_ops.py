@@ -81,7 +81,7 @@ def test_mesh_renderer_geometry_seam(lib):
     poses, intr = _clip_positions(v, 4, S)
     mr = MeshRenderer(near=0.01, far=100)
     t = lambda a: torch.from_numpy(a).cuda()
-    out = mr(t(v), t(f), t(vn.astype(np.float32)), t(f), t(poses), t(intr), S, S)
+    out = mr.render_geometry(t(v), t(f), t(vn.astype(np.float32)), t(f), t(poses), t(intr), S, S)
     alpha, depth, normal = out['alpha'][..., 0], out['depth'], out['normal']
     # silhouette: a sphere of radius 0.6 seen from 3.7 -> angular radius asin(0.6/3.7); fov 30 deg
     frac = np.pi * (np.tan(np.arcsin(0.6 / 3.7)) / np.tan(np.deg2rad(15))) ** 2 / 4
@@ -139,3 +139,91 @@ def test_bake_multiview_vs_oracle(lib, S, map_size, subdiv, n_views):
     np.testing.assert_allclose(alb_h[seen][:, :3], np.clip(alb_o[seen], 0, 1), rtol=0, atol=3e-4)
     # texels no view sees keep weight 0 before dilation; after it every texel near a chart carries some colour
     assert mesh.textureless is False
+
+
+@pytest.mark.gpu
+def test_edge_opposites_and_antialias_bit_exact(lib):
+    """Topology table and dr.antialias restatement: same arithmetic as oracle/raster_oracle.c, no contraction -> bit-exact."""
+    from mvedit_amd.mesh_ops import MeshRenderer, rasterize, antialias, edge_opposites
+    from oracle import raster as OR
+    from scene import icosphere
+    v, f = icosphere(3, 0.6)
+    v = (v * (1 + 0.3 * np.sin(6 * v[:, :1]) * np.cos(5 * v[:, 1:2]))).astype(np.float32)      # bumps: interior silhouettes
+    f = f[: f.shape[0] - 40]                                                                   # a hole: boundary edges
+    f = np.concatenate([f, f[:1]])                                                             # a duplicated face: non-manifold edges
+    opp_o = OR.edge_opposites(f)
+    t = lambda a: torch.from_numpy(a).cuda()
+    assert (edge_opposites(t(f)).cpu().numpy() == opp_o).all() and (opp_o < 0).sum() > 20
+    S = 96
+    poses, intr = _clip_positions(v, 4, S)
+    mr = MeshRenderer(near=0.01, far=100)
+    v_cam, v_clip, _ = mr.project(t(v), t(poses), t(intr), S, S)
+    rast = rasterize(v_clip, t(f), (S, S))
+    color = np.random.default_rng(3).random((4, S, S, 8)).astype(np.float32)
+    out_o = OR.antialias(color, rast.cpu().numpy(), v_clip.cpu().numpy(), f, opp_o)
+    out_h = antialias(t(color), rast, v_clip, t(f)).cpu().numpy()
+    changed = (out_o != color).any(-1)
+    assert 0.005 < changed.mean() < 0.2, changed.mean()
+    assert (out_h == out_o).all()
+    # blends are convex combinations of two input pixels, applied at most four times
+    assert out_o.min() >= -1e-6 and out_o.max() <= 1 + 1e-6
+    out5 = antialias(t(color[..., :5].copy()), rast, v_clip, t(f)).cpu().numpy()
+    assert (out5 == out_o[..., :5]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ssaa', [1, 2])
+def test_mesh_renderer_forward_vs_oracle(lib, ssaa):
+    """MeshRenderer.forward with a textured mesh (base_mesh_renderer.py:207-395) assembled from oracle pieces."""
+    from mvedit_amd.mesh_ops import MeshRenderer, Mesh
+    from oracle import raster as OR, bake_oracle as BO
+    from scene import icosphere, face_atlas
+    v, f = icosphere(3, 0.6)
+    vn = (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+    vt, ft = face_atlas(f)
+    tex = np.random.default_rng(1).random((64, 64, 4)).astype(np.float32)
+    S, nv = 64, 3
+    poses, intr = _clip_positions(v, nv, S)
+    t = lambda a: torch.from_numpy(a).cuda()
+    mr = MeshRenderer(near=0.01, far=100, ssaa=ssaa)
+    mesh = Mesh(t(v), t(f), t(vt), t(ft), vn=t(vn), fn=t(f), albedo=t(tex))
+    out = mr([mesh], t(poses)[None], t(intr)[None], S, S, dilate_edges=0, aa=True)
+    assert out['rgba'].shape == (1, nv, S, S, 4) and out['depth'].shape == (1, nv, S, S) and out['normal'].shape == (1, nv, S, S, 3)
+    # oracle pipeline on the projected vertices the renderer used
+    Sh = S * ssaa
+    v_cam, v_clip, r_c2w = mr.project(t(v), t(poses), t(intr) * ssaa, Sh, Sh)
+    vc, vcl = v_cam.cpu().numpy(), v_clip.cpu().numpy()
+    rast = OR.rasterize(vcl, f, (Sh, Sh))
+    fg = rast[..., 3] > 0
+    with np.errstate(divide='ignore'):
+        depth = (1 / OR.interpolate(-vc[..., 2:3], rast, f)[..., 0]).astype(np.float32)
+    depth[~fg] = 0
+    nrm = OR.interpolate(vn[None], rast, f)
+    nrm = nrm / np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-12)
+    rot = (np.einsum('bhwk,bkj->bhwj', nrm, r_c2w.cpu().numpy()) / 2 + 0.5).astype(np.float32)
+    rot[~fg] = np.array([0.5, 0.5, 1.0], np.float32)
+    texc = OR.interpolate(vt[None], rast, ft)
+    alb = np.stack([BO.texture_bilinear(tex[..., :3], texc[i]) for i in range(nv)])
+    alb[~fg] = 0
+    packed = np.concatenate([alb, fg[..., None].astype(np.float32), depth[..., None], rot], -1)
+    packed = OR.antialias(packed, rast, vcl, f)
+    if ssaa > 1:
+        packed = packed.reshape(nv, S, ssaa, S, ssaa, 8).mean(axis=(2, 4))
+    np.testing.assert_allclose(out['rgba'][0].cpu().numpy(), packed[..., :4], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out['depth'][0].cpu().numpy(), packed[..., 4], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out['normal'][0].cpu().numpy(), packed[..., 5:], rtol=0, atol=3e-6)
+    a = out['rgba'][0, ..., 3]
+    assert ((a > 0) & (a < 1)).float().mean() > 0.001, 'antialiasing must soften the silhouette'
+    # vertex colours + shading_fun + edge dilation path
+    vcol = np.concatenate([np.random.default_rng(2).random((v.shape[0], 3)), np.ones((v.shape[0], 1))], -1).astype(np.float32)
+    mesh2 = Mesh(t(v), t(f), vn=t(vn), fn=t(f), vc=t(vcol))
+    seen = {}
+
+    def shade(world_pos, albedo, world_normal, fg_mask):
+        seen.update(n=world_pos.shape[0], r=world_pos.norm(dim=-1).mean().item(), nn=world_normal.norm(dim=-1).mean().item())
+        return albedo * 0.5
+    o2 = mr([mesh2], t(poses)[None], t(intr)[None], S, S, shading_fun=shade, dilate_edges=1, aa=False)
+    o3 = mr([mesh2], t(poses)[None], t(intr)[None], S, S, dilate_edges=0, aa=False)
+    assert seen['n'] > 100 and abs(seen['r'] - 0.6) < 0.01 and abs(seen['nn'] - 1) < 1e-3
+    m = o3['rgba'][..., 3] > (0 if ssaa == 1 else 0.999)
+    np.testing.assert_allclose(o2['rgba'][..., :3][m].cpu().numpy(), 0.5 * o3['rgba'][..., :3][m].cpu().numpy(), atol=1e-6)
