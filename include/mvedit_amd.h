@@ -390,6 +390,17 @@ MVE_API int mve_texture_bilinear(const float* d_tex, int Bt, int th, int tw, int
                                  int w, float* d_out, void* stream);
 MVE_API int mve_box_downsample(const float* d_x, int B, int H, int W, int C, int factor, float* d_y, void* stream);
 
+/* Marching tetrahedra, DMTet.__call__ (lib/models/decoders/mesh_renderer/base_mesh_renderer.py:140-188): pos [Nv,3] f32,
+ * sdf [Nv] f32 (occupied where sdf > 0), tets [Nt,4] int32 -> verts [n_verts,3] f32 (one per sign-changing edge, in the
+ * lexicographic order of the reference's torch.unique), faces [n_faces,3] int32 (one-triangle tets first, then two-triangle
+ * tets, each in tet order).  Two calls because the sizes are data dependent: count writes (n_verts, n_faces) to d_counts
+ * (device int32[2]); after reading them the caller allocates the outputs and calls write with the SAME untouched workspace. */
+MVE_API size_t mve_dmtet_workspace_bytes(size_t n_verts, size_t n_tets);
+MVE_API int mve_dmtet_count(const float* d_sdf, const int32_t* d_tets, size_t n_verts, size_t n_tets, int32_t* d_counts,
+                            void* d_workspace, size_t workspace_bytes, void* stream);
+MVE_API int mve_dmtet_write(const float* d_pos, const float* d_sdf, const int32_t* d_tets, size_t n_verts, size_t n_tets,
+                            float* d_out_verts, int32_t* d_out_faces, void* d_workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

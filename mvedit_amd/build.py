@@ -31,6 +31,7 @@ EXTRA_FLAGS = {
     'raymarching.hip': ['-ffp-contract=off'],
     'nerf.hip': ['-ffp-contract=off'],
     'raster.hip': ['-ffp-contract=off'],
+    'dmtet.hip': ['-ffp-contract=off'],
 }
 
 

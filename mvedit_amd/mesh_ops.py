@@ -256,3 +256,34 @@ class Mesh:
     def __init__(self, v, f, vt=None, ft=None, vn=None, fn=None, albedo=None, vc=None):
         self.v, self.f, self.vt, self.ft, self.vn, self.fn, self.albedo, self.vc = v, f, vt, ft, vn, fn, albedo, vc
         self.textureless = albedo is None
+
+
+class DMTet:
+    """Mirror of the reference's DMTet (base_mesh_renderer.py:104-188): `DMTet(device)(pos_nx3, sdf_n, tet_fx4) -> verts, faces`.
+    Inference-only (the reference differentiates verts w.r.t. pos/sdf; the backward is SURVEY section 8(f) rank 1 material)."""
+
+    def __init__(self, device='cuda'):
+        self.device = torch.device(device)
+        self._tets_key, self._tets32 = None, None
+
+    def __call__(self, pos_nx3, sdf_n, tet_fx4):
+        pos = pos_nx3.detach().to(self.device, torch.float32).contiguous()
+        sdf = sdf_n.detach().to(self.device, torch.float32).contiguous()
+        key = (tet_fx4.data_ptr(), tuple(tet_fx4.shape), tet_fx4.dtype)
+        if key != self._tets_key:                                   # the tet grid is constant across iterations: convert once
+            self._tets32 = tet_fx4.to(self.device, torch.int32).contiguous()
+            self._tets_key = key
+        tets = self._tets32
+        nv, nt = pos.shape[0], tets.shape[0]
+        nbytes = _lib.raw('mve_dmtet_workspace_bytes')(nv, nt)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        counts = torch.zeros(2, dtype=torch.int32, device=self.device)
+        sp = _lib.stream_ptr(self.device)
+        with torch.cuda.device(self.device):
+            _lib.call('mve_dmtet_count', _lib.ptr(sdf), _lib.ptr(tets), nv, nt, _lib.ptr(counts), _lib.ptr(ws), nbytes, sp)
+            n_verts, n_faces = (int(x) for x in counts.tolist())     # one host read, as march_rays_train
+            verts = torch.empty(n_verts, 3, dtype=torch.float32, device=self.device)
+            faces = torch.empty(n_faces, 3, dtype=torch.int32, device=self.device)
+            _lib.call('mve_dmtet_write', _lib.ptr(pos), _lib.ptr(sdf), _lib.ptr(tets), nv, nt, _lib.ptr(verts), _lib.ptr(faces),
+                      _lib.ptr(ws), nbytes, sp)
+        return verts, faces.long()

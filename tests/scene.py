@@ -104,3 +104,30 @@ def face_atlas(f, pad=0.08):
         vt[3 * i:3 * i + 3] = (tri + np.array([ox, oy], np.float32)) / cells
     ft = np.arange(3 * F, dtype=np.int32).reshape(F, 3)
     return vt, ft
+
+
+def tet_grid(n):
+    """Regular tetrahedral grid on [-1,1]^3: (n+1)^3 vertices, every cube split into the 6 Kuhn tetrahedra around its main diagonal
+    (stands in for demo/tets/{128,256}_tets.npz, which the reference tree does not ship -- SURVEY.md F12)."""
+    import itertools
+    g = np.linspace(-1, 1, n + 1, dtype=np.float32)
+    pos = np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(-1, 3)
+    vid = lambda i, j, k: (i * (n + 1) + j) * (n + 1) + k
+    ii, jj, kk = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing='ij')
+    ii, jj, kk = ii.ravel(), jj.ravel(), kk.ravel()
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        cur = [ii.copy(), jj.copy(), kk.copy()]
+        verts = [vid(*cur)]
+        for ax in perm:
+            cur[ax] = cur[ax] + 1
+            verts.append(vid(*cur))
+        tets.append(np.stack(verts, -1))
+    tets = np.stack(tets, 1).reshape(-1, 4)                   # cube-major, 6 tets per cube
+    return pos, tets.astype(np.int64)
+
+
+def blob_sdf(pos, seed=0, radius=0.6, noise=0.08):
+    """occupancy sign convention of the reference's DMTet: inside where sdf > 0."""
+    rng = np.random.default_rng(seed)
+    return (radius - np.linalg.norm(pos, axis=-1) + noise * rng.standard_normal(pos.shape[0])).astype(np.float32)
