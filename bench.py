@@ -73,6 +73,19 @@ def cpu_baseline(cfg):
                        f'best of 2: {dt:.2f} s; scaled linearly to {2 * VIEWS} forwards')
 
 
+def pmc_traffic(cls):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this kernel is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    try:
+        rec = json.load(open(path)).get(cls)
+        if not rec or rec.get('fetch_kib_mean') is None or rec.get('write_kib_mean') is None:
+            return None
+        return float((2 * rec['fetch_kib_mean'] + rec['write_kib_mean']) * 1024)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -163,7 +176,7 @@ def main():
         roof = dict(bound='mfma', kernel={'conv3x3': 'k_gemm<MODE=1> implicit-GEMM conv3x3', 'linear': 'k_gemm<MODE=0>',
                                           'attention': 'k_attention'}[dom],
                     achieved=round(achieved, 1), peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(achieved / PEAK_TFLOPS_F16, 4),
-                    traffic=None, launches_per_step=b['launches'], flops_per_step=b['flops'],
+                    traffic=pmc_traffic(dom), launches_per_step=b['launches'], flops_per_step=b['flops'],
                     avg_launch_ms=round(b['ms'] / b['launches'], 4),
                     per_class_ms={k: round(v['ms'], 3) for k, v in breakdown.items()},
                     per_class_tflops={k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) for k, v in breakdown.items() if v['flops'] > 0})
