@@ -174,6 +174,11 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int l
                      const void* d_residual, int ldr, int flags, float out_scale, void* d_workspace,
                      size_t workspace_bytes, int rows_per_image, void* stream);
 
+/* Tuning knob: GEMM / conv launches whose 256 x 320 tiling yields at least `big_min_blocks` blocks use the big-tile kernel
+ * (csrc/gemm_big.hip; bit-identical results, so the choice never affects parity or batch invariance).  0 disables it, a negative
+ * value only queries.  Returns the previous setting.  The default comes from the environment variable MVE_GEMM_BIG. */
+MVE_API int mve_gemm_tune(int big_min_blocks);
+
 /* Split-K: at the deep UNet levels one image contributes only a few output tiles while K = 9*1280..9*2560; K is then cut
  * into slices that run concurrently and are summed in a fixed order by a second launch.  The slice count depends on
  * (rows_per_image, N, K) only -- never on the batch -- so results are bit-identical however views are chunked or

@@ -42,6 +42,9 @@ constexpr int BM = 128;
 // defined in gemm_rs.hip (variant 2: role-split 256-row tiles)
 }  // namespace
 int mve_gemm_rs_launch(int dtype, int mode, const void* params, void* stream);
+// defined in gemm_big.hip (256 x 320 tiles, bit-identical results)
+long long mve_gemm_big_blocks(int M, int N, int splitk);
+int mve_gemm_big_launch(int dtype, int mode, const void* params, void* stream);
 namespace {
 
 template <class Tag, int BN, int MODE, int VARIANT>   // MODE 0: dense A, 1: conv3x3 gather; VARIANT 0: register staged, 1: LDS-DMA
@@ -328,10 +331,29 @@ int launch_v(const GemmParams& p, hipStream_t s) {
     return MVE_OK;
 }
 
+// minimum number of 256 x 320 blocks for which the big-tile kernel is used (0 disables it); MVE_GEMM_BIG overrides
+int g_big_min_blocks = -1;
+int gemm_big_min_blocks() {
+    if (g_big_min_blocks < 0) {
+        const char* e = getenv("MVE_GEMM_BIG");
+        g_big_min_blocks = e ? atoi(e) : 256;     // one block per CU: measured break-even on MI355X (profiles/r01_ab_gemm_big*.log)
+    }
+    return g_big_min_blocks;
+}
+
 template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int v = gemm_variant();
     if (v == 2 && p.splitk <= 1 && p.M >= 256 && p.N >= 64) return mve_gemm_rs_launch(Tag::dtype, MODE, &p, s);
+    if (v == 1 && gemm_big_min_blocks() > 0 && mve_gemm_big_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
+        const int rc = mve_gemm_big_launch(Tag::dtype, MODE, &p, s);
+        if (rc) return rc;
+        if (p.splitk > 1) {
+            k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
+            MVE_LAUNCH_CHECK();
+        }
+        return MVE_OK;
+    }
     return v == 0 ? launch_v<Tag, MODE, 0>(p, s) : launch_v<Tag, MODE, 1>(p, s);
 }
 
@@ -351,6 +373,12 @@ int check_common(const GemmParams& p, const char* who) {
 }  // namespace
 
 extern "C" {
+
+int mve_gemm_tune(int big_min_blocks) {
+    const int old = gemm_big_min_blocks();
+    if (big_min_blocks >= 0) g_big_min_blocks = big_min_blocks;
+    return old;
+}
 
 size_t mve_gemm_workspace_bytes(int M, int N, int K, int rows_per_image) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -1,0 +1,222 @@
+// 256 x 320 x 64 tile variant of the MFMA GEMM / implicit-GEMM conv (see gemm.hip for the algorithm, the LDS layout, the
+// swapped-operand MFMA and the epilogue conventions; this file only changes the decomposition).
+//
+// Why: rocprofv3 PMC passes on the 128 x 160 kernel (profiles/r01_rocprof_v3_summary.txt) show conv launches fetching ~5x
+// their algorithmic bytes (operand re-reads across N- and M-tiles miss L2), and per k-tile the four 64 x 80 wave tiles read
+// 72 KB of fragments from LDS for 640 MFMA cycles per wave -- LDS bandwidth (128 B/clk/CU) is ~90 % of the MFMA time.
+//   block 256 x 320, 512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 x 80 = 8 x 5 fragments, 160 accumulator registers;
+//   LDS fragment traffic per MFMA drops by 1.4x ((128+80)/(128*80) vs (64+80)/(64*80)), global->LDS traffic per FLOP by 2x;
+//   two 72 KB stages = 144 KB of the 160 KB LDS (dynamic shared memory), one block per CU, 2 waves per SIMD.
+// The k order (tile by tile, two 32-wide MFMA steps per tile) and the split-K slicing are identical to gemm.hip, so both
+// kernels produce bit-identical results and the dispatcher may pick either by problem size without breaking batch invariance.
+#include "common.h"
+
+#include "gemm_shared.h"
+
+namespace {
+
+constexpr int BM2 = 256, BN2 = 320, NTH = 512;
+constexpr int WAVES_N = 4;
+constexpr int WTM = 128, WTN = 80;
+constexpr int MF = WTM / 16, NF = WTN / 16;          // 8 x 5 fragments per wave
+constexpr int RPP = NTH / 8;                         // 64 rows per load pass
+constexpr int A_PASSES = BM2 / RPP, B_PASSES = BN2 / RPP;   // 4, 5
+constexpr int A_STAGE = BM2 * ROW_BYTES, B_STAGE = BN2 * ROW_BYTES, STAGE = A_STAGE + B_STAGE;
+constexpr int CS_LD = BN2 + 4;
+constexpr int SMEM_BIG = 2 * STAGE;                  // 147456 B; the fp32 epilogue tile (64 x 324 x 4 B) lives inside it
+static_assert(64 * CS_LD * 4 <= SMEM_BIG, "epilogue staging must fit");
+
+template <class Tag, int MODE>
+__global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
+    typedef typename Tag::V8 V8;
+    typedef typename Tag::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+
+    const int tiles_n = (p.N + BN2 - 1) / BN2;
+    const int tiles_m = (p.M + BM2 - 1) / BM2;
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    const unsigned lin = mve_xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n * S));
+    const int kslice = lin % S;
+    const unsigned tile = lin / S;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    const int lr = tid >> 3;                                   // 0..63
+    const int lc = (tid & 7) ^ ((lr >> 1) & 7);                // source chunk: swizzle applied on the global side
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W);
+
+    const T* a_row[A_PASSES];
+    int cb[A_PASSES], cy[A_PASSES], cx[A_PASSES];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            int m = m0 + lr + j * RPP;
+            m = m < p.M ? m : p.M - 1;
+            a_row[j] = reinterpret_cast<const T*>(p.A) + (size_t)m * p.lda;
+        }
+    } else {
+        const int hw = p.g.Ho * p.g.Wo;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            int m = m0 + lr + j * RPP;
+            m = m < p.M ? m : p.M - 1;
+            const int b = m / hw, r = m - b * hw;
+            const int y = r / p.g.Wo;
+            cb[j] = b;
+            cy[j] = y * p.g.stride - 1;
+            cx[j] = (r - y * p.g.Wo) * p.g.stride - 1;
+        }
+    }
+    const T* w_row[B_PASSES];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+        int n = n0 + lr + j * RPP;
+        n = n < p.N ? n : p.N - 1;
+        w_row[j] = Wp + (size_t)n * p.ldw;
+    }
+
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt_begin = (int)((long long)nk_all * kslice / S), kt_end = (int)((long long)nk_all * (kslice + 1) / S);
+    const int Ctot = p.g.C1 + p.g.C2;
+    int tap = 0, cin = 0;
+    if constexpr (MODE == 1) {
+        if (!p.g.chunk64) {
+            const int k0 = kt_begin * BK + lc * 8;
+            tap = k0 / Ctot;
+            cin = k0 - tap * Ctot;
+        }
+    }
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+    auto dma_tile = [&](int kt, int stage) {
+        const bool kin = kt * BK + lc * 8 < p.K;
+        unsigned char* As = smem + stage * STAGE;
+        unsigned char* Bs = As + A_STAGE;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            const T* s;
+            if constexpr (MODE == 0) s = kin ? a_row[j] + kt * BK + lc * 8 : nullptr;
+            else {
+                int t_ = tap, c_ = cin;
+                if (p.g.chunk64) { t_ = kt % 9; c_ = (kt / 9) * 64 + lc * 8; }
+                s = conv_src<T>(p, cb[j], cy[j], cx[j], t_, c_, kin);
+            }
+            s = s ? s : zero;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * RPP + wid * 8) * ROW_BYTES), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) {
+            const T* s = kin ? w_row[j] + kt * BK + lc * 8 : zero;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(Bs + (j * RPP + wid * 8) * ROW_BYTES), 16, 0, 0);
+        }
+        if constexpr (MODE == 1) {
+            if (!p.g.chunk64) {
+                cin += BK;
+                while (cin >= Ctot) { cin -= Ctot; ++tap; }
+            }
+        }
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    dma_tile(kt_begin, 0);
+    __syncthreads();
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) dma_tile(kt + 1, cur ^ 1);
+        const unsigned char* As = smem + cur * STAGE;
+        const unsigned char* Bs = As + A_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8 xf[MF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const V8*>(As + swz(wm * WTM + i * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const V8 wf = *reinterpret_cast<const V8*>(Bs + swz(wn * WTN + j * 16 + frow, ks * 4 + fchunk));
+#pragma unroll
+                for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf, xf[i], acc[j][i]);
+            }
+        }
+        __syncthreads();   // drains the in-flight LDS-DMA of tile kt+1 (vmcnt(0)) and frees stage `cur`
+    }
+
+    // ---- epilogue: four 64-row passes through an fp32 LDS tile, 16-byte row-segment stores ----------------------------
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CHUNKS = BN2 / 8;
+    constexpr int TASKS = 64 * CHUNKS;
+#pragma unroll
+    for (int pass = 0; pass < BM2 / 64; ++pass) {
+        if (wm == pass / 2) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int i = (pass & 1) * 4 + i4;
+                    const int r = i4 * 16 + (lane & 15);
+                    const int c = wn * WTN + j * 16 + (lane >> 4) * 4;
+                    *reinterpret_cast<f32x4*>(Cs + r * CS_LD + c) = acc[j][i];
+                }
+        }
+        __syncthreads();
+        for (int task = tid; task < TASKS; task += NTH) {
+            const int r = task / CHUNKS, ch = task - r * CHUNKS;
+            const int m = m0 + pass * 64 + r, n = n0 + ch * 8;
+            if (m >= p.M || n >= p.N) continue;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+            if (p.splitk > 1) {
+                float* pp = p.partial + ((size_t)kslice * p.M + m) * p.N + n;
+                *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(pp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                continue;
+            }
+            gemm_epilogue_store<Tag>(p, m, n, v);
+        }
+        __syncthreads();
+    }
+}
+
+template <class Tag, int MODE>
+int launch_big(const GemmParams& p, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big<Tag, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG));
+        configured = true;
+    }
+    const unsigned grid = (unsigned)mve_cdiv(p.M, BM2) * (unsigned)mve_cdiv(p.N, BN2) * (unsigned)(p.splitk > 1 ? p.splitk : 1);
+    k_gemm_big<Tag, MODE><<<grid, NTH, SMEM_BIG, s>>>(p);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+}  // namespace
+
+// number of blocks the 256 x 320 kernel would launch (0: shape not eligible)
+long long mve_gemm_big_blocks(int M, int N, int splitk) {
+    if (N % BN2 != 0 || M < 64) return 0;
+    return (long long)mve_cdiv(M, BM2) * (N / BN2) * (splitk > 1 ? splitk : 1);
+}
+
+// main loop + epilogue (or split-K partials; the caller runs the reducer)
+int mve_gemm_big_launch(int dtype, int mode, const void* params, void* stream) {
+    const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MVE_F16) return mode == 0 ? launch_big<F16Tag, 0>(p, s) : launch_big<F16Tag, 1>(p, s);
+    if (dtype == MVE_BF16) return mode == 0 ? launch_big<BF16Tag, 0>(p, s) : launch_big<BF16Tag, 1>(p, s);
+    mve_set_error("gemm_big: unsupported dtype %d", dtype);
+    return MVE_ERR_ARG;
+}

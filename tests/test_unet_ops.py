@@ -272,3 +272,36 @@ def test_splitk_small_m_big_k(lib, dtype):
     w_il = torch.stack([wv, wg], 1).reshape(1280, K).contiguous()
     out = ops.gemm(a.cuda(), w_il.cuda(), flags=ops.GEGLU, rows_per_image=64)
     check('geglu split-K', out, (a.float() @ wv.float().t()) * F.gelu(a.float() @ wg.float().t()), dtype)
+
+
+@pytest.mark.gpu
+def test_big_tile_kernel_is_bit_identical(lib):
+    """The 256x320 kernel (csrc/gemm_big.hip) walks K in the same order with the same MFMA as the 128x160 kernel, so the
+    dispatcher's size-based choice must never change a single bit (it would break batch / partition invariance)."""
+    from mvedit_amd import ops, _lib
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        dtype = torch.float16
+        for (M, N, K, rpi, fl) in [(4096, 640, 640, 0, 0), (1000, 320, 328, 0, 0), (2048, 2560, 320, 0, ops.GEGLU), (512, 1280, 11520, 64, 0)]:
+            a, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
+            bias = rnd((N,), torch.float32, 3).cuda()
+            res = None if fl else rnd((M, N), dtype, 4).cuda()
+            outs = []
+            for big in (0, 1):
+                tune(1 if big else 0)
+                outs.append(ops.gemm(a, w, bias=bias, residual=res, flags=fl, rows_per_image=rpi))
+            assert torch.equal(outs[0], outs[1]), (M, N, K)
+        for (B, H, C1, C2, Cout, stride, ups) in [(4, 16, 320, 0, 320, 1, False), (3, 16, 640, 320, 640, 1, False), (2, 16, 320, 0, 320, 2, False),
+                                                  (2, 8, 640, 0, 640, 1, True), (5, 9, 72, 0, 320, 1, False)]:
+            x1 = to_nhwc(rnd((B, C1, H, H), dtype, 1)).cuda()
+            x2 = to_nhwc(rnd((B, C2, H, H), dtype, 2)).cuda() if C2 else None
+            wt = rnd((Cout, C1 + C2, 3, 3), dtype, 3, (9 * (C1 + C2)) ** -0.5)
+            w_k, wflag = ops.pack_conv_weight(wt, (C1 % 64 == 0 and C2 % 64 == 0))
+            outs = []
+            for big in (0, 1):
+                tune(1 if big else 0)
+                outs.append(ops.conv3x3(x1, w_k.cuda(), B, H, H, x2=x2, stride=stride, upsample=ups, flags=wflag)[0])
+            assert torch.equal(outs[0], outs[1]), (B, H, C1, C2, Cout, stride, ups)
+    finally:
+        tune(old)
