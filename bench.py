@@ -91,7 +91,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # MVE_BENCH_FORCE_DIST=1 runs the RCCL code path (init, barrier, all-gather, all-reduce) with a single rank, so that it can
+    # be exercised on a 1-GPU box under `torch.distributed.run --nproc-per-node 1`
+    use_dist = world > 1 or os.environ.get('MVE_BENCH_FORCE_DIST') == '1'
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -125,7 +128,7 @@ def main():
     t = torch.full((B,), 499.0, device=dev)
     info = eng.plan(B, LATENT, LATENT, CTX_LEN, 1, False, dtype)
     optab = eng.op_table()
-    gathered = torch.empty(V, 4, LATENT, LATENT, device=dev, dtype=torch.float32) if world > 1 else None
+    gathered = torch.empty(V, 4, LATENT, LATENT, device=dev, dtype=torch.float32) if use_dist else None
 
     def step(profile):
         if profile:
@@ -134,28 +137,33 @@ def main():
             out, ms = eng(sample, t, ctx)[0], None
         un, tx = out[:v_loc].float(), out[v_loc:].float()
         noise = ops.cfg_combine(un, tx, GUIDANCE)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, noise.contiguous())
         return noise, ms
 
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     per_op = [0.0] * info['n_ops']
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, ms = step(not args.no_op_timing)
+    # per-op HIP events cost ~1 ms of host time per step: on every timed step at N = 1 (82 ms steps), on the last timed step
+    # only at N > 1 where a rank's step is ~10 ms and the events would distort the scaling measurement
+    n_prof = 0
+    for i in range(args.steps):
+        prof = (not args.no_op_timing) and (world == 1 or i == args.steps - 1)
+        _, ms = step(prof)
         if ms is not None:
             per_op = [a + b for a, b in zip(per_op, ms)]
+            n_prof += 1
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -167,7 +175,7 @@ def main():
     if not args.no_op_timing:
         for (ph, cls, fl, lab), m in zip(optab, per_op):
             d = breakdown.setdefault(cls, dict(ms=0.0, flops=0.0, launches=0))
-            d['ms'] += m / args.steps
+            d['ms'] += m / max(n_prof, 1)
             d['flops'] += fl
             d['launches'] += 1
         dom = max(('conv3x3', 'linear', 'attention'), key=lambda k: breakdown[k]['ms'])
@@ -199,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

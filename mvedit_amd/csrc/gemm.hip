@@ -173,10 +173,43 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<u32x4*>(Bs + swz(lr + j * ROWS_PER_PASS, lc)) = b_reg[j];
     };
+    // fast conv addressing for the slab-major K order without upsample (see gemm_big.hip): uniform tap / slab arithmetic,
+    // one multiply-add per row, the halo test is a bit of a per-row mask computed once
+    const bool fast = MODE == 1 && VARIANT == 1 && p.g.chunk64 && !p.g.ups;
+    int pix[A_PASSES];
+    unsigned vmask[A_PASSES];
+    if constexpr (MODE == 1 && VARIANT == 1) {
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            pix[j] = (cb[j] * p.g.Hs + cy[j]) * p.g.Ws + cx[j];
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yi = cy[j] + t / 3, xi = cx[j] + t % 3;
+                if (yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv) mk |= 1u << t;
+            }
+            vmask[j] = mk;
+        }
+    }
     auto dma_tile = [&](int kt, int stage) {   // variant 1: global -> LDS directly, 1 KiB per wave instruction
         const bool kin = kt * BK + lc * 8 < p.K;
         unsigned char* As = smem + stage * STAGE;
         unsigned char* Bs = As + A_STAGE;
+        if (MODE == 1 && VARIANT == 1 && fast) {
+            const int t_ = kt % 9, c0 = (kt / 9) * 64;                 // uniform
+            const bool second = c0 >= p.g.C1;
+            const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
+            const int cs = second ? p.g.C2 : p.g.C1;
+            const int ch = (second ? c0 - p.g.C1 : c0) + lc * 8;
+            const int dy = t_ / 3;
+            const int toff = dy * p.g.Ws + (t_ - dy * 3);
+#pragma unroll
+            for (int j = 0; j < A_PASSES; ++j) {
+                const unsigned off = (unsigned)((pix[j] + toff) * cs + ch);
+                const T* s = ((vmask[j] >> t_) & 1u) ? src + off : zero;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES), 16, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
             const T* s = a_src(kt, j, kin);

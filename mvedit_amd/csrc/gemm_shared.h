@@ -44,7 +44,15 @@ struct GemmParams {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact (erf) GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the 16-bit output rounding): one rcp,
+// one exp and five FMAs instead of erff's ~40 instructions -- the GEGLU epilogue evaluates 3.4e8 of these per level-0 launch
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
 
 // address of the 16-byte source chunk of im2col element (row = output pixel (cb,cy,cx), tap, channel `cin`)
 template <class T>
