@@ -187,6 +187,38 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
         __syncthreads();   // drains the in-flight LDS-DMA of tile kt+1 (vmcnt(0)) and frees stage `cur`
     }
 
+    // ---- GEGLU epilogue: out[m][i] = (v[2i] + b[2i]) * gelu(v[2i+1] + b[2i+1]).  A lane owns 4 consecutive n = two
+    // (value, gate) pairs of one row, so the activation is evaluated on the accumulators; only the 16-bit results (half the
+    // columns) pass through LDS, in ONE 256-row pass, for 16-byte row-segment stores.  Same arithmetic as gemm_epilogue_store.
+    if (p.geglu && p.splitk <= 1) {
+        constexpr int HS_LD = BN2 / 2 + 8;              // 168 elements: conflict-free 4-byte writes (row stride 84 words)
+        T* Hs = reinterpret_cast<T*>(smem);
+        typedef T T2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int c = wn * WTN + j * 16 + (lane >> 4) * 4;
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n0 + c < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const f32x4 v = acc[j][i];
+                T2 o;
+                o[0] = Tag::from_f32((v[0] + b4[0]) * gelu_erf(v[1] + b4[1]));
+                o[1] = Tag::from_f32((v[2] + b4[2]) * gelu_erf(v[3] + b4[3]));
+                *reinterpret_cast<T2*>(Hs + (wm * WTM + i * 16 + (lane & 15)) * HS_LD + (c >> 1)) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int HCH = BN2 / 16;                   // 20 chunks of 8 output columns per row
+        for (int task = tid; task < BM2 * HCH; task += NTH) {
+            const int r = task / HCH, ch = task - r * HCH;
+            const int m = m0 + r, n = n0 + ch * 16;     // n: first of the 16 input columns behind this output chunk
+            if (m >= p.M || n >= p.N) continue;
+            *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1)) = *reinterpret_cast<const V8*>(Hs + r * HS_LD + ch * 8);
+        }
+        return;
+    }
+
     // ---- epilogue: four 64-row passes through an fp32 LDS tile, 16-byte row-segment stores ----------------------------
     float* Cs = reinterpret_cast<float*>(smem);
     constexpr int CHUNKS = BN2 / 8;
