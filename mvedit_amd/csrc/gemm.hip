@@ -366,6 +366,7 @@ int launch_v(const GemmParams& p, hipStream_t s) {
 
 // minimum number of 256 x 320 blocks for which the big-tile kernel is used (0 disables it); MVE_GEMM_BIG overrides
 int g_big_min_blocks = -1;
+int g_seq_splitk = 1;         // mve_gemm_tune bit 29 clears it (A/B: real split-K + reducer)
 int gemm_big_min_blocks() {
     if (g_big_min_blocks < 0) {
         const char* e = getenv("MVE_GEMM_BIG");
@@ -378,6 +379,15 @@ template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int v = gemm_variant();
     if (v == 2 && p.splitk <= 1 && p.M >= 256 && p.N >= 64) return mve_gemm_rs_launch(Tag::dtype, MODE, &p, s);
+    // enough 256 x 320 tiles to fill the chip WITHOUT cutting K: one block per tile walks the slices one after the other and
+    // reproduces the split-K rounding exactly (GemmParams::splitk_seq) -- no partial tiles, no reducer launch
+    if (v == 1 && gemm_big_min_blocks() > 0 && p.splitk > 1 && g_seq_splitk && mve_gemm_big_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&
+        (size_t)mve_gemm_big_blocks(p.M, p.N, 1) * 256 * 320 <= (size_t)p.splitk * p.M * p.N) {
+        GemmParams q = p;
+        q.splitk_seq = p.splitk;
+        q.splitk = 1;
+        return mve_gemm_big_launch(Tag::dtype, MODE, &q, s);
+    }
     if (v == 1 && gemm_big_min_blocks() > 0 && mve_gemm_big_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
         const int rc = mve_gemm_big_launch(Tag::dtype, MODE, &p, s);
         if (rc) return rc;
@@ -409,7 +419,7 @@ extern "C" {
 
 int mve_gemm_tune(int big_min_blocks) {
     const int old = gemm_big_min_blocks();
-    if (big_min_blocks >= 0) g_big_min_blocks = big_min_blocks;
+    if (big_min_blocks >= 0) { g_seq_splitk = (big_min_blocks & (1 << 29)) ? 0 : 1; g_big_min_blocks = big_min_blocks & ~(1 << 29); }
     return old;
 }
 

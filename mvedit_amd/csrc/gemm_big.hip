@@ -26,7 +26,7 @@ constexpr int CS_LD = BN2 + 4;
 constexpr int SMEM_BIG = 2 * STAGE;                  // 147456 B; the fp32 epilogue tile (64 x 324 x 4 B) lives inside it
 static_assert(64 * CS_LD * 4 <= SMEM_BIG, "epilogue staging must fit");
 
-template <class Tag, int MODE>
+template <class Tag, int MODE, bool SEQ>
 __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
@@ -166,25 +166,47 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
     dma_tile(kt_begin, 0);
     __syncthreads();
 
+    // sequential split-K emulation (see GemmParams::splitk_seq): the K loop runs slice by slice; between slices the accumulators
+    // are folded into lane-private 16-byte slots of a block-private fp32 running total (1 KiB per wave access)
+    const int SQ = SEQ ? p.splitk_seq : 1;
     const int frow = lane & 15, fchunk = lane >> 4;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) dma_tile(kt + 1, cur ^ 1);
-        const unsigned char* As = smem + cur * STAGE;
-        const unsigned char* Bs = As + A_STAGE;
+    int kt = kt_begin;
+    for (int sl = 0; sl < SQ; ++sl) {
+        const int kend = SEQ ? (int)((long long)nk_all * (sl + 1) / SQ) : kt_end;
+        for (; kt < kend; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
+            if (kt + 1 < kt_end) dma_tile(kt + 1, cur ^ 1);
+            const unsigned char* As = smem + cur * STAGE;
+            const unsigned char* Bs = As + A_STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            V8 xf[MF];
+            for (int ks = 0; ks < 2; ++ks) {
+                V8 xf[MF];
 #pragma unroll
-            for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const V8*>(As + swz(wm * WTM + i * 16 + frow, ks * 4 + fchunk));
+                for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const V8*>(As + swz(wm * WTM + i * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const V8 wf = *reinterpret_cast<const V8*>(Bs + swz(wn * WTN + j * 16 + frow, ks * 4 + fchunk));
+                for (int j = 0; j < NF; ++j) {
+                    const V8 wf = *reinterpret_cast<const V8*>(Bs + swz(wn * WTN + j * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
-                for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf, xf[i], acc[j][i]);
+                    for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf, xf[i], acc[j][i]);
+                }
             }
+            __syncthreads();   // drains the in-flight LDS-DMA of tile kt+1 (vmcnt(0)) and frees stage `cur`
         }
-        __syncthreads();   // drains the in-flight LDS-DMA of tile kt+1 (vmcnt(0)) and frees stage `cur`
+        if constexpr (SEQ) {
+            f32x4* tot = reinterpret_cast<f32x4*>(p.partial) + ((size_t)tile * (BM2 * BN2 / 4) + (size_t)wid * (NF * MF * 64) + lane);
+            const bool last = sl + 1 == SQ;
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    f32x4* slot = tot + (j * MF + i) * 64;
+                    f32x4 t = acc[j][i];
+                    if (sl > 0) { const f32x4 o = *slot; t = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]}; }
+                    if (last) acc[j][i] = t;                       // result = running total + last slice
+                    else { *slot = t; acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
     }
 
     // ---- GEGLU epilogue: out[m][i] = (v[2i] + b[2i]) * gelu(v[2i+1] + b[2i+1]).  A lane owns 4 consecutive n = two
@@ -259,17 +281,21 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
     }
 }
 
-template <class Tag, int MODE>
-int launch_big(const GemmParams& p, hipStream_t s) {
+template <class Tag, int MODE, bool SEQ>
+int launch_big2(const GemmParams& p, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
-        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big<Tag, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG));
+        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big<Tag, MODE, SEQ>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG));
         configured = true;
     }
     const unsigned grid = (unsigned)mve_cdiv(p.M, BM2) * (unsigned)mve_cdiv(p.N, BN2) * (unsigned)(p.splitk > 1 ? p.splitk : 1);
-    k_gemm_big<Tag, MODE><<<grid, NTH, SMEM_BIG, s>>>(p);
+    k_gemm_big<Tag, MODE, SEQ><<<grid, NTH, SMEM_BIG, s>>>(p);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
+}
+template <class Tag, int MODE>
+int launch_big(const GemmParams& p, hipStream_t s) {
+    return p.splitk_seq > 1 ? launch_big2<Tag, MODE, true>(p, s) : launch_big2<Tag, MODE, false>(p, s);
 }
 
 }  // namespace

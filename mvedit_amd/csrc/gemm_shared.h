@@ -39,6 +39,9 @@ struct GemmParams {
     float out_scale;   // multiplies the final value (1/output_scale_factor)
     int splitk;        // > 1: K is cut into `splitk` slices, each block writes an fp32 partial tile to `partial`
     float* partial;    // [splitk][M][N] fp32 workspace (split-K only)
+    int splitk_seq;    // > 1 (big-tile kernel only): ONE block walks all of K but rounds like `splitk_seq` concurrent slices --
+                       // at every slice boundary the accumulators are folded into a block-private fp32 running total kept in
+                       // `partial`, so the result is bit-identical to split-K + reducer without the reducer's traffic / launch
     ConvGeom g;
 };
 
