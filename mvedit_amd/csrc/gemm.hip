@@ -389,7 +389,8 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         return mve_gemm_big_launch(Tag::dtype, MODE, &q, s);
     }
     if (v == 1 && gemm_big_min_blocks() > 0 && mve_gemm_big_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
-        const int rc = mve_gemm_big_launch(Tag::dtype, MODE, &p, s);
+        GemmParams q = p;
+        const int rc = mve_gemm_big_launch(Tag::dtype, MODE, &q, s);
         if (rc) return rc;
         if (p.splitk > 1) {
             k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
@@ -419,7 +420,10 @@ extern "C" {
 
 int mve_gemm_tune(int big_min_blocks) {
     const int old = gemm_big_min_blocks();
-    if (big_min_blocks >= 0) { g_seq_splitk = (big_min_blocks & (1 << 29)) ? 0 : 1; g_big_min_blocks = big_min_blocks & ~(1 << 29); }
+    if (big_min_blocks >= 0) {
+        g_seq_splitk = (big_min_blocks & (1 << 29)) ? 0 : 1;
+        g_big_min_blocks = big_min_blocks & ~(3 << 28);
+    }
     return old;
 }
 

@@ -26,7 +26,7 @@ constexpr int CS_LD = BN2 + 4;
 constexpr int SMEM_BIG = 2 * STAGE;                  // 147456 B; the fp32 epilogue tile (64 x 324 x 4 B) lives inside it
 static_assert(64 * CS_LD * 4 <= SMEM_BIG, "epilogue staging must fit");
 
-template <class Tag, int MODE, bool SEQ>
+template <class Tag, int MODE, bool SEQ, bool FAST>      // FAST (conv only): slab-major K order without upsample
 __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
@@ -50,6 +50,8 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
 
     const T* a_row[A_PASSES];
     int cb[A_PASSES], cy[A_PASSES], cx[A_PASSES];
+    int pix[A_PASSES];
+    unsigned vmask[A_PASSES];
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
@@ -68,6 +70,16 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
             cb[j] = b;
             cy[j] = y * p.g.stride - 1;
             cx[j] = (r - y * p.g.Wo) * p.g.stride - 1;
+            if constexpr (FAST) {     // per-row pixel base and 9-bit halo mask; cb/cy/cx are dead after this in the fast kernel
+                pix[j] = (cb[j] * p.g.Hs + cy[j]) * p.g.Ws + cx[j];
+                unsigned mk = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yi = cy[j] + t / 3, xi = cx[j] + t % 3;
+                    if (yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv) mk |= 1u << t;
+                }
+                vmask[j] = mk;
+            }
         }
     }
     const T* w_row[B_PASSES];
@@ -96,28 +108,11 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
     // a per-row 9-bit mask computed once.  The generic path below costs ~45 VALU instructions and two divergent branches per
     // row and K tile (64-bit multiplies, bounds tests); with two waves per SIMD running the loop in lock-step that address
     // phase left the MFMA pipe idle for a third of every K tile (rocprofv3 SQ_WAIT_* / ISA inspection, round 1).
-    const bool fast = MODE == 1 && p.g.chunk64 && !p.g.ups;
-    int pix[A_PASSES];
-    unsigned vmask[A_PASSES];
-    if constexpr (MODE == 1) {
-#pragma unroll
-        for (int j = 0; j < A_PASSES; ++j) {
-            pix[j] = (cb[j] * p.g.Hs + cy[j]) * p.g.Ws + cx[j];
-            unsigned mk = 0;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yi = cy[j] + t / 3, xi = cx[j] + t % 3;
-                if (yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv) mk |= 1u << t;
-            }
-            vmask[j] = mk;
-        }
-    }
-
     auto dma_tile = [&](int kt, int stage) {
         const bool kin = kt * BK + lc * 8 < p.K;
         unsigned char* As = smem + stage * STAGE;
         unsigned char* Bs = As + A_STAGE;
-        if (MODE == 1 && fast) {
+        if constexpr (MODE == 1 && FAST) {
             const int t_ = kt % 9, c0 = (kt / 9) * 64;                 // uniform
             const bool second = c0 >= p.g.C1;
             const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
@@ -131,7 +126,7 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
                 const T* s = ((vmask[j] >> t_) & 1u) ? src + off : zero;
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * RPP + wid * 8) * ROW_BYTES), 16, 0, 0);
             }
-        } else
+        } else {
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
             const T* s;
@@ -144,12 +139,13 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
             s = s ? s : zero;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * RPP + wid * 8) * ROW_BYTES), 16, 0, 0);
         }
+        }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
             const T* s = kin ? w_row[j] + kt * BK + lc * 8 : zero;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(Bs + (j * RPP + wid * 8) * ROW_BYTES), 16, 0, 0);
         }
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 1 && !FAST) {
             if (!p.g.chunk64) {
                 cin += BK;
                 while (cin >= Ctot) { cin -= Ctot; ++tap; }
@@ -175,11 +171,9 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
         const int kend = SEQ ? (int)((long long)nk_all * (sl + 1) / SQ) : kt_end;
         for (; kt < kend; ++kt) {
             const int cur = (kt - kt_begin) & 1;
-            if (kt + 1 < kt_end) dma_tile(kt + 1, cur ^ 1);
             const unsigned char* As = smem + cur * STAGE;
             const unsigned char* Bs = As + A_STAGE;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            auto mfma_step = [&](int ks) {
                 V8 xf[MF];
 #pragma unroll
                 for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const V8*>(As + swz(wm * WTM + i * 16 + frow, ks * 4 + fchunk));
@@ -189,7 +183,12 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
 #pragma unroll
                     for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf, xf[i], acc[j][i]);
                 }
-            }
+            };
+            // (Tried: staggering the DMA issue of the two waves that share a SIMD -- "ping-pong" -- measured 1 % slower end to end
+            // on the same box, profiles/r01_ab_tuning.log, so both wave groups issue at the top of the iteration.)
+            if (kt + 1 < kt_end) dma_tile(kt + 1, cur ^ 1);
+            mfma_step(0);
+            mfma_step(1);
             __syncthreads();   // drains the in-flight LDS-DMA of tile kt+1 (vmcnt(0)) and frees stage `cur`
         }
         if constexpr (SEQ) {
@@ -281,17 +280,24 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
     }
 }
 
-template <class Tag, int MODE, bool SEQ>
-int launch_big2(const GemmParams& p, hipStream_t s) {
+template <class Tag, int MODE, bool SEQ, bool FAST>
+int launch_big3(const GemmParams& p, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
-        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big<Tag, MODE, SEQ>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG));
+        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big<Tag, MODE, SEQ, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG));
         configured = true;
     }
     const unsigned grid = (unsigned)mve_cdiv(p.M, BM2) * (unsigned)mve_cdiv(p.N, BN2) * (unsigned)(p.splitk > 1 ? p.splitk : 1);
-    k_gemm_big<Tag, MODE, SEQ><<<grid, NTH, SMEM_BIG, s>>>(p);
+    k_gemm_big<Tag, MODE, SEQ, FAST><<<grid, NTH, SMEM_BIG, s>>>(p);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
+}
+template <class Tag, int MODE, bool SEQ>
+int launch_big2(const GemmParams& p, hipStream_t s) {
+    if constexpr (MODE == 1) {
+        if (p.g.chunk64 && !p.g.ups) return launch_big3<Tag, MODE, SEQ, true>(p, s);
+    }
+    return launch_big3<Tag, MODE, SEQ, false>(p, s);
 }
 template <class Tag, int MODE>
 int launch_big(const GemmParams& p, hipStream_t s) {
