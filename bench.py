@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--views', type=int, default=VIEWS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the NeRF / raster / back-projection figures')
     ap.add_argument('--no-op-timing', action='store_true', help='time the steps without per-op HIP events')
     return ap.parse_args()
 
@@ -84,6 +85,92 @@ def pmc_traffic(cls):
         return float((2 * rec['fetch_kib_mean'] + rec['write_kib_mean']) * 1024)
     except (OSError, ValueError):
         return None
+
+
+def surround_poses(n, radius=3.7, elev=0.2):
+    """n look-at c2w matrices (OpenCV convention: x right, y down, z forward) on a circle, as the reference's camera rig
+    (lib/apis/adapter3d.py:991-996: distance 3.7, fov 30 degrees)."""
+    import math
+    poses = torch.zeros(n, 3, 4)
+    for i in range(n):
+        az = 2 * math.pi * i / n
+        c = torch.tensor([radius * math.cos(elev) * math.cos(az), radius * math.cos(elev) * math.sin(az), radius * math.sin(elev)])
+        fwd = -c / c.norm()
+        right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0]))
+        right = right / right.norm()
+        down = torch.linalg.cross(fwd, right)
+        poses[i, :, 0], poses[i, :, 1], poses[i, :, 2], poses[i, :, 3] = right, down, fwd, c
+    return poses
+
+
+def secondary(dev):
+    """SURVEY section 8(d) secondary figures on rank 0: NeRF render views/s, raster views/s, back-projection texel-views/s, each
+    with its algorithmic HBM rate.  Synthetic scene: 128^3 occupancy sphere + 12-level hash grid; 81,920-face icosphere."""
+    import math
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests'))
+    from scene import face_atlas, icosphere, sphere_density_grid
+    from mvedit_amd import nerf, raymarching as rm
+    from mvedit_amd.mesh_ops import Mesh, MeshRenderer, rasterize
+
+    def timed(fn, it=3):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(it):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / it * 1e-3
+
+    out = {}
+    S, nv = 512, 6
+    f = S / (2 * math.tan(math.radians(15)))
+    intr = torch.tensor([[f, f, S / 2, S / 2]] * nv, device=dev)
+    poses = surround_poses(nv).to(dev)
+    # ---- NeRF: fused march + hash grid + MLP + composite (BaseNeRF.render, one launch) ----------------------------------
+    meta, rows = nerf.grid_meta(12, 16, 320)
+    g = torch.Generator().manual_seed(7)
+    table = (torch.rand(rows, 2, generator=g) * 2 - 1) * 1e-4                       # ingp_decoder.py:88 init
+    w1 = (torch.rand(64, 24, generator=g) * 2 - 1) * math.sqrt(6 / (64 + 24))
+    w2 = (torch.rand(4, 64, generator=g) * 2 - 1) * math.sqrt(6 / (4 + 64))
+    dec = nerf.INGPDecoderParams(table, w1, torch.zeros(64), w2, torch.tensor([2.0, 0.0, 0.0, 0.0]), 12, 320, device=dev)
+    bits = rm.packbits(torch.from_numpy(sphere_density_grid(128, radius=0.5)).to(dev), 0.5)
+    ro, rd, _ = nerf.camera_rays(intr, poses, S, S)
+    _, _, _, cnt = dec.render_rays(ro, rd, bits, 128, 0.0, return_counts=True)
+    samples = int(cnt.sum().item())
+    nr = nerf.NeRFRenderer(grid_size=128)
+    cfg = dict(return_rgba=True, compute_normal=True, dt_gamma_scale=0.0)
+    t = timed(lambda: nr.render(dec, None, bits[None], S, S, intr[None], poses[None], cfg=cfg))
+    nbytes = ro.shape[0] * 52 + samples * (56 + 768)
+    out['nerf_render'] = dict(views_per_s=round(nv / t, 1), ms=round(t * 1e3, 2), rays=ro.shape[0], samples=samples,
+                              algorithmic_GBps=round(nbytes / t / 1e9, 1), frac_of_hbm_peak=round(nbytes / t / 8e12, 4))
+    # ---- mesh: rasterise + full MeshRenderer.forward -------------------------------------------------------------------------
+    v, fc = icosphere(6, 0.6)
+    vt, ft = face_atlas(fc)
+    tv = lambda a: torch.from_numpy(a).to(dev)
+    vn = tv((v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32))
+    mr = MeshRenderer(near=0.01, far=100)
+    _, v_clip, _ = mr.project(tv(v), poses, intr, S, S)
+    faces = tv(fc)
+    t = timed(lambda: rasterize(v_clip, faces, (S, S)))
+    rb = nv * S * S * 16 + v.shape[0] * 36 * nv + fc.shape[0] * 12 * nv
+    out['rasterize'] = dict(views_per_s=round(nv / t, 1), ms=round(t * 1e3, 3), faces=int(fc.shape[0]), algorithmic_GBps=round(rb / t / 1e9, 1))
+    mesh = Mesh(tv(v), faces, tv(vt), tv(ft), vn=vn, fn=faces, albedo=torch.rand(1024, 1024, 4, device=dev))
+    t = timed(lambda: mr([mesh], poses[None], intr[None], S, S))
+    out['mesh_forward'] = dict(views_per_s=round(nv / t, 1), ms=round(t * 1e3, 3))
+    # ---- back-projection: 32 views 512^2 -> 1024^2 atlas ------------------------------------------------------------------------
+    V = 32
+    poses32 = surround_poses(V).to(dev)
+    intr32 = intr[:1].expand(V, -1).contiguous()
+    images = torch.rand(1, V, S, S, 3, device=dev)
+    alphas = torch.ones(1, V, S, S, 1, device=dev)
+    t = timed(lambda: mr.bake_multiview([mesh], images, alphas, poses32[None], intr32[None], map_size=1024, render_bs=8), it=2)
+    tb = V * 1024 * 1024 * 36
+    out['bake_multiview'] = dict(texel_views_per_s=round(V * 1024 * 1024 / t / 1e9, 3), unit='G texel-views/s', ms=round(t * 1e3, 2),
+                                 algorithmic_GBps=round(tb / t / 1e9, 1), frac_of_hbm_peak=round(tb / t / 8e12, 4))
+    return out
 
 
 def main():
@@ -206,6 +293,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
+        if world == 1 and not args.no_secondary:
+            line['secondary'] = secondary(dev)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -66,6 +66,7 @@ __device__ __forceinline__ void hash_encode(const DecoderParams& p, float x, flo
         const bool s2 = s1 && (uint64_t)res * res <= size;            // stride after y
         const uint64_t stride3 = (uint64_t)res * res * (s2 ? res : 1u);
         const bool hashed = s2 ? (size < stride3) : true;
+        const bool pow2 = (size & (size - 1u)) == 0u;
         const float2p* tab = reinterpret_cast<const float2p*>(p.table) + p.g.off[l];
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
@@ -77,16 +78,26 @@ __device__ __forceinline__ void hash_encode(const DecoderParams& p, float x, flo
                 if (corner & (1 << d)) { wt = wt * w[d]; c[d] = cell[d] + 1u; }
                 else { wt = wt * (1.0f - w[d]); c[d] = cell[d]; }
             }
+            // idx mod size without the 32-bit division (it was ~1/3 of the kernel's VALU work): hashed tables have 2^k rows;
+            // a dense index of an in-range point is below 2*size, anything else (points outside the box) takes the slow path
             uint32_t idx;
-            if (hashed) idx = (c[0] * 1u) ^ (c[1] * 2654435761u) ^ (c[2] * 805459861u);
-            else idx = c[0] + c[1] * res + c[2] * res * res;
-            idx %= size;
+            if (hashed) {
+                idx = (c[0] * 1u) ^ (c[1] * 2654435761u) ^ (c[2] * 805459861u);
+                idx = pow2 ? (idx & (size - 1u)) : (idx % size);
+            } else {
+                idx = c[0] + c[1] * res + c[2] * res * res;
+                if (idx >= size) idx -= size;
+                if (idx >= size) idx %= size;
+            }
             const float2p f = tab[idx];
             a0 = fmaf(wt, f.x, a0);
             a1 = fmaf(wt, f.y, a1);
         }
         enc[2 * l] = a0;
         enc[2 * l + 1] = a1;
+        // one level at a time: without this the scheduler hoists all 8*NL gathers to the top, needs > 256 VGPRs and the kernel
+        // runs at one wave per SIMD -- latency-bound on its own dependent index arithmetic
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -111,6 +122,158 @@ __device__ __forceinline__ void decode_point(const DecoderParams& p, float x, fl
     sigma = expf(o[0] + blob);
 #pragma unroll
     for (int k = 0; k < 3; ++k) rgb[k] = (1.0f / (1.0f + expf(-o[1 + k]))) * p.sat_scale - p.sat_shift;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Occupancy-friendly decoder (hidden == 64).  The straight-line version above unrolls all levels: ~20 k instructions, > 256 VGPRs,
+// ONE wave per SIMD -- and the kernel is bound by the latency of its own dependent index arithmetic.  Here the level loop is
+// rolled and the first MLP layer is accumulated level by level (h_j += w1[j][2l] e0; h_j += w1[j][2l+1] e1 -- the same FMA
+// sequence per hidden unit, so the result is bit-identical); w1 is staged once per block in LDS as [level][hidden][2] and read
+// with broadcast ds_read_b128.  64 accumulators + one level's gathers fit in 128 VGPRs: four waves per SIMD.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int HID = 64;
+
+template <int NL>
+__device__ __forceinline__ void stage_w1(const DecoderParams& p, float* __restrict__ w1t) {
+    for (int i = threadIdx.x; i < HID * 2 * NL; i += NB) {
+        const int j = i / (2 * NL), c = i - j * (2 * NL);        // w1[j][c], c = 2*l + f
+        w1t[((c >> 1) * HID + j) * 2 + (c & 1)] = p.w1[i];
+    }
+}
+
+template <int NL>
+__device__ __forceinline__ void decode_point2(const DecoderParams& p, const float* __restrict__ w1t, float x, float y, float z, float& sigma,
+                                              float (&rgb)[3]) {
+    float h[HID];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) h[j] = p.b1[j];
+    const float inv = 1.0f / (2.0f * p.bound);
+    const float u[3] = {(x + p.bound) * inv, (y + p.bound) * inv, (z + p.bound) * inv};
+#pragma unroll 1
+    for (int l = 0; l < NL; ++l) {
+        const float scale = p.g.scale[l];
+        const uint32_t res = p.g.res[l], size = p.g.size[l];
+        uint32_t cell[3];
+        float w[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float pos = fmaf(scale, u[d], 0.5f);
+            const float fl = floorf(pos);
+            cell[d] = (uint32_t)(int)fl;
+            const float fr = pos - fl;
+            w[d] = fr * fr * (3.0f - 2.0f * fr);
+        }
+        const bool s1 = res <= size;
+        const bool s2 = s1 && (uint64_t)res * res <= size;
+        const uint64_t stride3 = (uint64_t)res * res * (s2 ? res : 1u);
+        const bool hashed = s2 ? (size < stride3) : true;
+        const bool pow2 = (size & (size - 1u)) == 0u;
+        const float2p* tab = reinterpret_cast<const float2p*>(p.table) + p.g.off[l];
+        float a0 = 0.f, a1 = 0.f;
+        auto corners = [&](auto index_of) {
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                float wt = 1.0f;
+                uint32_t c[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    if (corner & (1 << d)) { wt = wt * w[d]; c[d] = cell[d] + 1u; }
+                    else { wt = wt * (1.0f - w[d]); c[d] = cell[d]; }
+                }
+                const float2p f = tab[index_of(c)];
+                a0 = fmaf(wt, f.x, a0);
+                a1 = fmaf(wt, f.y, a1);
+            }
+        };
+        if (hashed && pow2) {            // wave-uniform: 2^k-row hash table
+            const uint32_t mask = size - 1u;
+            corners([&](const uint32_t (&c)[3]) { return ((c[0] * 1u) ^ (c[1] * 2654435761u) ^ (c[2] * 805459861u)) & mask; });
+        } else if (!hashed) {            // dense level: an in-range point indexes below 2 * size
+            corners([&](const uint32_t (&c)[3]) {
+                uint32_t idx = c[0] + c[1] * res + c[2] * res * res;
+                if (idx >= size) idx -= size;
+                if (idx >= size) idx %= size;
+                return idx;
+            });
+        } else {
+            corners([&](const uint32_t (&c)[3]) { return ((c[0] * 1u) ^ (c[1] * 2654435761u) ^ (c[2] * 805459861u)) % size; });
+        }
+        const f32x4* wl = reinterpret_cast<const f32x4*>(w1t + l * (HID * 2));
+#pragma unroll
+        for (int j2 = 0; j2 < HID / 2; ++j2) {
+            const f32x4 wv = wl[j2];                               // (w[2j][e0], w[2j][e1], w[2j+1][e0], w[2j+1][e1]), broadcast
+            h[2 * j2] = fmaf(wv[0], a0, h[2 * j2]);
+            h[2 * j2] = fmaf(wv[1], a1, h[2 * j2]);
+            h[2 * j2 + 1] = fmaf(wv[2], a0, h[2 * j2 + 1]);
+            h[2 * j2 + 1] = fmaf(wv[3], a1, h[2 * j2 + 1]);
+        }
+    }
+    float o[4] = {p.b2[0], p.b2[1], p.b2[2], p.b2[3]};
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+        const float a = fmaxf(h[j], 0.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = fmaf(p.w2[k * HID + j], a, o[k]);
+    }
+    const float d2 = fmaxf(x * x + y * y + z * z, 0.2f);
+    const float blob = p.blob_density * expf(-d2 * p.blob_inv_2r2);
+    sigma = expf(o[0] + blob);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = (1.0f / (1.0f + expf(-o[1 + k]))) * p.sat_scale - p.sat_shift;
+}
+
+template <int NL>
+__global__ __launch_bounds__(NB, 4) void k_point_decode2(DecoderParams p, const float* __restrict__ xyz, uint32_t M,
+                                                         float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    __shared__ __attribute__((aligned(16))) float w1t[HID * 2 * NL];
+    stage_w1<NL>(p, w1t);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * NB + threadIdx.x;
+    if (i >= M) return;
+    const float3p q = reinterpret_cast<const float3p*>(xyz)[i];
+    float s, c[3];
+    decode_point2<NL>(p, w1t, q.x, q.y, q.z, s, c);
+    sigmas[i] = s;
+    if (rgbs) reinterpret_cast<float3p*>(rgbs)[i] = float3p{c[0], c[1], c[2]};
+}
+
+template <int NL>
+__global__ __launch_bounds__(NB, 4) void k_render_rays2(DecoderParams dp, MarchParams mp, const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d, const float* __restrict__ aabb,
+                                                        uint32_t N, float min_near, float T_thresh,
+                                                        float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                        float* __restrict__ image, int32_t* __restrict__ n_samples) {
+    __shared__ __attribute__((aligned(16))) float w1t[HID * 2 * NL];
+    stage_w1<NL>(dp, w1t);
+    __syncthreads();
+    const uint32_t n = blockIdx.x * NB + threadIdx.x;
+    if (n >= N) return;
+    const float3p o = reinterpret_cast<const float3p*>(rays_o)[n];
+    const float3p d = reinterpret_cast<const float3p*>(rays_d)[n];
+    float near, far;
+    near_far_one(o, d, aabb, min_near, near, far);
+    GridWalker w;
+    w.init(mp, rays_o + 3ull * n, rays_d + 3ull * n);
+    float ws = 0.f, dep = 0.f, r = 0.f, g = 0.f, b = 0.f;
+    float t = near;
+    t += w.step_len(t) * 0.0f;
+    const uint32_t cnt = w.walk(t, far, mp.max_steps, [&](float cx, float cy, float cz, float tn, float dt) {
+        float sigma, c[3];
+        decode_point2<NL>(dp, w1t, cx, cy, cz, sigma, c);
+        const float alpha = 1.0f - __expf(-sigma * dt);
+        const float T = 1 - ws;
+        const float wgt = alpha * T;
+        ws += wgt;
+        dep += wgt / tn;
+        r += wgt * c[0];
+        g += wgt * c[1];
+        b += wgt * c[2];
+        return !(T < T_thresh);
+    });
+    weights_sum[n] = ws;
+    depth[n] = dep;
+    reinterpret_cast<float3p*>(image)[n] = float3p{r, g, b};
+    if (n_samples) n_samples[n] = (int32_t)cnt;
 }
 
 template <int NL>
@@ -301,7 +464,11 @@ int mve_hashgrid_mlp_decode(const float* d_xyz, uint32_t M, const float* d_table
     if (rc) return rc;
     const unsigned grid = mve_cdiv(M, NB);
     hipStream_t s = (hipStream_t)stream;
-    if (n_levels == 12) k_point_decode<12><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
+    if (hidden == HID) {
+        if (n_levels == 12) k_point_decode2<12><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
+        else if (n_levels == 14) k_point_decode2<14><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
+        else k_point_decode2<16><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
+    } else if (n_levels == 12) k_point_decode<12><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
     else if (n_levels == 14) k_point_decode<14><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
     else k_point_decode<16><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
     MVE_LAUNCH_CHECK();
@@ -328,10 +495,16 @@ int mve_nerf_render_rays(const float* d_rays_o, const float* d_rays_d, uint32_t 
     const unsigned grid = mve_cdiv(N, NB);
     hipStream_t s = (hipStream_t)stream;
 #define GO(NL) k_render_rays<NL><<<grid, NB, 0, s>>>(p, mp, d_rays_o, d_rays_d, d_aabb, N, min_near, T_thresh, d_weights_sum, d_depth, d_image, d_n_samples)
-    if (n_levels == 12) GO(12);
+#define GO2(NL) k_render_rays2<NL><<<grid, NB, 0, s>>>(p, mp, d_rays_o, d_rays_d, d_aabb, N, min_near, T_thresh, d_weights_sum, d_depth, d_image, d_n_samples)
+    if (hidden == HID) {
+        if (n_levels == 12) GO2(12);
+        else if (n_levels == 14) GO2(14);
+        else GO2(16);
+    } else if (n_levels == 12) GO(12);
     else if (n_levels == 14) GO(14);
     else GO(16);
 #undef GO
+#undef GO2
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }
