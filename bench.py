@@ -170,6 +170,18 @@ def secondary(dev):
     tb = V * 1024 * 1024 * 36
     out['bake_multiview'] = dict(texel_views_per_s=round(V * 1024 * 1024 / t / 1e9, 3), unit='G texel-views/s', ms=round(t * 1e3, 2),
                                  algorithmic_GBps=round(tb / t / 1e9, 1), frac_of_hbm_peak=round(tb / t / 8e12, 4))
+    # ---- DMTet on the 128^3 tet grid of the reference's mesh stage (6 tets per cube, 12.6 M tets) ----------------------------------
+    from scene import tet_grid
+    from mvedit_amd.mesh_ops import DMTet
+    pos, tets = tet_grid(128)
+    tp, tt = tv(pos), torch.from_numpy(tets).to(dev)
+    sdf = (0.6 - tp.norm(dim=-1) + 0.02 * torch.sin(9 * tp[:, 0]) * torch.cos(7 * tp[:, 1])).contiguous()
+    dm = DMTet(dev)
+    vv, ff = dm(tp, sdf, tt)
+    t = timed(lambda: dm(tp, sdf, tt))
+    db = tets.shape[0] * (16 + 8 + 8) + pos.shape[0] * 24
+    out['dmtet'] = dict(ms=round(t * 1e3, 3), tets=int(tets.shape[0]), verts_out=int(vv.shape[0]), faces_out=int(ff.shape[0]),
+                        mtets_per_s=round(tets.shape[0] / t / 1e6, 1), algorithmic_GBps=round(db / t / 1e9, 1))
     return out
 
 
