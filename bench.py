@@ -280,7 +280,7 @@ def main():
         dom = max(('conv3x3', 'linear', 'attention'), key=lambda k: breakdown[k]['ms'])
         b = breakdown[dom]
         achieved = b['flops'] / (b['ms'] * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel={'conv3x3': 'k_gemm<MODE=1> implicit-GEMM conv3x3', 'linear': 'k_gemm<MODE=0>',
+        roof = dict(bound='mfma', kernel={'conv3x3': 'k_gemm_big<MODE=1> implicit-GEMM conv3x3 (256x320 tile)', 'linear': 'k_gemm_big<MODE=0> (256x320 tile)',
                                           'attention': 'k_attention'}[dom],
                     achieved=round(achieved, 1), peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(achieved / PEAK_TFLOPS_F16, 4),
                     traffic=pmc_traffic(dom), launches_per_step=b['launches'], flops_per_step=b['flops'],
