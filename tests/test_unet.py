@@ -310,3 +310,32 @@ def test_engine_reference_attention(lib, cfg_first, S_ref):
         p0 = eng(x.to(dtype).cuda(), 300, ctx.to(dtype).cuda())[0]
         assert torch.equal(out[:1], p0[:1]) and not torch.equal(out[1:], p0[1:])
     del keep
+
+
+@pytest.mark.gpu
+def test_engine_sd21_topology_zero123pp_tiling(lib):
+    """BASELINE config 2 (Zero123++): SD-2.1 topology -- head_dim 64, use_linear_projection, context dim 1024 -- on the
+    reference-true 3:2 latent tiling (120 x 80 scaled down to 48 x 32), with reference-only attention and CFG-first item
+    (lib/pipelines/zero123plus.py:107-150)."""
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg = dict(U.SD21, block_out_channels=(320, 640, 1280), layers_per_block=1, down_attn=(True, True, True), num_heads=(5, 10, 20),
+               transformer_layers=(1, 1, 1))
+    dtype, B = torch.float16, 2
+    sd = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=12).items()}
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 4, 48, 32, generator=g).to(dtype).float()          # 3:2 tiling of six views
+    cond = torch.randn(B, 4, 16, 16, generator=g).to(dtype).float()       # condition latent (size from the checkpoint's preprocessor)
+    ctx = torch.randn(B, 77, 1024, generator=g).to(dtype).float()
+
+    def oracle(q):
+        d = {}
+        U.unet_forward(sd, cfg, cond, 400, ctx, attn_opts=dict(mode='w', ref_dict=d, ref_skip=1), q=q)
+        return U.unet_forward(sd, cfg, x, 400, ctx, attn_opts=dict(mode='r', ref_dict=d, ref_skip=1), q=q)
+    with torch.no_grad():
+        ref32, ref16 = oracle(None), oracle(U.quantizer(dtype))
+    eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype)
+    d = {}
+    eng(cond.to(dtype).cuda(), 400, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='w', ref_dict=d, is_cfg_guidance=True))
+    out = eng(x.to(dtype).cuda(), 400, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='r', ref_dict=d, is_cfg_guidance=True))[0]
+    assert out.shape == (B, 4, 48, 32)
+    _check(out, ref16, ref32)
