@@ -282,10 +282,12 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
 
 template <class Tag, int MODE, bool SEQ, bool FAST>
 int launch_big3(const GemmParams& p, hipStream_t s) {
-    static bool configured = false;
-    if (!configured) {
+    static bool configured[64] = {};             // the attribute is per device; one process may drive several
+    int dev = 0;
+    MVE_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !configured[dev]) {
         MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big<Tag, MODE, SEQ, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG));
-        configured = true;
+        configured[dev] = true;
     }
     const unsigned grid = (unsigned)mve_cdiv(p.M, BM2) * (unsigned)mve_cdiv(p.N, BN2) * (unsigned)(p.splitk > 1 ? p.splitk : 1);
     k_gemm_big<Tag, MODE, SEQ, FAST><<<grid, NTH, SMEM_BIG, s>>>(p);
