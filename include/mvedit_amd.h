@@ -164,6 +164,7 @@ MVE_API int mve_density_grid_update(float* d_density_grid, float* d_tmp_grid, ui
 #define MVE_GEMM_OUT_F32 2   /* out is float32 instead of `dtype` */
 #define MVE_CONV_W_CHUNK64 4 /* conv weight is [Cout][Cin/64][3][3][64] (needs C1, C2 multiples of 64) */
 #define MVE_GEMM_NO_SPLITK 8 /* never split K even if a workspace is given */
+#define MVE_GEMM_RES_AFTER_SCALE 16   /* out = (acc + bias) * out_scale + residual (default: residual is added before the scale) */
 
 /* out[m][n] = out_scale * ( sum_k A[m][k]*W[n][k] + bias[n] + rowvec[m/rows_per_vec][n] + residual[m][n] )
  * A: [M][lda] dtype, W: [N][ldw] dtype (torch Linear / 1x1-conv layout; ldw > K selects a column block),
@@ -275,6 +276,23 @@ MVE_API int mve_unet_forward(void* handle, int phase, const void* d_sample, int 
                              const void* d_ctx, int B, int H, int W, int ctx_len, int num_cross_attn_imgs,
                              const void* const* down_residuals, const void* d_mid_residual, int residuals_nhwc,
                              void* d_out, void* d_workspace, size_t workspace_bytes, float* op_ms, void* stream);
+/* ControlNetModel (diffusers; lib/pipelines/adapter3d_mixin.py:101-116, :173-186, :279-287 call it through MultiControlNetModel):
+ * the UNet's conv_in + down blocks + mid block, a conditioning embedding on the 8H x 8W control image that is added to
+ * conv_in(sample), and one 1x1 "zero" convolution per skip / mid tensor.  Same topology arguments and parameter-loading
+ * protocol as the UNet (mve_unet_load_param / _missing_params / _plan / _weight_bytes / _destroy work on the handle; parameter
+ * names are the ControlNetModel state-dict names).
+ *   d_cond       [B, conditioning_channels, 8H, 8W] NCHW in io_dtype
+ *   d_outputs    n_levels*(layers_per_block+1) + 1 device pointers: down_block_res_samples then mid_block_res_sample, each NHWC
+ *                [B*h*w, C] in the ENGINE dtype -- exactly what mve_unet_forward accepts with residuals_nhwc = 1
+ *   out_k = conditioning_scale * zero_conv_k(feature_k), or, with accumulate != 0, out_k += that (MultiControlNetModel's sum) */
+MVE_API int mve_controlnet_create(void** handle, int dtype, int in_channels, int conditioning_channels, int n_levels,
+                                  const int* block_out_channels, int layers_per_block, const int* down_attn, const int* num_heads,
+                                  const int* transformer_layers, int cross_attention_dim, int norm_num_groups, float norm_eps,
+                                  int use_linear_projection);
+MVE_API int mve_controlnet_forward(void* handle, const void* d_sample, int io_dtype, const float* d_timesteps, const void* d_ctx,
+                                   const void* d_cond, int B, int H, int W, int ctx_len, float conditioning_scale, int accumulate,
+                                   void* const* d_outputs, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Attention-processor options of the reference, applied to every later plan/forward of this engine:
  *   ip_tokens > 0 : IPAttnProcessor2_0 (lib/models/architecture/ip_adapter/attention_processor.py:301-396) -- the last ip_tokens rows of
  *                   encoder_hidden_states are projected with `<block>.attn2.processor.to_k_ip/to_v_ip.weight` (loaded through

@@ -444,6 +444,7 @@ int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* ou
     p.geglu = (flags & MVE_GEMM_GEGLU) ? 1 : 0;
     p.out_f32 = (flags & MVE_GEMM_OUT_F32) ? 1 : 0;
     p.out_scale = out_scale;
+    p.res_after_scale = (flags & MVE_GEMM_RES_AFTER_SCALE) ? 1 : 0;
     if (M == 0) return MVE_OK;
     int rc = check_common(p, "gemm");
     if (rc) return rc;
@@ -488,6 +489,7 @@ int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B
     p.geglu = 0;
     p.out_f32 = (flags & MVE_GEMM_OUT_F32) ? 1 : 0;
     p.out_scale = out_scale;
+    p.res_after_scale = (flags & MVE_GEMM_RES_AFTER_SCALE) ? 1 : 0;
     int rc = check_common(p, "conv3x3");
     if (rc) return rc;
     p.splitk = 1;

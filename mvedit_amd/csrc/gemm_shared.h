@@ -37,6 +37,7 @@ struct GemmParams {
     int geglu;         // 1: out[m][i] = v[2i] * gelu(v[2i+1])
     int out_f32;       // 1: out is float
     float out_scale;   // multiplies the final value (1/output_scale_factor)
+    int res_after_scale;   // 1: out = (acc + bias) * out_scale + residual  (ControlNet: running sum over nets of scale * zero_conv)
     int splitk;        // > 1: K is cut into `splitk` slices, each block writes an fp32 partial tile to `partial`
     float* partial;    // [splitk][M][N] fp32 workspace (split-K only)
     int splitk_seq;    // > 1 (big-tile kernel only): ONE block walks all of K but rounds like `splitk_seq` concurrent slices --
@@ -100,13 +101,18 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, 
         *reinterpret_cast<T4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1)) = pk;
         return;
     }
-    if (p.residual) {
+    if (p.residual && !p.res_after_scale) {
         const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+    if (p.residual && p.res_after_scale) {
+        const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
+    }
     if (p.out_f32) {
         float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
         *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};

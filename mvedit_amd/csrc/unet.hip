@@ -102,7 +102,10 @@ __global__ void k_group_mean(const typename Tag::T* __restrict__ x, typename Tag
 // ---------------------------------------------------------------------------------------------------
 // configuration / parameter table
 // ---------------------------------------------------------------------------------------------------
+constexpr int CN_EMB[4] = {16, 32, 96, 256};      // diffusers ControlNetModel conditioning_embedding_out_channels (default)
+
 struct Config {
+    int controlnet = 0, cond_ch = 3;   // ControlNetModel: encoder + mid of the UNet, conditioning embedding, zero convolutions
     int dtype, in_ch, out_ch, n_levels, layers_per_block, ctx_dim, groups, linear_proj;
     float eps;
     int ch[MAX_LEVELS], attn[MAX_LEVELS], heads[MAX_LEVELS], tlayers[MAX_LEVELS];
@@ -118,7 +121,7 @@ struct Param {   // one engine-owned packed tensor (or a slice view of one)
 enum OpClass { OC_CONV = 0, OC_LINEAR = 1, OC_ATTN = 2, OC_NORM = 3, OC_OTHER = 4, OC_COUNT = 5 };
 
 struct Ref {
-    enum Kind { NUL, WS, WT, SAMPLE, TIMESTEPS, CTX, OUT, DOWNRES, MIDRES, REFSTORE } kind = NUL;
+    enum Kind { NUL, WS, WT, SAMPLE, TIMESTEPS, CTX, OUT, DOWNRES, MIDRES, REFSTORE, CNCOND, CNOUT } kind = NUL;
     size_t off = 0;
     int idx = 0;
 };
@@ -128,6 +131,10 @@ struct Run {
     const void* sample; const float* timesteps; const void* ctx; void* out;
     const void* const* down_res; const void* mid_res;
     unsigned char* ref_store;
+    const void* cn_cond = nullptr;            // ControlNet: conditioning image [B, cond_ch, 8H, 8W] NCHW (io dtype)
+    void* const* cn_out = nullptr;            // ControlNet: n_skips + 1 output tensors (NHWC, engine dtype)
+    float cn_scale = 1.0f;                    // conditioning_scale
+    int cn_accum = 0;                         // 1: add to what the outputs already hold (MultiControlNetModel's sum)
     hipStream_t stream;
     void* p(const Ref& r) const {
         switch (r.kind) {
@@ -140,6 +147,8 @@ struct Run {
             case Ref::DOWNRES: return (void*)down_res[r.idx];
             case Ref::MIDRES: return (void*)mid_res;
             case Ref::REFSTORE: return ref_store + r.off;
+            case Ref::CNCOND: return (void*)cn_cond;
+            case Ref::CNOUT: return cn_out[r.idx];
             default: return nullptr;
         }
     }
@@ -257,6 +266,7 @@ void enumerate(const Config& c, std::vector<ResnetDesc>& rs, std::vector<XfDesc>
     rs.push_back({"mid_block.resnets.0", c.ch[n - 1], c.ch[n - 1]});
     xs.push_back({"mid_block.attentions.0", c.ch[n - 1], c.heads[n - 1], c.tlayers[n - 1]});
     rs.push_back({"mid_block.resnets.1", c.ch[n - 1], c.ch[n - 1]});
+    if (c.controlnet) return;
     int prev = c.ch[n - 1];
     for (int i = 0; i < n; ++i) {
         const int lvl = n - 1 - i, cout = c.ch[lvl];
@@ -360,15 +370,46 @@ void layout_params(Unet& u) {
         const std::string d = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
         sb.add(d + ".w", C * 9 * C, false); need(d + ".weight");
         sb.add(d + ".b", C, true); need(d + ".bias");
+        if (c.controlnet) continue;
         const size_t Cu = c.ch[c.n_levels - 1 - i];
         const std::string up = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
         sb.add(up + ".w", Cu * 9 * Cu, false); need(up + ".weight");
         sb.add(up + ".b", Cu, true); need(up + ".bias");
     }
-    sb.add("norm_out.g", c.ch[0], true); need("conv_norm_out.weight");
-    sb.add("norm_out.b", c.ch[0], true); need("conv_norm_out.bias");
-    sb.add("conv_out.w", (size_t)8 * 9 * c.ch[0], false); need("conv_out.weight");
-    sb.add("conv_out.b", 8, true); need("conv_out.bias");
+    if (!c.controlnet) {
+        sb.add("norm_out.g", c.ch[0], true); need("conv_norm_out.weight");
+        sb.add("norm_out.b", c.ch[0], true); need("conv_norm_out.bias");
+        sb.add("conv_out.w", (size_t)8 * 9 * c.ch[0], false); need("conv_out.weight");
+        sb.add("conv_out.b", 8, true); need("conv_out.bias");
+    } else {
+        // controlnet_cond_embedding: conv_in (cond_ch -> 16), blocks (16->16, 16->32 s2, 32->32, 32->96 s2, 96->96, 96->256 s2),
+        // conv_out (256 -> ch[0]); controlnet_down_blocks.k / controlnet_mid_block: 1x1 "zero" convolutions
+        const std::string e = "controlnet_cond_embedding.";
+        sb.add(e + "conv_in.w", (size_t)CN_EMB[0] * 9 * 8, false); need(e + "conv_in.weight");
+        sb.add(e + "conv_in.b", CN_EMB[0], true); need(e + "conv_in.bias");
+        for (int k = 0; k < 6; ++k) {
+            const int ci = CN_EMB[k / 2], co = CN_EMB[(k + 1) / 2];
+            const std::string b = e + "blocks." + std::to_string(k);
+            sb.add(b + ".w", (size_t)co * 9 * ci, false); need(b + ".weight");
+            sb.add(b + ".b", co, true); need(b + ".bias");
+        }
+        sb.add(e + "conv_out.w", (size_t)c.ch[0] * 9 * CN_EMB[3], false); need(e + "conv_out.weight");
+        sb.add(e + "conv_out.b", c.ch[0], true); need(e + "conv_out.bias");
+        int k = 0;
+        auto zero_conv = [&](int C) {
+            const std::string z = "controlnet_down_blocks." + std::to_string(k++);
+            sb.add(z + ".w", (size_t)C * C, false); need(z + ".weight");
+            sb.add(z + ".b", C, true); need(z + ".bias");
+        };
+        zero_conv(c.ch[0]);
+        for (int i = 0; i < c.n_levels; ++i) {
+            for (int j = 0; j < c.layers_per_block; ++j) zero_conv(c.ch[i]);
+            if (i + 1 < c.n_levels) zero_conv(c.ch[i]);
+        }
+        const size_t Cm = c.ch[c.n_levels - 1];
+        sb.add("controlnet_mid_block.w", Cm * Cm, false); need("controlnet_mid_block.weight");
+        sb.add("controlnet_mid_block.b", Cm, true); need("controlnet_mid_block.bias");
+    }
     u.slab_bytes = sb.top;
 }
 
@@ -440,6 +481,20 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         const std::string r = strip(name, ".time_emb_proj.bias");
         MVE_CHECK(u.temb_off.count(r), MVE_ERR_ARG, "load_param: unknown resnet %s", r.c_str());
         rc = vec(P("temb_proj.b"), u.temb_off[r], shape[0], 1);
+    } else if (name == "controlnet_cond_embedding.conv_in.weight") {
+        MVE_HIP(hipMemsetAsync(dstp(P("controlnet_cond_embedding.conv_in.w"), 0), 0, P("controlnet_cond_embedding.conv_in.w")->bytes, s));
+        rc = conv(P("controlnet_cond_embedding.conv_in.w"), CN_EMB[0], c.cond_ch, CN_EMB[0], 8);
+    } else if (name.compare(0, 26, "controlnet_cond_embedding.") == 0 && ends_with(name, ".weight")) {
+        MVE_CHECK(ndim == 4, MVE_ERR_ARG, "load_param(%s): expected a 4-D conv weight", name.c_str());
+        rc = conv(P(strip(name, ".weight") + ".w"), shape[0], shape[1], shape[0], shape[1]);
+    } else if (name.compare(0, 26, "controlnet_cond_embedding.") == 0 && ends_with(name, ".bias")) {
+        rc = vec(P(strip(name, ".bias") + ".b"), 0, shape[0], 1);
+    } else if ((name.compare(0, 23, "controlnet_down_blocks.") == 0 || name.compare(0, 21, "controlnet_mid_block.") == 0) && ends_with(name, ".weight")) {
+        Param* p = P(strip(name, ".weight") + ".w");
+        MVE_CHECK(p && ndim >= 2, MVE_ERR_ARG, "load_param: no slot for %s", name.c_str());
+        rc = mat(p, 0, shape[0], shape[1], shape[1]);
+    } else if ((name.compare(0, 23, "controlnet_down_blocks.") == 0 || name.compare(0, 21, "controlnet_mid_block.") == 0) && ends_with(name, ".bias")) {
+        rc = vec(P(strip(name, ".bias") + ".b"), 0, shape[0], 1);
     } else if (ends_with(name, ".conv_shortcut.weight")) {
         Param* p = P(strip(name, ".conv_shortcut.weight") + ".sc.w");
         MVE_CHECK(p && ndim >= 2, MVE_ERR_ARG, "load_param: no slot for %s", name.c_str());
@@ -611,6 +666,23 @@ struct Builder {
             return hipMemcpy2DAsync(r.p(dst), dpitch, r.p(src), spitch, width, rows, hipMemcpyDeviceToDevice, r.stream) == hipSuccess
                        ? MVE_OK : MVE_ERR_HIP;
         });
+    }
+
+    // ControlNet output k: out_k (+)= conditioning_scale * (W x + b), a 1x1 "zero convolution" (diffusers ControlNetModel
+    // controlnet_down_blocks / controlnet_mid_block, then the `* conditioning_scale` and MultiControlNetModel's running sum)
+    void zero_conv(Ref x, int C, int M, int hw, const std::string& name, int out_idx) {
+        const int d = dt;
+        Ref W = wt(name + ".w"), bias = wt(name + ".b");
+        Ref out; out.kind = Ref::CNOUT; out.idx = out_idx;
+        live(x, "controlnet zero conv");
+        const size_t skb = mve_gemm_workspace_bytes(M, C, C, hw);
+        Ref sk = skb ? ws(skb) : Ref();
+        op(OC_LINEAR, 2.0 * M * (double)C * C, "controlnet zero conv", [=](const Run& r) {
+            void* o = r.p(out);
+            return mve_gemm(d, r.p(x), C, r.p(W), C, o, C, M, C, C, (const float*)r.p(bias), nullptr, 0, 0, r.cn_accum ? o : nullptr, C,
+                            MVE_GEMM_RES_AFTER_SCALE, r.cn_scale, r.p(sk), skb, hw, r.stream);
+        });
+        rel(sk);
     }
 
     // ResnetBlock2D.  x [M,C1] (+ skip [M,C2]) -> new buffer [M,Cout]
@@ -826,7 +898,37 @@ struct Builder {
         struct Skip { Ref r; int C, H, W; };
         std::vector<Skip> skips;
         Ref x = ws((size_t)M0 * c.ch[0] * e);
-        conv(x_in, 8, Bb, H, W, 1, 0, wt("conv_in.w"), c.ch[0], x, wt("conv_in.b"), Ref(), 0, Ref(), 0, "conv_in");
+        if (c.controlnet) {
+            // controlnet_cond_embedding on the 8H x 8W conditioning image, added to conv_in(sample)
+            const int Hc = 8 * H, Wc = 8 * W, cc = c.cond_ch;
+            Ref cimg = ws((size_t)Bb * Hc * Wc * 8 * e);
+            {
+                Ref src; src.kind = Ref::CNCOND;
+                op(OC_OTHER, 0, "cond nchw->nhwc", [=](const Run& r) { return mve_nchw_to_nhwc(d, io_dtype, r.p(src), Bb, cc, Hc, Wc, 8, r.p(cimg), r.stream); });
+            }
+            const std::string en = "controlnet_cond_embedding.";
+            int hc = Hc, wc = Wc, ci = 8;
+            Ref cur = cimg;
+            auto emb_conv = [&](const std::string& nm, int co, int stride, bool act) {
+                const int ho = (hc - 1) / stride + 1, wo = (wc - 1) / stride + 1;
+                Ref y = ws((size_t)Bb * ho * wo * co * e);
+                conv(cur, ci, Bb, hc, wc, stride, 0, wt(nm + ".w"), co, y, wt(nm + ".b"), Ref(), 0, Ref(), 0, "cond_embedding.conv");
+                rel(cur);
+                if (act) {
+                    const size_t nel = (size_t)Bb * ho * wo * co;
+                    op(OC_OTHER, 0, "silu", [=](const Run& r) { return mve_silu(d, r.p(y), r.p(y), nel, r.stream); });
+                }
+                cur = y; hc = ho; wc = wo; ci = co;
+            };
+            emb_conv(en + "conv_in", CN_EMB[0], 1, true);
+            for (int k = 0; k < 6; ++k) emb_conv(en + "blocks." + std::to_string(k), CN_EMB[(k + 1) / 2], (k & 1) ? 2 : 1, true);
+            emb_conv(en + "conv_out", c.ch[0], 1, false);
+            MVE_CHECK(hc == H && wc == W, MVE_ERR_ARG, "controlnet: conditioning image must be 8x the latent size");
+            conv(x_in, 8, Bb, H, W, 1, 0, wt("conv_in.w"), c.ch[0], x, wt("conv_in.b"), Ref(), 0, cur, 0, "conv_in + cond_embedding");
+            rel(cur);
+        } else {
+            conv(x_in, 8, Bb, H, W, 1, 0, wt("conv_in.w"), c.ch[0], x, wt("conv_in.b"), Ref(), 0, Ref(), 0, "conv_in");
+        }
         rel(x_in);
         skips.push_back({x, c.ch[0], H, W});
         int h = H, w = W, cin = c.ch[0];
@@ -853,6 +955,21 @@ struct Builder {
             }
         }
         pl.enc_end = pl.ops.size();
+        if (c.controlnet) {
+            const int C = c.ch[n - 1];
+            for (size_t i = 0; i < skips.size(); ++i)
+                zero_conv(skips[i].r, skips[i].C, Bb * skips[i].H * skips[i].W, skips[i].H * skips[i].W, "controlnet_down_blocks." + std::to_string(i), (int)i);
+            Ref y = resnet("mid_block.resnets.0", x, C, Ref(), 0, C, h, w);
+            Ref z = transformer("mid_block.attentions.0", y, C, c.heads[n - 1], c.tlayers[n - 1], h, w);
+            rel(y);
+            Ref m = resnet("mid_block.resnets.1", z, C, Ref(), 0, C, h, w);
+            rel(z);
+            zero_conv(m, C, Bb * h * w, h * w, "controlnet_mid_block", (int)skips.size());
+            pl.ws_bytes = ar.peak + 256;
+            pl.ref_store_bytes = ref_off;
+            if (!u.err.empty()) { mve_set_error("controlnet plan: %s", u.err.c_str()); u.err.clear(); return MVE_ERR_STATE; }
+            return MVE_OK;
+        }
         // ---- ControlNet residuals (diffusers.py:110-121 of the reference) -----------------------------------
         if (has_res) {
             for (size_t i = 0; i < skips.size(); ++i) {
@@ -1010,6 +1127,66 @@ int mve_unet_create(void** handle, int dtype, int in_channels, int out_channels,
     return MVE_OK;
 }
 
+int mve_controlnet_create(void** handle, int dtype, int in_channels, int conditioning_channels, int n_levels, const int* block_out_channels,
+                          int layers_per_block, const int* down_attn, const int* num_heads, const int* transformer_layers,
+                          int cross_attention_dim, int norm_num_groups, float norm_eps, int use_linear_projection) {
+    MVE_CHECK(conditioning_channels >= 1 && conditioning_channels <= 8, MVE_ERR_ARG, "controlnet_create: conditioning channels must be <= 8");
+    // same topology arguments as the UNet; build the parameter table in ControlNet mode
+    MVE_CHECK(handle, MVE_ERR_ARG, "controlnet_create: null handle");
+    MVE_CHECK(dtype == MVE_F16 || dtype == MVE_BF16, MVE_ERR_ARG, "controlnet_create: dtype must be f16 or bf16");
+    MVE_CHECK(n_levels >= 1 && n_levels <= MAX_LEVELS && layers_per_block >= 1, MVE_ERR_ARG, "controlnet_create: bad topology");
+    MVE_CHECK(in_channels >= 1 && in_channels <= 8, MVE_ERR_ARG, "controlnet_create: in channels must be <= 8");
+    MVE_CHECK(cross_attention_dim % 8 == 0, MVE_ERR_ARG, "controlnet_create: cross_attention_dim must be a multiple of 8");
+    Unet* u = new Unet();
+    Config& c = u->cfg;
+    c.controlnet = 1; c.cond_ch = conditioning_channels;
+    c.dtype = dtype; c.in_ch = in_channels; c.out_ch = in_channels; c.n_levels = n_levels; c.layers_per_block = layers_per_block;
+    c.ctx_dim = cross_attention_dim; c.groups = norm_num_groups; c.eps = norm_eps; c.linear_proj = use_linear_projection;
+    for (int i = 0; i < n_levels; ++i) {
+        c.ch[i] = block_out_channels[i]; c.attn[i] = down_attn[i]; c.heads[i] = num_heads[i]; c.tlayers[i] = transformer_layers[i];
+        if (c.ch[i] % 32 != 0 || c.ch[i] % c.groups != 0 || (c.attn[i] && c.ch[i] % c.heads[i] != 0)) {
+            delete u;
+            mve_set_error("controlnet_create: channel count %d incompatible with groups/heads", block_out_channels[i]);
+            return MVE_ERR_ARG;
+        }
+    }
+    layout_params(*u);
+    *handle = u;
+    return MVE_OK;
+}
+
+int mve_controlnet_forward(void* handle, const void* d_sample, int io_dtype, const float* d_timesteps, const void* d_ctx, const void* d_cond,
+                           int B, int H, int W, int ctx_len, float conditioning_scale, int accumulate, void* const* d_outputs,
+                           void* d_workspace, size_t workspace_bytes, void* stream) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "controlnet_forward: null handle");
+    Unet* u = (Unet*)handle;
+    MVE_CHECK(u->cfg.controlnet, MVE_ERR_ARG, "controlnet_forward: handle is a UNet, not a ControlNet");
+    {
+        char first[256];
+        const int miss = mve_unet_missing_params(handle, first, sizeof(first));
+        MVE_CHECK(miss == 0, MVE_ERR_STATE, "controlnet_forward: %d parameters not loaded (first: %s)", miss, first);
+    }
+    MVE_CHECK(d_sample && d_timesteps && d_ctx && d_cond && d_outputs, MVE_ERR_ARG, "controlnet_forward: null pointer");
+    int rc = ensure_plan(*u, B, H, W, 1, 0, io_dtype, 0, ctx_len);
+    if (rc) return rc;
+    const Plan& pl = *u->cur;
+    MVE_CHECK(d_workspace && workspace_bytes >= pl.ws_bytes, MVE_ERR_NOMEM, "controlnet_forward: workspace %zu < required %zu", workspace_bytes,
+              pl.ws_bytes);
+    const int n_out = u->cfg.n_levels * (u->cfg.layers_per_block + 1) + 1;
+    for (int i = 0; i < n_out; ++i) MVE_CHECK(d_outputs[i], MVE_ERR_ARG, "controlnet_forward: null output %d", i);
+    Run r;
+    r.ws = (unsigned char*)d_workspace; r.wt = u->slab;
+    r.sample = d_sample; r.timesteps = d_timesteps; r.ctx = d_ctx; r.out = nullptr;
+    r.down_res = nullptr; r.mid_res = nullptr; r.ref_store = nullptr;
+    r.cn_cond = d_cond; r.cn_out = d_outputs; r.cn_scale = conditioning_scale; r.cn_accum = accumulate ? 1 : 0;
+    r.stream = (hipStream_t)stream;
+    for (size_t i = 0; i < pl.ops.size(); ++i) {
+        rc = pl.ops[i].fn(r);
+        if (rc) return rc;
+    }
+    return MVE_OK;
+}
+
 int mve_unet_destroy(void* handle) {
     if (!handle) return MVE_OK;
     Unet* u = (Unet*)handle;
@@ -1064,6 +1241,7 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
                      float* op_ms /* optional host array [n_ops]: per-op milliseconds (synchronises) */, void* stream) {
     MVE_CHECK(handle, MVE_ERR_ARG, "unet_forward: null handle");
     Unet* u = (Unet*)handle;
+    MVE_CHECK(!u->cfg.controlnet, MVE_ERR_ARG, "unet_forward: handle is a ControlNet (use mve_controlnet_forward)");
     {
         char first[256];
         const int miss = mve_unet_missing_params(handle, first, sizeof(first));

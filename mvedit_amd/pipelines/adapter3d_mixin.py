@@ -48,8 +48,8 @@ class Adapter3DMixin:
                 conditioning_scale=[tile_weight, depth_weight] + [1.0] * len(extra_control),
                 guess_mode=False, added_cond_kwargs=added_cond_kwargs, return_dict=False)
             if paired:   # zero residuals for the reference rows (adapter3d_mixin.py:110-116)
-                down_res = [torch.stack([torch.zeros_like(r), r], dim=1).view(-1, *r.shape[1:]) for r in down_res]
-                mid_res = torch.stack([torch.zeros_like(mid_res), mid_res], dim=1).view(-1, *mid_res.shape[1:])
+                down_res = [torch.stack([torch.zeros_like(r), r], dim=1).reshape(-1, *r.shape[1:]) for r in down_res]
+                mid_res = torch.stack([torch.zeros_like(mid_res), mid_res], dim=1).reshape(-1, *mid_res.shape[1:])
         out = self.unet(unet_in, t, encoder_hidden_states=unet_embeds, cross_attention_kwargs=cross_attention_kwargs,
                         down_block_additional_residuals=down_res, mid_block_additional_residual=mid_res,
                         added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
@@ -102,8 +102,8 @@ class Adapter3DMixin:
     @staticmethod
     def _pad_pair(down_res, mid_res):
         """zero residuals for the reference rows (adapter3d_mixin.py:186-192)."""
-        down_res = [torch.stack([torch.zeros_like(r), r], dim=1).view(-1, *r.shape[1:]) for r in down_res]
-        mid_res = torch.stack([torch.zeros_like(mid_res), mid_res], dim=1).view(-1, *mid_res.shape[1:])
+        down_res = [torch.stack([torch.zeros_like(r), r], dim=1).reshape(-1, *r.shape[1:]) for r in down_res]
+        mid_res = torch.stack([torch.zeros_like(mid_res), mid_res], dim=1).reshape(-1, *mid_res.shape[1:])
         return down_res, mid_res
 
     def _sub_controlnet(self, nets):

@@ -181,6 +181,13 @@ class UNet2DConditionEngine:
         if has_res:
             want = len(self.cfg['block_out_channels']) * (self.cfg['layers_per_block'] + 1)
             assert len(down_res) == want, f'expected {want} down-block residuals, got {len(down_res)}'
+            # residuals produced by mvedit_amd.controlnet are logical NCHW over channels-last storage in the engine dtype:
+            # hand the storage over as NHWC without a copy
+            cl = lambda r: r.dim() == 4 and r.dtype == self.dtype and r.is_cuda and r.permute(0, 2, 3, 1).is_contiguous()
+            if not residuals_nhwc and all(cl(r) for r in down_res) and cl(mid_res):
+                residuals_nhwc = True
+                down_res = [r.permute(0, 2, 3, 1) for r in down_res]
+                mid_res = mid_res.permute(0, 2, 3, 1)
             rdt = self.dtype if residuals_nhwc else io_dtype
             keep = [r.to(device=self.device, dtype=rdt).contiguous() for r in down_res]
             mid_res = mid_res.to(device=self.device, dtype=rdt).contiguous()

@@ -1,0 +1,116 @@
+"""ControlNet executor (csrc/unet.hip in ControlNet mode, mvedit_amd.controlnet) vs the torch oracle restatement of diffusers'
+ControlNetModel / MultiControlNetModel as the reference calls them (lib/pipelines/adapter3d_mixin.py:101-116).
+SURVEY section 8(f) rank 2 ("next" row): same kernels as the UNet, parity bar as tests/test_unet.py."""
+import pytest
+import torch
+
+from oracle import unet_oracle as U
+from test_unet import _rel, inputs
+
+
+def test_plan_flops_sd15_controlnet(lib):
+    from mvedit_amd.controlnet import ControlNetEngine
+    eng = ControlNetEngine(U.SD15, torch.float16, device='cpu')
+    info = eng.plan(1, 64, 64, 77)
+    total = sum(info['flops'][k] for k in ('conv3x3', 'linear', 'attention'))
+    # one SD-1.5 ControlNet ~ 0.261 TFLOP/image (encoder + mid) + ~0.02 for the conditioning embedding / zero convs
+    assert 0.255e12 < total < 0.30e12, total
+    shapes, mid = eng.output_shapes(1, 64, 64)
+    assert len(shapes) == 12 and shapes[0] == (320, 64, 64) and shapes[-1] == (1280, 8, 8) and mid == (1280, 8, 8)
+
+
+def _case(cfg, B, S, seed):
+    sd = {k: v.half().float() for k, v in U.make_controlnet_state_dict(cfg, seed=seed).items()}
+    x, ctx = inputs(cfg, B, S, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    cond = torch.rand(B, 3, 8 * S, 8 * S, generator=g)
+    return sd, x.half().float(), ctx.half().float(), cond.half().float()
+
+
+@pytest.mark.gpu
+def test_controlnet_engine_vs_oracle(lib):
+    from mvedit_amd.controlnet import ControlNetEngine
+    cfg, dtype, B, S = U.TINY, torch.float16, 2, 16
+    sd, x, ctx, cond = _case(cfg, B, S, 1)
+    with torch.no_grad():
+        d32, m32 = U.controlnet_forward(sd, cfg, x, 300, ctx, cond, 0.7)
+        d16, m16 = U.controlnet_forward(sd, cfg, x, 300, ctx, cond, 0.7, q=U.quantizer(dtype))
+    eng = ControlNetEngine.from_state_dict(sd, cfg, dtype)
+    down, mid = eng(x.half().cuda(), 300, ctx.half().cuda(), cond.half().cuda(), conditioning_scale=0.7)
+    assert len(down) == len(d32) == 4
+    for got, r16, r32 in zip(list(down) + [mid], list(d16) + [m16], list(d32) + [m32]):
+        assert got.shape == r32.shape and got.dtype == dtype
+        l2_16, mx_16 = _rel(got, r16)
+        l2_32, _ = _rel(got, r32)
+        emu, _ = _rel(r16, r32)
+        assert l2_16 <= 3e-3 and mx_16 <= 6e-3, (l2_16, mx_16)
+        assert l2_32 <= 1.05 * emu + 1e-4, (l2_32, emu)
+    # unknown parameter names / a UNet state dict are rejected loudly
+    from mvedit_amd._lib import MveError
+    with pytest.raises((MveError, KeyError)):
+        ControlNetEngine.from_state_dict(U.make_state_dict(cfg), cfg, dtype)
+
+
+@pytest.mark.gpu
+def test_multi_controlnet_feeds_unet_zero_copy(lib):
+    """Two nets with different scales are summed in place (MultiControlNetModel); the channels-last outputs go into the UNet
+    engine without a layout conversion and give the same bits as NCHW copies of them."""
+    from mvedit_amd.controlnet import ControlNetEngine, MultiControlNetEngine
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg, dtype, B, S = U.TINY, torch.float16, 3, 16
+    sd1, x, ctx, cond1 = _case(cfg, B, S, 2)
+    sd2, _, _, cond2 = _case(cfg, B, S, 3)
+    multi = MultiControlNetEngine([ControlNetEngine.from_state_dict(sd1, cfg, dtype), ControlNetEngine.from_state_dict(sd2, cfg, dtype)])
+    xg, cg = x.half().cuda(), ctx.half().cuda()
+    down, mid = multi(xg, 450, cg, [cond1.half().cuda(), cond2.half().cuda()], [0.5, 1.25])
+    with torch.no_grad():
+        q = U.quantizer(dtype)
+        da, ma = U.controlnet_forward(sd1, cfg, x, 450, ctx, cond1, 0.5, q=q)
+        db, mb = U.controlnet_forward(sd2, cfg, x, 450, ctx, cond2, 1.25, q=q)
+    for got, a, b in zip(list(down) + [mid], list(da) + [ma], list(db) + [mb]):
+        l2, mx = _rel(got, a + b)
+        assert l2 <= 3e-3 and mx <= 8e-3, (l2, mx)
+    usd = {k: v.half().float() for k, v in U.make_state_dict(cfg, seed=21).items()}
+    unet = UNet2DConditionEngine.from_state_dict(usd, cfg, dtype)
+    out_cl = unet(xg, 450, cg, down_block_additional_residuals=down, mid_block_additional_residual=mid)[0]
+    out_nchw = unet(xg, 450, cg, down_block_additional_residuals=[d.contiguous() for d in down], mid_block_additional_residual=mid.contiguous())[0]
+    assert torch.equal(out_cl, out_nchw)
+    with torch.no_grad():
+        ref = U.unet_forward(usd, cfg, x, 450, ctx, 1, [a + b for a, b in zip(da, db)], ma + mb, q=q)
+    assert _rel(out_cl, ref)[0] <= 3e-3
+
+
+@pytest.mark.gpu
+def test_get_noise_pred_with_native_controlnets(lib):
+    """The 1-pass method of the reference (adapter3d_mixin.py:68-135) end to end on native engines, paired latents included."""
+    from mvedit_amd.controlnet import ControlNetEngine, MultiControlNetEngine
+    from mvedit_amd.pipelines import Adapter3DMixin
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg, dtype, V, S = U.TINY, torch.float16, 2, 16
+
+    class Pipe(Adapter3DMixin):
+        pass
+    p = Pipe()
+    usd = {k: v.half().float() for k, v in U.make_state_dict(cfg, seed=21).items()}
+    p.unet = UNet2DConditionEngine.from_state_dict(usd, cfg, dtype)
+    sds = [_case(cfg, 1, S, s)[0] for s in (5, 6)]
+    p.controlnet = MultiControlNetEngine([ControlNetEngine.from_state_dict(sd, cfg, dtype) for sd in sds])
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(2 * V, 4, S, S, generator=g).half()
+    emb = torch.randn(2 * V, 77, 768, generator=g).half()
+    img = torch.rand(2 * V, 3, 8 * S, 8 * S, generator=g).half()
+    dep = torch.rand(2 * V, 3, 8 * S, 8 * S, generator=g).half()
+    out = p.get_noise_pred([lat[:V].cuda(), lat[V:].cuda()], [emb[:V].cuda(), emb[V:].cuda()], [img[:V].cuda(), img[V:].cuda()],
+                           [dep[:V].cuda(), dep[V:].cuda()], 500, 0.6, 0.4, 4.0)
+    with torch.no_grad():
+        q = U.quantizer(dtype)
+        da, ma = U.controlnet_forward(sds[0], cfg, lat.float(), 500, emb.float(), img.float(), 0.6, q=q)
+        db, mb = U.controlnet_forward(sds[1], cfg, lat.float(), 500, emb.float(), dep.float(), 0.4, q=q)
+        full = U.unet_forward(usd, cfg, lat.float(), 500, emb.float(), 1, [a + b for a, b in zip(da, db)], ma + mb, q=q)
+    ref = 4.0 * full[V:] + (1 - 4.0) * full[:V]
+    bound = (4.0 + 3.0) * 3e-3 * max(full[V:].norm(), full[:V].norm()).item()
+    assert (out.float().cpu() - ref).norm().item() <= bound
+    # paired latents ([b,4,2H,W]): reference rows get zero residuals (adapter3d_mixin.py:110-116); just has to run and be finite
+    lat2 = torch.randn(2 * V, 4, 2 * S, S, generator=g).half().cuda()
+    out2 = p.get_noise_pred([lat2], [emb.cuda()], [img.cuda()], [dep.cuda()], 500, 0.6, 0.4, 4.0)
+    assert out2.shape == (V, 4, S, S) and torch.isfinite(out2).all()
