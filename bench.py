@@ -170,6 +170,20 @@ def secondary(dev):
     tb = V * 1024 * 1024 * 36
     out['bake_multiview'] = dict(texel_views_per_s=round(V * 1024 * 1024 / t / 1e9, 3), unit='G texel-views/s', ms=round(t * 1e3, 2),
                                  algorithmic_GBps=round(tb / t / 1e9, 1), frac_of_hbm_peak=round(tb / t / 8e12, 4))
+    # ---- one SD-1.5 ControlNet over the 64 images of a step (0.28 TFLOP per image incl. the 512^2 embedding) ----
+    from mvedit_amd.controlnet import ControlNetEngine
+    from mvedit_amd.unet import SD15_CONFIG
+    from oracle import unet_oracle as U                     # weights generator only
+    cn = ControlNetEngine.from_state_dict(U.make_controlnet_state_dict(dict(SD15_CONFIG), dtype=torch.float16), dict(SD15_CONFIG), torch.float16, dev)
+    Bc = 2 * VIEWS
+    xs = torch.randn(Bc, 4, LATENT, LATENT, device=dev, dtype=torch.float16)
+    cs = torch.randn(Bc, CTX_LEN, 768, device=dev, dtype=torch.float16)
+    ci = torch.rand(Bc, 3, 8 * LATENT, 8 * LATENT, device=dev, dtype=torch.float16)
+    dn, md = cn.new_outputs(Bc, LATENT, LATENT)
+    t = timed(lambda: cn.run(xs, 499, cs, ci, 1.0, dn, md, False), it=2)
+    fl = sum(cn.plan(Bc, LATENT, LATENT, CTX_LEN)['flops'][k] for k in ('conv3x3', 'linear', 'attention'))
+    out['controlnet_forward'] = dict(ms=round(t * 1e3, 2), images=Bc, tflops_per_s=round(fl / t / 1e12, 1))
+    del cn, dn, md
     # ---- DMTet on the 128^3 tet grid of the reference's mesh stage (6 tets per cube, 12.6 M tets) ----------------------------------
     from scene import tet_grid
     from mvedit_amd.mesh_ops import DMTet
