@@ -173,8 +173,8 @@ def secondary(dev):
     # ---- one SD-1.5 ControlNet over the 64 images of a step (0.28 TFLOP per image incl. the 512^2 embedding) ----
     from mvedit_amd.controlnet import ControlNetEngine
     from mvedit_amd.unet import SD15_CONFIG
-    from oracle import unet_oracle as U                     # weights generator only
-    cn = ControlNetEngine.from_state_dict(U.make_controlnet_state_dict(dict(SD15_CONFIG), dtype=torch.float16), dict(SD15_CONFIG), torch.float16, dev)
+    from mvedit_amd import synthetic as SY
+    cn = ControlNetEngine.from_state_dict(SY.make_controlnet_state_dict(dict(SD15_CONFIG), dtype=torch.float16), dict(SD15_CONFIG), torch.float16, dev)
     Bc = 2 * VIEWS
     xs = torch.randn(Bc, 4, LATENT, LATENT, device=dev, dtype=torch.float16)
     cs = torch.randn(Bc, CTX_LEN, 768, device=dev, dtype=torch.float16)
@@ -218,7 +218,7 @@ def main():
     from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG
     from mvedit_amd import ops
     from mvedit_amd.parallel import partition_views
-    from oracle import unet_oracle as U   # weights generator only (shared with the cpu_baseline leg)
+    from mvedit_amd import synthetic as U   # seeded random weights in diffusers layout (the oracle is used by cpu_baseline only)
 
     dtype = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
     cfg = dict(SD15_CONFIG)

@@ -1,0 +1,149 @@
+"""Seeded synthetic weights in diffusers' state-dict layout (names and shapes of `UNet2DConditionModel` / `ControlNetModel`,
+diffusers 0.27.2) for benchmarks and smoke runs -- no checkpoint can be downloaded offline.  Product-side utility: bench.py's
+measured path uses this module, never `oracle/` (tests/test_unet.py checks that it agrees with the oracle's own inventory)."""
+import math
+
+import torch
+
+CN_EMB = (16, 32, 96, 256)
+
+
+def _resnet_shapes(p, cin, cout, temb):
+    s = {f'{p}.norm1.weight': (cin,), f'{p}.norm1.bias': (cin,),
+         f'{p}.conv1.weight': (cout, cin, 3, 3), f'{p}.conv1.bias': (cout,),
+         f'{p}.time_emb_proj.weight': (cout, temb), f'{p}.time_emb_proj.bias': (cout,),
+         f'{p}.norm2.weight': (cout,), f'{p}.norm2.bias': (cout,),
+         f'{p}.conv2.weight': (cout, cout, 3, 3), f'{p}.conv2.bias': (cout,)}
+    if cin != cout:
+        s[f'{p}.conv_shortcut.weight'] = (cout, cin, 1, 1)
+        s[f'{p}.conv_shortcut.bias'] = (cout,)
+    return s
+
+
+def _transformer_shapes(p, c, ctx, layers, linear):
+    proj = (c, c) if linear else (c, c, 1, 1)
+    s = {f'{p}.norm.weight': (c,), f'{p}.norm.bias': (c,),
+         f'{p}.proj_in.weight': proj, f'{p}.proj_in.bias': (c,),
+         f'{p}.proj_out.weight': proj, f'{p}.proj_out.bias': (c,)}
+    for k in range(layers):
+        b = f'{p}.transformer_blocks.{k}'
+        for n in ('norm1', 'norm2', 'norm3'):
+            s[f'{b}.{n}.weight'] = (c,)
+            s[f'{b}.{n}.bias'] = (c,)
+        for a, kv in (('attn1', c), ('attn2', ctx)):
+            s[f'{b}.{a}.to_q.weight'] = (c, c)
+            s[f'{b}.{a}.to_k.weight'] = (c, kv)
+            s[f'{b}.{a}.to_v.weight'] = (c, kv)
+            s[f'{b}.{a}.to_out.0.weight'] = (c, c)
+            s[f'{b}.{a}.to_out.0.bias'] = (c,)
+        s[f'{b}.ff.net.0.proj.weight'] = (8 * c, c)
+        s[f'{b}.ff.net.0.proj.bias'] = (8 * c,)
+        s[f'{b}.ff.net.2.weight'] = (c, 4 * c)
+        s[f'{b}.ff.net.2.bias'] = (c,)
+    return s
+
+
+def param_shapes(cfg):
+    """Ordered {name: shape} of UNet2DConditionModel(**cfg).state_dict() in diffusers 0.27.2."""
+    ch = cfg['block_out_channels']
+    L = cfg['layers_per_block']
+    temb = ch[0] * 4
+    ctx = cfg['cross_attention_dim']
+    lin = cfg['use_linear_projection']
+    s = {'conv_in.weight': (ch[0], cfg['in_channels'], 3, 3), 'conv_in.bias': (ch[0],),
+         'time_embedding.linear_1.weight': (temb, ch[0]), 'time_embedding.linear_1.bias': (temb,),
+         'time_embedding.linear_2.weight': (temb, temb), 'time_embedding.linear_2.bias': (temb,)}
+    n = len(ch)
+    cin = ch[0]
+    for i, cout in enumerate(ch):
+        for j in range(L):
+            s.update(_resnet_shapes(f'down_blocks.{i}.resnets.{j}', cin if j == 0 else cout, cout, temb))
+            if cfg['down_attn'][i]:
+                s.update(_transformer_shapes(f'down_blocks.{i}.attentions.{j}', cout, ctx, cfg['transformer_layers'][i], lin))
+        if i < n - 1:
+            s[f'down_blocks.{i}.downsamplers.0.conv.weight'] = (cout, cout, 3, 3)
+            s[f'down_blocks.{i}.downsamplers.0.conv.bias'] = (cout,)
+        cin = cout
+    s.update(_resnet_shapes('mid_block.resnets.0', ch[-1], ch[-1], temb))
+    s.update(_transformer_shapes('mid_block.attentions.0', ch[-1], ctx, cfg['transformer_layers'][-1], lin))
+    s.update(_resnet_shapes('mid_block.resnets.1', ch[-1], ch[-1], temb))
+    rev = list(reversed(ch))
+    rev_attn = list(reversed(cfg['down_attn']))
+    rev_tl = list(reversed(cfg['transformer_layers']))
+    prev = rev[0]
+    for i, cout in enumerate(rev):
+        cin_blk = rev[min(i + 1, n - 1)]
+        for j in range(L + 1):
+            skip = cin_blk if j == L else cout
+            rin = prev if j == 0 else cout
+            s.update(_resnet_shapes(f'up_blocks.{i}.resnets.{j}', rin + skip, cout, temb))
+            if rev_attn[i]:
+                s.update(_transformer_shapes(f'up_blocks.{i}.attentions.{j}', cout, ctx, rev_tl[i], lin))
+        if i < n - 1:
+            s[f'up_blocks.{i}.upsamplers.0.conv.weight'] = (cout, cout, 3, 3)
+            s[f'up_blocks.{i}.upsamplers.0.conv.bias'] = (cout,)
+        prev = cout
+    s['conv_norm_out.weight'] = (ch[0],)
+    s['conv_norm_out.bias'] = (ch[0],)
+    s['conv_out.weight'] = (cfg['out_channels'], ch[0], 3, 3)
+    s['conv_out.bias'] = (cfg['out_channels'],)
+    return s
+
+
+def make_state_dict(cfg, seed=1234, dtype=torch.float32):
+    """Seeded random weights (no checkpoint is available offline).  Weights ~ U(+-sqrt(3/fan_in)) (unit
+    gain, so every branch contributes at the scale of the residual stream and wiring errors are visible),
+    biases ~ 0.1 N(0,1), norm scales 1 + 0.1 N(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in param_shapes(cfg).items():
+        if name.endswith('.bias'):
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif '.norm' in name or name.startswith('conv_norm_out'):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            fan_in = math.prod(shape[1:])
+            bound = math.sqrt(3.0 / fan_in)
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        sd[name] = t.to(dtype)
+    return sd
+
+
+def controlnet_param_shapes(cfg, cond_channels=3):
+    full = param_shapes(cfg)
+    s = {k: v for k, v in full.items() if not (k.startswith('up_blocks.') or k.startswith('conv_norm_out') or k.startswith('conv_out'))}
+    ch = cfg['block_out_channels']
+    e = 'controlnet_cond_embedding.'
+    s[e + 'conv_in.weight'] = (CN_EMB[0], cond_channels, 3, 3)
+    s[e + 'conv_in.bias'] = (CN_EMB[0],)
+    for k in range(6):
+        ci, co = CN_EMB[k // 2], CN_EMB[(k + 1) // 2]
+        s[f'{e}blocks.{k}.weight'] = (co, ci, 3, 3)
+        s[f'{e}blocks.{k}.bias'] = (co,)
+    s[e + 'conv_out.weight'] = (ch[0], CN_EMB[3], 3, 3)
+    s[e + 'conv_out.bias'] = (ch[0],)
+    outs = [ch[0]]
+    for i, c in enumerate(ch):
+        outs += [c] * cfg['layers_per_block']
+        if i < len(ch) - 1:
+            outs.append(c)
+    for k, c in enumerate(outs):
+        s[f'controlnet_down_blocks.{k}.weight'] = (c, c, 1, 1)
+        s[f'controlnet_down_blocks.{k}.bias'] = (c,)
+    s['controlnet_mid_block.weight'] = (ch[-1], ch[-1], 1, 1)
+    s['controlnet_mid_block.bias'] = (ch[-1],)
+    return s
+
+
+def make_controlnet_state_dict(cfg, seed=777, dtype=torch.float32, cond_channels=3):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in controlnet_param_shapes(cfg, cond_channels).items():
+        if name.endswith('.bias'):
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif '.norm' in name:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(3.0 / math.prod(shape[1:]))
+        sd[name] = t.to(dtype)
+    return sd

@@ -339,3 +339,16 @@ def test_engine_sd21_topology_zero123pp_tiling(lib):
     out = eng(x.to(dtype).cuda(), 400, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='r', ref_dict=d, is_cfg_guidance=True))[0]
     assert out.shape == (B, 4, 48, 32)
     _check(out, ref16, ref32)
+
+
+def test_synthetic_weights_module_matches_oracle_inventory():
+    """mvedit_amd.synthetic (what bench.py uses for weights) and the oracle's own parameter inventory must describe the same
+    state dict, name for name and value for value."""
+    from mvedit_amd import synthetic as S
+    for cfg in (U.SD15, U.SD21, U.TINY):
+        assert list(S.param_shapes(cfg).items()) == list(U.param_shapes(cfg).items())
+        assert S.controlnet_param_shapes(cfg) == U.controlnet_param_shapes(cfg)
+    a, b = S.make_state_dict(U.TINY, seed=3), U.make_state_dict(U.TINY, seed=3)
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    a, b = S.make_controlnet_state_dict(U.TINY, seed=4), U.make_controlnet_state_dict(U.TINY, seed=4)
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
