@@ -241,7 +241,11 @@ def main():
     t = torch.full((B,), 499.0, device=dev)
     info = eng.plan(B, LATENT, LATENT, CTX_LEN, 1, False, dtype)
     optab = eng.op_table()
-    gathered = torch.empty(V, 4, LATENT, LATENT, device=dev, dtype=torch.float32) if use_dist else None
+    # The one collective of a pipeline step (BASELINE north_star): every rank contributes the rendered / decoded
+    # RGB + alpha + depth + normal maps of ITS views (8 channels x 512^2 fp16 = 4 MiB per view) and receives all V of them before
+    # the replicated 3D update.  Synthetic payload of exactly that size; the per-view noise prediction itself stays local.
+    maps_local = torch.zeros(v_loc, 8, 8 * LATENT, 8 * LATENT, device=dev, dtype=torch.float16) if use_dist else None
+    gathered = torch.empty(V, 8, 8 * LATENT, 8 * LATENT, device=dev, dtype=torch.float16) if use_dist else None
 
     def step(profile):
         if profile:
@@ -251,7 +255,7 @@ def main():
         un, tx = out[:v_loc].float(), out[v_loc:].float()
         noise = ops.cfg_combine(un, tx, GUIDANCE)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, noise.contiguous())
+            dist.all_gather_into_tensor(gathered, maps_local)
         return noise, ms
 
     for _ in range(args.warmup):
@@ -312,7 +316,7 @@ def main():
             'data': 'synthetic (seeded random SD-1.5-topology weights and latents)',
             'config': {'workload': f'{V}-view 512x512 get_noise_pred: {2 * V} SD-1.5 UNet forwards (64x64 latents, ctx 77x768) + CFG per step; '
                                    'ControlNet residuals zero', 'views': V, 'latent': LATENT, 'cfg': True,
-                       'parallelism': f'views/{world}' + (' + all_gather(noise_pred)' if world > 1 else '')},
+                       'parallelism': f'views/{world}' + (' + all_gather(RGBD/normal maps, 4 MiB per view)' if world > 1 else '')},
             'model_tflops_per_s': round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
             'model_flops_frac_of_peak': round(total_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_TFLOPS_F16 * world), 4),
             'roofline': roof,

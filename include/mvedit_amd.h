@@ -291,7 +291,8 @@ MVE_API int mve_controlnet_create(void** handle, int dtype, int in_channels, int
                                   int use_linear_projection);
 MVE_API int mve_controlnet_forward(void* handle, const void* d_sample, int io_dtype, const float* d_timesteps, const void* d_ctx,
                                    const void* d_cond, int B, int H, int W, int ctx_len, float conditioning_scale, int accumulate,
-                                   void* const* d_outputs, void* d_workspace, size_t workspace_bytes, void* stream);
+                                   void* const* d_outputs, void* d_workspace, size_t workspace_bytes,
+                                   float* op_ms /* optional host array [n_ops]: per-op milliseconds (synchronises) */, void* stream);
 
 /* Attention-processor options of the reference, applied to every later plan/forward of this engine:
  *   ip_tokens > 0 : IPAttnProcessor2_0 (lib/models/architecture/ip_adapter/attention_processor.py:301-396) -- the last ip_tokens rows of

@@ -57,7 +57,7 @@ class ControlNetEngine(UNet2DConditionEngine):
         mk = lambda s: torch.empty(B, s[1], s[2], s[0], dtype=self.dtype, device=self.device).permute(0, 3, 1, 2)
         return [mk(s) for s in shapes], mk(mid)
 
-    def run(self, sample, timestep, encoder_hidden_states, cond, scale, down, mid, accumulate):
+    def run(self, sample, timestep, encoder_hidden_states, cond, scale, down, mid, accumulate, profile=False):
         B, _, H, W = sample.shape
         io = encoder_hidden_states.dtype
         ctx = encoder_hidden_states.to(self.device).contiguous()
@@ -71,8 +71,12 @@ class ControlNetEngine(UNet2DConditionEngine):
         outs = list(down) + [mid]
         ptrs = (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
         with torch.cuda.device(self.device):
+            op_ms = (ctypes.c_float * info['n_ops'])() if profile else None
             _lib.call('mve_controlnet_forward', self._h, _lib.ptr(sample), _dt(io), _lib.ptr(t), _lib.ptr(ctx), _lib.ptr(cond), B, H, W,
-                      ctx.shape[1], float(scale), int(bool(accumulate)), ptrs, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self.device))
+                      ctx.shape[1], float(scale), int(bool(accumulate)), ptrs, _lib.ptr(ws), ws.numel(), op_ms,
+                      _lib.stream_ptr(self.device))
+        if profile:
+            return [(c, lab, fl, m) for (ph, c, fl, lab), m in zip(self.op_table(), list(op_ms))]
 
     def __call__(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, guess_mode=False,
                  added_cond_kwargs=None, return_dict=False, **unused):

@@ -1157,7 +1157,7 @@ int mve_controlnet_create(void** handle, int dtype, int in_channels, int conditi
 
 int mve_controlnet_forward(void* handle, const void* d_sample, int io_dtype, const float* d_timesteps, const void* d_ctx, const void* d_cond,
                            int B, int H, int W, int ctx_len, float conditioning_scale, int accumulate, void* const* d_outputs,
-                           void* d_workspace, size_t workspace_bytes, void* stream) {
+                           void* d_workspace, size_t workspace_bytes, float* op_ms, void* stream) {
     MVE_CHECK(handle, MVE_ERR_ARG, "controlnet_forward: null handle");
     Unet* u = (Unet*)handle;
     MVE_CHECK(u->cfg.controlnet, MVE_ERR_ARG, "controlnet_forward: handle is a UNet, not a ControlNet");
@@ -1180,9 +1180,21 @@ int mve_controlnet_forward(void* handle, const void* d_sample, int io_dtype, con
     r.down_res = nullptr; r.mid_res = nullptr; r.ref_store = nullptr;
     r.cn_cond = d_cond; r.cn_out = d_outputs; r.cn_scale = conditioning_scale; r.cn_accum = accumulate ? 1 : 0;
     r.stream = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev;
+    if (op_ms) {
+        ev.resize(pl.ops.size() + 1);
+        for (auto& e : ev) MVE_HIP(hipEventCreate(&e));
+        MVE_HIP(hipEventRecord(ev[0], r.stream));
+    }
     for (size_t i = 0; i < pl.ops.size(); ++i) {
         rc = pl.ops[i].fn(r);
         if (rc) return rc;
+        if (op_ms) MVE_HIP(hipEventRecord(ev[i + 1], r.stream));
+    }
+    if (op_ms) {
+        MVE_HIP(hipStreamSynchronize(r.stream));
+        for (size_t i = 0; i < pl.ops.size(); ++i) MVE_HIP(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return MVE_OK;
 }

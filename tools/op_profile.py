@@ -8,13 +8,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mvedit_amd.unet import SD15_CONFIG, UNet2DConditionEngine  # noqa: E402
-from oracle import unet_oracle as U  # noqa: E402
+from mvedit_amd import synthetic as U  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 eng = UNet2DConditionEngine(SD15_CONFIG, torch.float16)
 g = torch.Generator().manual_seed(0)
 sd = {}
-for name, shape in U.param_shapes(U.SD15).items():
+for name, shape in U.param_shapes(SD15_CONFIG).items():
     sd[name] = torch.randn(shape, generator=g, dtype=torch.float16) * 0.02
 eng.load_state_dict(sd)
 x = torch.randn(B, 4, 64, 64, device='cuda', dtype=torch.float16)
