@@ -39,9 +39,7 @@ namespace {
 
 constexpr int BM = 128;
 
-// defined in gemm_rs.hip (variant 2: role-split 256-row tiles)
 }  // namespace
-int mve_gemm_rs_launch(int dtype, int mode, const void* params, void* stream);
 // defined in gemm_big.hip (256 x 320 tiles, bit-identical results)
 long long mve_gemm_big_blocks(int M, int N, int splitk);
 int mve_gemm_big_launch(int dtype, int mode, const void* params, void* stream);
@@ -339,7 +337,7 @@ int gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MVE_GEMM_VARIANT");
-        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+        v = (e && e[0] == '0') ? 0 : 1;
     }
     return v;
 }
@@ -378,7 +376,6 @@ int gemm_big_min_blocks() {
 template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int v = gemm_variant();
-    if (v == 2 && p.splitk <= 1 && p.M >= 256 && p.N >= 64) return mve_gemm_rs_launch(Tag::dtype, MODE, &p, s);
     // enough 256 x 320 tiles to fill the chip WITHOUT cutting K: one block per tile walks the slices one after the other and
     // reproduces the split-K rounding exactly (GemmParams::splitk_seq) -- no partial tiles, no reducer launch
     if (v == 1 && gemm_big_min_blocks() > 0 && p.splitk > 1 && g_seq_splitk && mve_gemm_big_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&

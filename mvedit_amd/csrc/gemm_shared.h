@@ -1,5 +1,4 @@
-// Definitions shared by the GEMM / implicit-GEMM conv kernels (gemm.hip: 128-row tiles; gemm_rs.hip: role-split
-// 256-row tiles).  Everything is in an anonymous namespace: each translation unit gets its own copy.
+// Definitions shared by the GEMM / implicit-GEMM conv kernels (gemm.hip: 128 x 160 tiles; gemm_big.hip: 256 x 320 tiles).  Everything is in an anonymous namespace: each translation unit gets its own copy.
 #pragma once
 #include "common.h"
 
