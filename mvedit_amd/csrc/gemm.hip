@@ -24,8 +24,8 @@
 //   16-byte zero page; tile k+1 is in flight while tile k feeds the MFMAs, one barrier per K tile;
 //   blockIdx -> tile uses the XCD-aware bijective remap so that tiles sharing an activation row panel
 //   run on one XCD (one L2).
-// A register-staged variant (global -> VGPR -> ds_write) is kept as variant 0
-// (MVE_GEMM_VARIANT=0) for A/B measurements.
+// (A register-staged variant -- global -> VGPR -> ds_write -- measured 4 % slower end to end, profiles/r01_bench_v0.log vs
+// r01_bench_v1_dma.log, and was removed.)
 //
 // Replaces (behaviourally) the cuDNN/cuBLAS calls behind diffusers' ResnetBlock2D / Attention /
 // FeedForward as driven by lib/models/architecture/diffusers.py:57-164 of the reference.
@@ -45,7 +45,7 @@ long long mve_gemm_big_blocks(int M, int N, int splitk);
 int mve_gemm_big_launch(int dtype, int mode, const void* params, void* stream);
 namespace {
 
-template <class Tag, int BN, int MODE, int VARIANT>   // MODE 0: dense A, 1: conv3x3 gather; VARIANT 0: register staged, 1: LDS-DMA
+template <class Tag, int BN, int MODE>   // MODE 0: dense A, 1: conv3x3 gather
 __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     constexpr int WN = BN / 2;          // wave sub-tile width
     constexpr int NF = WN / 16;         // W fragments per wave (4 / 5 / 2)
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     constexpr int A_STAGE = BM * ROW_BYTES;             // 16 KB
     constexpr int B_STAGE = BN * ROW_BYTES;
     constexpr int STAGE = A_STAGE + B_STAGE;
-    constexpr int CS_LD = BN + 4;                       // fp32 staging row stride (floats), variant 0 only
+    constexpr int CS_LD = BN + 4;                       // fp32 epilogue staging row stride (floats)
     constexpr int SMEM0 = (2 * STAGE > 64 * CS_LD * 4) ? 2 * STAGE : 64 * CS_LD * 4;
     constexpr int SMEM = SMEM0;
     typedef typename Tag::V8 V8;
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
 
     // ---- per-thread load coordinates ------------------------------------------------------
     const int lr = tid >> 3;           // row within a 32-row pass
-    // variant 1 writes LDS lane-linearly, so the lane at physical chunk (tid&7) must FETCH the logical chunk that the
+    // the LDS-DMA writes LDS lane-linearly, so the lane at physical chunk (tid&7) must FETCH the logical chunk that the
     // swizzle maps there; (row>>1)&7 == (lr>>1)&7 for every pass because passes advance by 32 rows.
-    const int lc = VARIANT == 0 ? (tid & 7) : ((tid & 7) ^ ((lr >> 1) & 7));
+    const int lc = (tid & 7) ^ ((lr >> 1) & 7);
     const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W);
 
     const T* a_row[A_PASSES];
@@ -148,35 +148,12 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     };
 
     // ---- staging ---------------------------------------------------------------------------------
-    u32x4 a_reg[A_PASSES], b_reg[B_PASSES];   // variant 0 only
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    auto load_tile = [&](int kt) {             // variant 0: global -> registers
-        const bool kin = kt * BK + lc * 8 < p.K;
-#pragma unroll
-        for (int j = 0; j < A_PASSES; ++j) {
-            const T* s = a_src(kt, j, kin);
-            a_reg[j] = s ? *reinterpret_cast<const u32x4*>(s) : zero4;
-        }
-#pragma unroll
-        for (int j = 0; j < B_PASSES; ++j)
-            b_reg[j] = kin ? *reinterpret_cast<const u32x4*>(w_row[j] + kt * BK + lc * 8) : zero4;
-        advance();
-    };
-    auto store_tile = [&](int stage) {         // variant 0: registers -> LDS
-        unsigned char* As = smem + stage * STAGE;
-        unsigned char* Bs = As + A_STAGE;
-#pragma unroll
-        for (int j = 0; j < A_PASSES; ++j) *reinterpret_cast<u32x4*>(As + swz(lr + j * ROWS_PER_PASS, lc)) = a_reg[j];
-#pragma unroll
-        for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<u32x4*>(Bs + swz(lr + j * ROWS_PER_PASS, lc)) = b_reg[j];
-    };
     // fast conv addressing for the slab-major K order without upsample (see gemm_big.hip): uniform tap / slab arithmetic,
     // one multiply-add per row, the halo test is a bit of a per-row mask computed once
-    const bool fast = MODE == 1 && VARIANT == 1 && p.g.chunk64 && !p.g.ups;
+    const bool fast = MODE == 1 && p.g.chunk64 && !p.g.ups;
     int pix[A_PASSES];
     unsigned vmask[A_PASSES];
-    if constexpr (MODE == 1 && VARIANT == 1) {
+    if constexpr (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
             pix[j] = (cb[j] * p.g.Hs + cy[j]) * p.g.Ws + cx[j];
@@ -189,11 +166,11 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
             vmask[j] = mk;
         }
     }
-    auto dma_tile = [&](int kt, int stage) {   // variant 1: global -> LDS directly, 1 KiB per wave instruction
+    auto dma_tile = [&](int kt, int stage) {   // global -> LDS directly, 1 KiB per wave instruction
         const bool kin = kt * BK + lc * 8 < p.K;
         unsigned char* As = smem + stage * STAGE;
         unsigned char* Bs = As + A_STAGE;
-        if (MODE == 1 && VARIANT == 1 && fast) {
+        if (MODE == 1 && fast) {
             const int t_ = kt % 9, c0 = (kt / 9) * 64;                 // uniform
             const bool second = c0 >= p.g.C1;
             const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
@@ -228,16 +205,14 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (VARIANT == 0) { load_tile(kt_begin); store_tile(0); }
-    else dma_tile(kt_begin, 0);
+    dma_tile(kt_begin, 0);
     __syncthreads();
 
     const int frow = lane & 15, fchunk = lane >> 4;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         if (kt + 1 < kt_end) {
-            if constexpr (VARIANT == 0) load_tile(kt + 1);
-            else dma_tile(kt + 1, cur ^ 1);
+            dma_tile(kt + 1, cur ^ 1);
         }
         const unsigned char* As = smem + cur * STAGE;
         const unsigned char* Bs = As + A_STAGE;
@@ -255,10 +230,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf[j], xf[i], acc[j][i]);
         }
-        if constexpr (VARIANT == 0) {
-            if (kt + 1 < kt_end) store_tile(cur ^ 1);
-        }
-        __syncthreads();   // variant 1: the compiler drains the in-flight LDS-DMA (vmcnt(0)) ahead of this barrier
+        __syncthreads();   // the compiler drains the in-flight LDS-DMA (vmcnt(0)) ahead of this barrier
     }
 
     {
@@ -333,16 +305,7 @@ int choose_splitk(int rows_per_image, int N, int K) {
     return s < 2 ? 1 : (int)s;
 }
 
-int gemm_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MVE_GEMM_VARIANT");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
-}
-
-template <class Tag, int MODE, int VARIANT>
+template <class Tag, int MODE>
 int launch_v(const GemmParams& p, hipStream_t s) {
     // tile width: prefer the widest tile that divides N (no dead columns), else 128
     int bn = 128;
@@ -351,9 +314,9 @@ int launch_v(const GemmParams& p, hipStream_t s) {
     else if (p.N <= 64) bn = 64;
     const unsigned tiles_m = mve_cdiv(p.M, BM), tiles_n = mve_cdiv(p.N, bn);
     const unsigned grid = tiles_m * tiles_n * (p.splitk > 1 ? p.splitk : 1);
-    if (bn == 160) k_gemm<Tag, 160, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
-    else if (bn == 128) k_gemm<Tag, 128, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
-    else k_gemm<Tag, 64, MODE, VARIANT><<<grid, NT, 0, s>>>(p);
+    if (bn == 160) k_gemm<Tag, 160, MODE><<<grid, NT, 0, s>>>(p);
+    else if (bn == 128) k_gemm<Tag, 128, MODE><<<grid, NT, 0, s>>>(p);
+    else k_gemm<Tag, 64, MODE><<<grid, NT, 0, s>>>(p);
     MVE_LAUNCH_CHECK();
     if (p.splitk > 1) {
         k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
@@ -375,17 +338,16 @@ int gemm_big_min_blocks() {
 
 template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
-    const int v = gemm_variant();
     // enough 256 x 320 tiles to fill the chip WITHOUT cutting K: one block per tile walks the slices one after the other and
     // reproduces the split-K rounding exactly (GemmParams::splitk_seq) -- no partial tiles, no reducer launch
-    if (v == 1 && gemm_big_min_blocks() > 0 && p.splitk > 1 && g_seq_splitk && mve_gemm_big_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&
+    if (gemm_big_min_blocks() > 0 && p.splitk > 1 && g_seq_splitk && mve_gemm_big_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&
         (size_t)mve_gemm_big_blocks(p.M, p.N, 1) * 256 * 320 <= (size_t)p.splitk * p.M * p.N) {
         GemmParams q = p;
         q.splitk_seq = p.splitk;
         q.splitk = 1;
         return mve_gemm_big_launch(Tag::dtype, MODE, &q, s);
     }
-    if (v == 1 && gemm_big_min_blocks() > 0 && mve_gemm_big_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
+    if (gemm_big_min_blocks() > 0 && mve_gemm_big_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
         GemmParams q = p;
         const int rc = mve_gemm_big_launch(Tag::dtype, MODE, &q, s);
         if (rc) return rc;
@@ -395,7 +357,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         }
         return MVE_OK;
     }
-    return v == 0 ? launch_v<Tag, MODE, 0>(p, s) : launch_v<Tag, MODE, 1>(p, s);
+    return launch_v<Tag, MODE>(p, s);
 }
 
 int check_common(const GemmParams& p, const char* who) {
