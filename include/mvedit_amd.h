@@ -198,6 +198,16 @@ MVE_API int mve_conv3x3(int dtype, const void* d_x1, int C1, const void* d_x2, i
                         const float* d_bias, const float* d_rowvec, int ldrv, const void* d_residual, int ldr,
                         int flags, float out_scale, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ResnetBlock2D tail in one launch: out = conv3x3(x1; W[:, :9*C1]) + conv1x1([x3 | x4]; W[:, 9*C1:]) + bias + bias2 (+ residual).
+ * The 1x1 `conv_shortcut` of a resnet whose input and output widths differ (diffusers ResnetBlock2D, reached through
+ * lib/models/architecture/diffusers.py:86-97, :139-156) is appended to the K loop of conv2: W is [Cout][9*C1 + C3 + C4] with the 3x3
+ * part in MVE_CONV_W_CHUNK64 order followed by the shortcut matrix; x3 / x4 are the (optionally concatenated) block inputs, NHWC
+ * at the output resolution.  C1, C3, C4 multiples of 64.  Split-K sizing: mve_gemm_workspace_bytes(M, Cout, 9*C1 + C3 + C4, H*W). */
+MVE_API int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* x3, int C3, const void* x4, int C4, int B, int Hs,
+                                 int Ws, const void* W, int Cout, void* out, int ldc, const float* bias, const float* bias2,
+                                 const void* residual, int ldr, int flags, float out_scale, void* d_workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* Scaled-dot-product attention over packed projections (no head permutes):
  *   Q row (b,i) at d_Q + (b*Lq+i)*ldq, head h at column h*head_dim; same for K/V with Lk, O with Lq.
  *   Optional second KV segment (K2,V2,Lk2) is logically concatenated after the first along the key
@@ -293,6 +303,10 @@ MVE_API int mve_controlnet_forward(void* handle, const void* d_sample, int io_dt
                                    const void* d_cond, int B, int H, int W, int ctx_len, float conditioning_scale, int accumulate,
                                    void* const* d_outputs, void* d_workspace, size_t workspace_bytes,
                                    float* op_ms /* optional host array [n_ops]: per-op milliseconds (synchronises) */, void* stream);
+
+/* Tuning knob for engines created AFTER the call: 1 (default) folds every ResnetBlock2D conv_shortcut into conv2's K loop
+ * (mve_conv3x3_shortcut), 0 keeps the separate 1x1 GEMMs; negative only queries.  Returns the previous setting. */
+MVE_API int mve_unet_tune(int fuse_shortcut);
 
 /* Attention-processor options of the reference, applied to every later plan/forward of this engine:
  *   ip_tokens > 0 : IPAttnProcessor2_0 (lib/models/architecture/ip_adapter/attention_processor.py:301-396) -- the last ip_tokens rows of

@@ -171,11 +171,19 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
         unsigned char* As = smem + stage * STAGE;
         unsigned char* Bs = As + A_STAGE;
         if (MODE == 1 && fast) {
-            const int t_ = kt % 9, c0 = (kt / 9) * 64;                 // uniform
-            const bool second = c0 >= p.g.C1;
+            int t_ = kt % 9, c0 = (kt / 9) * 64;                       // uniform
+            bool second = c0 >= p.g.C1;
             const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
-            const int cs = second ? p.g.C2 : p.g.C1;
-            const int ch = (second ? c0 - p.g.C1 : c0) + lc * 8;
+            int cs = second ? p.g.C2 : p.g.C1;
+            int ch = (second ? c0 - p.g.C1 : c0) + lc * 8;
+            if (p.g.nk_main > 0 && kt >= p.g.nk_main) {                // 1x1 shortcut part: centre tap of the shortcut sources
+                t_ = 4;
+                c0 = (kt - p.g.nk_main) * 64;
+                second = c0 >= p.g.C3;
+                src = reinterpret_cast<const T*>(second ? p.A4 : p.A3);
+                cs = second ? p.g.C4 : p.g.C3;
+                ch = (second ? c0 - p.g.C3 : c0) + lc * 8;
+            }
             const int dy = t_ / 3;
             const int toff = dy * p.g.Ws + (t_ - dy * 3);
 #pragma unroll
@@ -366,8 +374,8 @@ int check_common(const GemmParams& p, const char* who) {
     MVE_CHECK(p.W && p.out, MVE_ERR_ARG, "%s: null pointer", who);
     MVE_CHECK(p.ldc % 4 == 0, MVE_ERR_ARG, "%s: ldc must be a multiple of 4", who);
     MVE_CHECK(!p.residual || p.ldr % 8 == 0, MVE_ERR_ARG, "%s: ldr must be a multiple of 8", who);
-    MVE_CHECK(!p.rowvec || (p.rows_per_vec > 0 && p.ldrv % 4 == 0 && p.ldrv >= p.N), MVE_ERR_ARG,
-              "%s: rowvec needs rows_per_vec > 0 and ldrv (%d) a multiple of 4 >= N", who, p.ldrv);
+    MVE_CHECK(!p.rowvec || (p.rows_per_vec > 0 && p.ldrv % 4 == 0 && (p.ldrv >= p.N || p.ldrv == 0)), MVE_ERR_ARG,
+              "%s: rowvec needs rows_per_vec > 0 and ldrv (%d) a multiple of 4 >= N (or 0: one vector for all rows)", who, p.ldrv);
     MVE_CHECK(p.ldw % 8 == 0 && p.ldw >= p.K, MVE_ERR_ARG, "%s: ldw (%d) must be a multiple of 8 and >= K", who, p.ldw);
     MVE_CHECK(!(p.geglu && (p.residual || p.out_f32)), MVE_ERR_ARG, "%s: geglu excludes residual/out_f32", who);
     return MVE_OK;
@@ -419,10 +427,10 @@ int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* ou
     return MVE_ERR_ARG;
 }
 
-int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int Hs, int Ws, int stride,
-                int upsample, const void* W, int Cout, void* out, int ldc, const float* bias, const float* rowvec,
-                int ldrv, const void* residual, int ldr, int flags, float out_scale, void* workspace, size_t workspace_bytes,
-                void* stream) {
+static int conv3x3_impl(int dtype, const void* x1, int C1, const void* x2, int C2, const void* x3, int C3, const void* x4, int C4, int B,
+                        int Hs, int Ws, int stride, int upsample, const void* W, int Cout, void* out, int ldc, const float* bias,
+                        const float* rowvec, int ldrv, const void* residual, int ldr, int flags, float out_scale, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     MVE_CHECK(stride == 1 || stride == 2, MVE_ERR_ARG, "conv3x3: stride must be 1 or 2");
@@ -443,6 +451,14 @@ int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B
               "conv3x3: MVE_CONV_W_CHUNK64 needs channel counts that are multiples of 64 (C1=%d C2=%d)", C1, C2);
     p.A = x1; p.A2 = x2; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
     p.M = B * p.g.Ho * p.g.Wo; p.N = Cout; p.K = 9 * (C1 + C2);
+    if (C3 > 0) {     // fused 1x1 shortcut: K continues over the channels of x3 (and x4)
+        MVE_CHECK(p.g.chunk64 && !upsample && stride == 1 && C3 % 64 == 0 && C4 >= 0 && C4 % 64 == 0 && x3 && (C4 == 0 || x4), MVE_ERR_ARG,
+                  "conv3x3_shortcut: needs MVE_CONV_W_CHUNK64, stride 1, no upsample and shortcut channel counts that are multiples of 64");
+        p.g.nk_main = p.K / BK;
+        p.g.C3 = C3; p.g.C4 = C4;
+        p.A3 = x3; p.A4 = x4;
+        p.K += C3 + C4;
+    }
     p.ldc = ldc; p.ldr = ldr; p.ldrv = ldrv; p.ldw = p.K;
     p.rows_per_vec = p.g.Ho * p.g.Wo;
     p.geglu = 0;
@@ -460,6 +476,23 @@ int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B
     if (dtype == MVE_BF16) return launch_gemm<BF16Tag, 1>(p, (hipStream_t)stream);
     mve_set_error("conv3x3: unsupported dtype %d", dtype);
     return MVE_ERR_ARG;
+}
+
+int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int Hs, int Ws, int stride,
+                int upsample, const void* W, int Cout, void* out, int ldc, const float* bias, const float* rowvec,
+                int ldrv, const void* residual, int ldr, int flags, float out_scale, void* workspace, size_t workspace_bytes,
+                void* stream) {
+    return conv3x3_impl(dtype, x1, C1, x2, C2, nullptr, 0, nullptr, 0, B, Hs, Ws, stride, upsample, W, Cout, out, ldc, bias, rowvec, ldrv,
+                        residual, ldr, flags, out_scale, workspace, workspace_bytes, stream);
+}
+
+int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* x3, int C3, const void* x4, int C4, int B, int Hs, int Ws,
+                         const void* W, int Cout, void* out, int ldc, const float* bias, const float* bias2, const void* residual, int ldr,
+                         int flags, float out_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    MVE_CHECK(C3 > 0, MVE_ERR_ARG, "conv3x3_shortcut: no shortcut source");
+    // bias2 (the shortcut's bias) rides in the per-image row-vector slot with a zero stride: every row adds the same vector
+    return conv3x3_impl(dtype, x1, C1, nullptr, 0, x3, C3, x4, C4, B, Hs, Ws, 1, 0, W, Cout, out, ldc, bias, bias2, 0, residual, ldr,
+                        flags | MVE_CONV_W_CHUNK64, out_scale, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

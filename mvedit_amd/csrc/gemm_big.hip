@@ -113,11 +113,19 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
         unsigned char* As = smem + stage * STAGE;
         unsigned char* Bs = As + A_STAGE;
         if constexpr (MODE == 1 && FAST) {
-            const int t_ = kt % 9, c0 = (kt / 9) * 64;                 // uniform
-            const bool second = c0 >= p.g.C1;
+            int t_ = kt % 9, c0 = (kt / 9) * 64;                       // uniform
+            bool second = c0 >= p.g.C1;
             const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
-            const int cs = second ? p.g.C2 : p.g.C1;
-            const int ch = (second ? c0 - p.g.C1 : c0) + lc * 8;
+            int cs = second ? p.g.C2 : p.g.C1;
+            int ch = (second ? c0 - p.g.C1 : c0) + lc * 8;
+            if (p.g.nk_main > 0 && kt >= p.g.nk_main) {                // 1x1 shortcut part: centre tap of the shortcut sources
+                t_ = 4;
+                c0 = (kt - p.g.nk_main) * 64;
+                second = c0 >= p.g.C3;
+                src = reinterpret_cast<const T*>(second ? p.A4 : p.A3);
+                cs = second ? p.g.C4 : p.g.C3;
+                ch = (second ? c0 - p.g.C3 : c0) + lc * 8;
+            }
             const int dy = t_ / 3;
             const int toff = dy * p.g.Ws + (t_ - dy * 3);
 #pragma unroll

@@ -20,11 +20,16 @@ struct ConvGeom {
     int stride;        // 1 or 2
     int ups;           // 0 or 1 (nearest 2x)
     int chunk64;       // 1: K order is (channel slab of 64, tap, channel in slab)
+    // fused 1x1 shortcut (ResnetBlock2D conv2 + conv_shortcut in ONE K loop): after the nk_main tiles of the 3x3 part, K continues
+    // over the channels of up to two more NHWC tensors sampled at the output pixel (centre tap); 0 = no shortcut part
+    int nk_main, C3, C4;
 };
 
 struct GemmParams {
     const void* A;     // dense A [M][lda]  or conv source 1 (NHWC)
     const void* A2;    // conv source 2 (concat) or null
+    const void* A3;    // shortcut source 1 (see ConvGeom::nk_main) or null
+    const void* A4;    // shortcut source 2 or null
     const void* W;     // [N][K]
     void* out;         // [M][ldc] (or [M][ldc] with N/2 valid columns for GEGLU)
     const float* bias;       // [N] or null

@@ -244,6 +244,8 @@ struct Unet {
     unsigned char* ref_store = nullptr;
     size_t ref_store_bytes = 0;
     int n_ip_loaded = 0, n_xf_layers = 0;
+    bool fuse_sc = false;                       // conv_shortcut folded into conv2's K loop (all widths multiples of 64)
+    std::map<std::string, int> sc_cin;          // resnet prefix -> input width, for resnets with a shortcut
     std::string err;
 };
 
@@ -295,6 +297,8 @@ struct SlabBuilder {
     }
 };
 
+int g_fuse_shortcut = 1;     // engines created afterwards fold conv_shortcut into conv2 (mve_unet_tune; A/B measurements)
+
 void layout_params(Unet& u) {
     const Config& c = u.cfg;
     SlabBuilder sb{u};
@@ -302,6 +306,8 @@ void layout_params(Unet& u) {
     std::vector<ResnetDesc> rs;
     std::vector<XfDesc> xs;
     enumerate(c, rs, xs);
+    u.fuse_sc = g_fuse_shortcut != 0;
+    for (int i = 0; i < c.n_levels; ++i) u.fuse_sc = u.fuse_sc && (c.ch[i] % 64 == 0);
     auto need = [&](const std::string& n) { u.expected.push_back(n); };
     sb.add("conv_in.w", (size_t)c.ch[0] * 9 * 8, false); need("conv_in.weight");
     sb.add("conv_in.b", c.ch[0], true); need("conv_in.bias");
@@ -321,10 +327,13 @@ void layout_params(Unet& u) {
         need(r.name + ".time_emb_proj.weight"); need(r.name + ".time_emb_proj.bias");
         sb.add(r.name + ".norm2.g", r.cout, true); need(r.name + ".norm2.weight");
         sb.add(r.name + ".norm2.b", r.cout, true); need(r.name + ".norm2.bias");
-        sb.add(r.name + ".conv2.w", (size_t)r.cout * 9 * r.cout, false); need(r.name + ".conv2.weight");
+        const bool sc = r.cin != r.cout;
+        sb.add(r.name + ".conv2.w", (size_t)r.cout * (9 * r.cout + (sc && u.fuse_sc ? r.cin : 0)), false); need(r.name + ".conv2.weight");
         sb.add(r.name + ".conv2.b", r.cout, true); need(r.name + ".conv2.bias");
-        if (r.cin != r.cout) {
-            sb.add(r.name + ".sc.w", (size_t)r.cout * r.cin, false); need(r.name + ".conv_shortcut.weight");
+        if (sc) {
+            u.sc_cin[r.name] = r.cin;
+            if (!u.fuse_sc) sb.add(r.name + ".sc.w", (size_t)r.cout * r.cin, false);
+            need(r.name + ".conv_shortcut.weight");
             sb.add(r.name + ".sc.b", r.cout, true); need(r.name + ".conv_shortcut.bias");
         }
     }
@@ -443,13 +452,14 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         d = PackDims{{1, 1, N, K}, {0, 0, K, 1}, {0, 0, dst_row_stride, 1}, K};
         return pack(src_dtype, c.dtype, src, dstp(p, elem_off), d, s);
     };
+    long long conv_row = 0;    // destination row length of the conv packer when the row also holds a fused shortcut (0: 9 * I)
     auto conv = [&](Param* p, long long O, long long I, long long Opad, long long Ipad) -> int {   // OIHW -> [O][3][3][Ipad]
         MVE_CHECK(p, MVE_ERR_ARG, "load_param: no slot for %s", name.c_str());
         MVE_CHECK(ndim == 4 && shape[0] == O && shape[1] == I && shape[2] == 3 && shape[3] == 3, MVE_ERR_ARG,
                   "load_param(%s): expected [%lld,%lld,3,3]", name.c_str(), O, I);
         (void)Opad;
         if (I % 64 == 0 && Ipad == I)   // channel-slab-major K order [O][I/64][9][64] (MVE_CONV_W_CHUNK64)
-            d = PackDims{{O, I / 64, 9, 64}, {I * 9, 64 * 9, 1, 9}, {9 * I, 9 * 64, 64, 1}, 64};
+            d = PackDims{{O, I / 64, 9, 64}, {I * 9, 64 * 9, 1, 9}, {conv_row ? conv_row : 9 * I, 9 * 64, 64, 1}, 64};
         else
             d = PackDims{{O, 3, 3, Ipad}, {I * 9, 3, 1, 9}, {9 * Ipad, 3 * Ipad, Ipad, 1}, I};
         return pack(src_dtype, c.dtype, src, dstp(p, 0), d, s);
@@ -495,6 +505,11 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         rc = mat(p, 0, shape[0], shape[1], shape[1]);
     } else if ((name.compare(0, 23, "controlnet_down_blocks.") == 0 || name.compare(0, 21, "controlnet_mid_block.") == 0) && ends_with(name, ".bias")) {
         rc = vec(P(strip(name, ".bias") + ".b"), 0, shape[0], 1);
+    } else if (ends_with(name, ".conv_shortcut.weight") && u.fuse_sc) {
+        const std::string r = strip(name, ".conv_shortcut.weight");
+        MVE_CHECK(u.sc_cin.count(r) && ndim >= 2 && shape[1] == u.sc_cin[r], MVE_ERR_ARG, "load_param: unexpected shortcut %s", name.c_str());
+        const long long cout = shape[0], cin = shape[1];
+        rc = mat(P(r + ".conv2.w"), (size_t)9 * cout, cout, cin, 9 * cout + cin);      // tail columns of every conv2 row
     } else if (ends_with(name, ".conv_shortcut.weight")) {
         Param* p = P(strip(name, ".conv_shortcut.weight") + ".sc.w");
         MVE_CHECK(p && ndim >= 2, MVE_ERR_ARG, "load_param: no slot for %s", name.c_str());
@@ -503,6 +518,10 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
     else if (ends_with(name, ".conv1.weight") || ends_with(name, ".conv2.weight") || ends_with(name, ".conv.weight")) {
         const std::string base = strip(name, ".weight");
         MVE_CHECK(ndim == 4, MVE_ERR_ARG, "load_param(%s): expected a 4-D conv weight", name.c_str());
+        if (u.fuse_sc && ends_with(name, ".conv2.weight")) {
+            const std::string r = strip(name, ".conv2.weight");
+            if (u.sc_cin.count(r)) conv_row = 9 * shape[1] + u.sc_cin[r];
+        }
         rc = conv(P(base + ".w"), shape[0], shape[1], shape[0], shape[1]);
     } else if (ends_with(name, ".conv1.bias") || ends_with(name, ".conv2.bias") || ends_with(name, ".conv.bias"))
         rc = vec(P(strip(name, ".bias") + ".b"), 0, shape[0], 1);
@@ -698,6 +717,22 @@ struct Builder {
         Ref h2 = ws((size_t)M * Cout * e);
         gn(h1, Cout, Ref(), 0, B, H * W, c.eps, wt(name + ".norm2.g"), wt(name + ".norm2.b"), 1, h2, "resnet.norm2+silu");
         rel(h1);
+        if (Cin != Cout && u.fuse_sc) {
+            // conv2 and the 1x1 conv_shortcut over [x | skip] share one K loop (mve_conv3x3_shortcut); no shortcut tensor exists
+            Ref out = ws((size_t)M * Cout * e);
+            const int d = dt, Bn = B;
+            Ref Wt = wt(name + ".conv2.w"), b2 = wt(name + ".conv2.b"), bs = wt(name + ".sc.b");
+            live(h2, "resnet.conv2+shortcut"); live(x, "resnet.conv2+shortcut"); live(skip, "resnet.conv2+shortcut");
+            const size_t skb = mve_gemm_workspace_bytes(M, Cout, 9 * Cout + Cin, H * W);
+            Ref sk = skb ? ws(skb) : Ref();
+            op(OC_CONV, 2.0 * M * (double)Cout * (9 * Cout + Cin), "resnet.conv2+shortcut", [=](const Run& r) {
+                return mve_conv3x3_shortcut(d, r.p(h2), Cout, r.p(x), C1, r.p(skip), C2, Bn, H, W, r.p(Wt), Cout, r.p(out), Cout,
+                                            (const float*)r.p(b2), (const float*)r.p(bs), nullptr, 0, 0, 1.0f, r.p(sk), skb, r.stream);
+            });
+            rel(sk);
+            rel(h2);
+            return out;
+        }
         Ref res = x, sc;
         if (Cin != Cout) {
             sc = ws((size_t)M * Cout * e);
@@ -1197,6 +1232,12 @@ int mve_controlnet_forward(void* handle, const void* d_sample, int io_dtype, con
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return MVE_OK;
+}
+
+int mve_unet_tune(int fuse_shortcut) {
+    const int old = g_fuse_shortcut;
+    if (fuse_shortcut >= 0) g_fuse_shortcut = fuse_shortcut ? 1 : 0;
+    return old;
 }
 
 int mve_unet_destroy(void* handle) {

@@ -77,6 +77,23 @@ def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec
     return out, Ho, Wo
 
 
+def conv3x3_shortcut(x1, w, B, H, W, x3, x4=None, bias=None, bias2=None, residual=None, splitk=True):
+    """ResnetBlock2D tail in one launch: conv3x3(x1) + conv1x1(cat[x3, x4]) + bias + bias2 (+ residual).
+    w [Cout, 9*C1 + C3 + C4]: 3x3 part in the channel-slab-major order of pack_conv_weight(..., True), then the 1x1 matrix."""
+    _chk16(x1, x3, x4, w, residual)
+    C1, C3 = x1.shape[1], x3.shape[1]
+    C4 = x4.shape[1] if x4 is not None else 0
+    Cout = w.shape[0]
+    assert w.numel() == Cout * (9 * C1 + C3 + C4)
+    out = torch.empty(B * H * W, Cout, dtype=x1.dtype, device=x1.device)
+    ws, ws_bytes = _splitk_ws(B * H * W, Cout, 9 * C1 + C3 + C4, x1.device, H * W if splitk else 0)
+    with torch.cuda.device(x1.device):
+        _lib.call('mve_conv3x3_shortcut', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x3), C3, _lib.ptr(x4), C4, B, H, W, _lib.ptr(w), Cout,
+                  _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(bias2), _lib.ptr(residual),
+                  residual.stride(0) if residual is not None else 0, 0, 1.0, _lib.ptr(ws), ws_bytes, _s(x1))
+    return out
+
+
 def pack_conv_weight(w_oihw, chunk64=None):
     """torch conv weight [O, I, 3, 3] -> (packed weight, flag): [O,3,3,I], or [O, I/64, 3, 3, 64] when I % 64 == 0."""
     O, I = w_oihw.shape[:2]

@@ -305,3 +305,34 @@ def test_big_tile_kernel_is_bit_identical(lib):
             assert torch.equal(outs[0], outs[1]), (B, H, C1, C2, Cout, stride, ups)
     finally:
         tune(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,C1,C3,C4', [(2, 16, 640, 320, 0), (3, 8, 320, 640, 320), (2, 8, 1280, 1280, 1280)])
+def test_conv3x3_with_fused_shortcut(lib, B, H, C1, C3, C4):
+    """conv2 + 1x1 conv_shortcut over the (concatenated) block input in one K loop, both kernels (bit-identical), with split-K."""
+    from mvedit_amd import ops, _lib
+    dtype = torch.float16
+    Cout = C1
+    h = rnd((B, C1, H, H), dtype, 1)
+    x3 = rnd((B, C3, H, H), dtype, 2)
+    x4 = rnd((B, C4, H, H), dtype, 3) if C4 else None
+    w = rnd((Cout, C1, 3, 3), dtype, 4, (9 * C1) ** -0.5)
+    wsc = rnd((Cout, C3 + C4, 1, 1), dtype, 5, (C3 + C4) ** -0.5)
+    b2, bs = rnd((Cout,), torch.float32, 6), rnd((Cout,), torch.float32, 7)
+    xin = torch.cat([x3, x4], 1) if C4 else x3
+    ref = conv_ref(h, w, b2) + F.conv2d(xin.float(), wsc.float(), bs)
+    w_k, _ = ops.pack_conv_weight(w, True)
+    wcat = torch.cat([w_k.reshape(Cout, -1), wsc.reshape(Cout, -1)], dim=1).contiguous()
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        outs = []
+        for big in (0, 1):
+            tune(1 if big else 0)
+            outs.append(ops.conv3x3_shortcut(to_nhwc(h).cuda(), wcat.cuda(), B, H, H, to_nhwc(x3).cuda(),
+                                             to_nhwc(x4).cuda() if C4 else None, bias=b2.cuda(), bias2=bs.cuda()))
+        assert torch.equal(outs[0], outs[1])
+        check('conv3x3 + shortcut', outs[0], to_nhwc(ref), dtype)
+    finally:
+        tune(old)
