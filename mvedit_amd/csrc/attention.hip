@@ -282,10 +282,19 @@ __global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnP
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 f32x8 e;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e[r] = __builtin_amdgcn_exp2f(s[2 * kk][f][r] * p.scale_log2e - mr);
-                    e[4 + r] = __builtin_amdgcn_exp2f(s[2 * kk + 1][f][r] * p.scale_log2e - mr);
+                {
+                    // exponent arguments on the packed-fp32 pipe (v_pk_fma_f32: two lanes of work per instruction)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 sc2 = {p.scale_log2e, p.scale_log2e}, mr2 = {mr, mr};
+                    const f32x4 a4 = s[2 * kk][f], b4 = s[2 * kk + 1][f];
+                    const f32x2 t0 = __builtin_elementwise_fma(f32x2{a4[0], a4[1]}, sc2, -mr2);
+                    const f32x2 t1 = __builtin_elementwise_fma(f32x2{a4[2], a4[3]}, sc2, -mr2);
+                    const f32x2 t2 = __builtin_elementwise_fma(f32x2{b4[0], b4[1]}, sc2, -mr2);
+                    const f32x2 t3 = __builtin_elementwise_fma(f32x2{b4[2], b4[3]}, sc2, -mr2);
+                    e[0] = __builtin_amdgcn_exp2f(t0[0]); e[1] = __builtin_amdgcn_exp2f(t0[1]);
+                    e[2] = __builtin_amdgcn_exp2f(t1[0]); e[3] = __builtin_amdgcn_exp2f(t1[1]);
+                    e[4] = __builtin_amdgcn_exp2f(t2[0]); e[5] = __builtin_amdgcn_exp2f(t2[1]);
+                    e[6] = __builtin_amdgcn_exp2f(t3[0]); e[7] = __builtin_amdgcn_exp2f(t3[1]);
                 }
                 if constexpr (!ONES) {
 #pragma unroll
