@@ -258,3 +258,31 @@ def test_gpu_update_extra_state(lib):
     it, th = vr.update_extra_state(grid, bitfield, 16)                # partial update touches at most half of the cells
     changed = (grid != before).float().mean().item()
     assert it == 17 and (grid >= before * 0.9 - 1e-7).all() and 0.05 < changed
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_render_properties(lib):
+    """BASELINE render batch (6 views x 512^2 rays, 128^3 grid, 12-level hash grid): determinism, opacity in [0,1], rays that
+    miss the occupied sphere render to exactly zero, depth only where there is opacity, and the result of a ray does not depend
+    on which rays share its launch."""
+    from mvedit_amd import nerf
+    p, dec = _decoder(12, 320, table_scale=2.0)
+    H = 128
+    bits = torch.from_numpy(ORM.packbits(sphere_density_grid(H, radius=0.5), 0.5)).cuda()
+    g = np.load(GOLD)
+    S = 512
+    f = S / (2 * np.tan(np.deg2rad(15)))
+    intr = torch.tensor([[f, f, S / 2, S / 2]] * 6, dtype=torch.float32).cuda()
+    poses = torch.from_numpy(g['poses'][:6, :3]).cuda()
+    ro, rd, _ = nerf.camera_rays(intr, poses, S, S)
+    ws, dep, img, cnt = dec.render_rays(ro, rd, bits, H, 0.0, return_counts=True)
+    ws2, dep2, img2 = dec.render_rays(ro, rd, bits, H, 0.0)
+    assert torch.equal(ws, ws2) and torch.equal(dep, dep2) and torch.equal(img, img2)
+    assert ws.min() >= 0 and ws.max() <= 1 + 1e-5 and cnt.max() <= dec.max_steps
+    miss = cnt == 0
+    assert 0.5 < miss.float().mean() < 0.95
+    assert (ws[miss] == 0).all() and (dep[miss] == 0).all() and (img[miss] == 0).all()
+    assert (dep[~miss] >= 0).all() and img.min() >= -1e-3 and img.max() <= 1 + 1e-3
+    idx = torch.randperm(ro.shape[0], device='cuda')[:100000]
+    ws3, dep3, img3 = dec.render_rays(ro[idx].contiguous(), rd[idx].contiguous(), bits, H, 0.0)
+    assert torch.equal(ws3, ws[idx]) and torch.equal(img3, img[idx]) and torch.equal(dep3, dep[idx])

@@ -352,3 +352,26 @@ def test_synthetic_weights_module_matches_oracle_inventory():
     assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
     a, b = S.make_controlnet_state_dict(U.TINY, seed=4), U.make_controlnet_state_dict(U.TINY, seed=4)
     assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.gpu
+def test_engine_sd15_full_size_properties(lib):
+    """BASELINE configs 3/4 at full size (SD-1.5, 64x64 latents): no oracle run at this size on the GPU box -- size-independent
+    properties instead: determinism, batch / partition invariance (a view's result does not depend on which other views share
+    the launch -- bitwise, across the big-tile / small-tile / split-K dispatch), and the CFG combination being linear."""
+    from mvedit_amd import ops, synthetic
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg, dtype = U.SD15, torch.float16
+    eng = UNet2DConditionEngine.from_state_dict(synthetic.make_state_dict(cfg, seed=1234, dtype=dtype), cfg, dtype)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(12, 4, 64, 64, generator=g).to(dtype).cuda()
+    ctx = torch.randn(12, 77, 768, generator=g).to(dtype).cuda()
+    full = eng(x, 499, ctx)[0]
+    assert full.shape == (12, 4, 64, 64) and torch.isfinite(full).all() and full.float().std() > 1e-3
+    assert torch.equal(full, eng(x, 499, ctx)[0]), 'deterministic'
+    for sl in (slice(0, 1), slice(3, 7), slice(8, 12)):          # 1, 4 and 4 images: other tile shapes, same bits
+        assert torch.equal(full[sl], eng(x[sl].contiguous(), 499, ctx[sl].contiguous())[0]), sl
+    un, tx = full[:6].float(), full[6:].float()
+    a, b = ops.cfg_combine(un, tx, 7.0), ops.cfg_combine(un, tx, 3.0)
+    mid = ops.cfg_combine(un, tx, 5.0)
+    assert (mid - 0.5 * (a + b)).abs().max() <= 1e-5 * (1 + mid.abs().max())
