@@ -340,6 +340,22 @@ MVE_API int mve_hashgrid_mlp_decode(const float* d_xyz, uint32_t M, const float*
                                     const float* d_b2, int hidden, float bound, float blob_density, float blob_radius,
                                     float sigmoid_saturation, float* d_sigmas, float* d_rgbs, void* stream);
 
+/* Decoder backward (the reconstruct step): gradients of  sum(g_sigma * sigma) + sum(g_rgb * rgb)  for the M
+ * points of a training batch w.r.t. the hash table and the MLP of iNGPDecoder.point_decode (lib/models/decoders/ingp_decoder.py:106-120;
+ * sigma uses the backward of the reference's _trunc_exp, lib/ops/activation.py:17-20).  The forward is recomputed, nothing has to be
+ * saved.  d_grad_table [rows][2] is ACCUMULATED into (float atomics; zero it per optimiser step); the four MLP gradients are
+ * overwritten (deterministic two-stage reduction).  d_grad_rgb may be NULL (density-only).  hidden must be 64. */
+MVE_API size_t mve_hashgrid_mlp_backward_workspace_bytes(uint32_t M, int n_levels);
+MVE_API int mve_hashgrid_mlp_backward(const float* d_xyz, uint32_t M, const float* d_table, int n_levels, const float* level_scale,
+                                      const uint32_t* level_res, const uint32_t* level_offset, const uint32_t* level_size,
+                                      const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2, int hidden, float bound,
+                                      float blob_density, float blob_radius, float sigmoid_saturation, const float* d_grad_sigma,
+                                      const float* d_grad_rgb, float* d_grad_table, float* d_grad_w1, float* d_grad_b1,
+                                      float* d_grad_w2, float* d_grad_b2, void* d_workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.Adam step (no weight decay, no amsgrad) in place on param / exp_avg / exp_avg_sq; step counts from 1. */
+MVE_API int mve_adam_step(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, size_t n, float lr, float beta1,
+                          float beta2, float eps, int step, void* stream);
+
 /* VolumeRenderer.forward, eval branch (lib/models/decoders/base_volume_renderer.py:264-329) as ONE launch:
  * near/far from the aabb, occupancy-grid march (cascade count 1, no contraction, noise 0), hash-grid + MLP decode and
  * compositing per ray, with the reference's termination rules.  Outputs [N], [N], [N,3]; d_n_samples [N] optional. */

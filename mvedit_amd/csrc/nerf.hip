@@ -222,6 +222,190 @@ __device__ __forceinline__ void decode_point2(const DecoderParams& p, const floa
     for (int k = 0; k < 3; ++k) rgb[k] = (1.0f / (1.0f + expf(-o[1 + k]))) * p.sat_scale - p.sat_shift;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Decoder backward: gradients of  sum(g_sigma * sigma) + sum(g_rgb * rgb)  w.r.t. the hash table and
+// the MLP, for the points of a training batch.  One thread per point recomputes the forward (nothing is saved by the forward
+// pass), back-propagates through the activations (sigma: the reference's _trunc_exp backward, lib/ops/activation.py:17-20) and
+// the two linear layers, scatters d enc into the table gradient (atomicAdd, as tiny-cuda-nn does) and leaves the per-point
+// factors of the weight gradients (dh, relu(h), enc, do) in a workspace; k_xty reduces them deterministically.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(NB, 2) void k_decode_backward(DecoderParams p, const float* __restrict__ xyz, uint32_t M,
+                                                           const float* __restrict__ g_sigma, const float* __restrict__ g_rgb,
+                                                           float* __restrict__ g_table, float* __restrict__ ws_dh /*[M][64]*/,
+                                                           float* __restrict__ ws_hr /*[M][64]*/, float* __restrict__ ws_enc /*[M][2NL]*/,
+                                                           float* __restrict__ ws_do /*[M][4]*/) {
+    __shared__ __attribute__((aligned(16))) float w1t[HID * 2 * NL];
+    stage_w1<NL>(p, w1t);
+    __syncthreads();
+    const uint32_t m = blockIdx.x * NB + threadIdx.x;
+    if (m >= M) return;
+    const float3p q = reinterpret_cast<const float3p*>(xyz)[m];
+    const float x = q.x, y = q.y, z = q.z;
+    const float inv = 1.0f / (2.0f * p.bound);
+    const float u[3] = {(x + p.bound) * inv, (y + p.bound) * inv, (z + p.bound) * inv};
+    // one level: cell / interpolation weights / table row of each corner, through `visit(corner_weight, row)`
+    auto level = [&](int l, auto&& visit) {
+        const float scale = p.g.scale[l];
+        const uint32_t res = p.g.res[l], size = p.g.size[l];
+        uint32_t cell[3];
+        float w[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float pos = fmaf(scale, u[d], 0.5f);
+            const float fl = floorf(pos);
+            cell[d] = (uint32_t)(int)fl;
+            const float fr = pos - fl;
+            w[d] = fr * fr * (3.0f - 2.0f * fr);
+        }
+        const bool s1 = res <= size;
+        const bool s2 = s1 && (uint64_t)res * res <= size;
+        const uint64_t stride3 = (uint64_t)res * res * (s2 ? res : 1u);
+        const bool hashed = s2 ? (size < stride3) : true;
+        const uint32_t off = p.g.off[l];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            float wt = 1.0f;
+            uint32_t c[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (corner & (1 << d)) { wt = wt * w[d]; c[d] = cell[d] + 1u; }
+                else { wt = wt * (1.0f - w[d]); c[d] = cell[d]; }
+            }
+            uint32_t idx = hashed ? ((c[0] * 1u) ^ (c[1] * 2654435761u) ^ (c[2] * 805459861u)) : (c[0] + c[1] * res + c[2] * res * res);
+            idx %= size;
+            visit(wt, off + idx);
+        }
+    };
+    // ---- forward: hidden pre-activations -------------------------------------------------------------------------------
+    float h[HID];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) h[j] = p.b1[j];
+    const float2p* tab = reinterpret_cast<const float2p*>(p.table);
+#pragma unroll 1
+    for (int l = 0; l < NL; ++l) {
+        float a0 = 0.f, a1 = 0.f;
+        level(l, [&](float wt, uint32_t row) { const float2p f = tab[row]; a0 = fmaf(wt, f.x, a0); a1 = fmaf(wt, f.y, a1); });
+        ws_enc[(size_t)m * (2 * NL) + 2 * l] = a0;
+        ws_enc[(size_t)m * (2 * NL) + 2 * l + 1] = a1;
+        const f32x4* wl = reinterpret_cast<const f32x4*>(w1t + l * (HID * 2));
+#pragma unroll
+        for (int j2 = 0; j2 < HID / 2; ++j2) {
+            const f32x4 wv = wl[j2];
+            h[2 * j2] = fmaf(wv[0], a0, h[2 * j2]);
+            h[2 * j2] = fmaf(wv[1], a1, h[2 * j2]);
+            h[2 * j2 + 1] = fmaf(wv[2], a0, h[2 * j2 + 1]);
+            h[2 * j2 + 1] = fmaf(wv[3], a1, h[2 * j2 + 1]);
+        }
+    }
+    float o[4] = {p.b2[0], p.b2[1], p.b2[2], p.b2[3]};
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+        const float a = fmaxf(h[j], 0.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = fmaf(p.w2[k * HID + j], a, o[k]);
+    }
+    // ---- output activations backward -----------------------------------------------------------------------------------------
+    const float d2 = fmaxf(x * x + y * y + z * z, 0.2f);
+    const float sigma = expf(o[0] + p.blob_density * expf(-d2 * p.blob_inv_2r2));
+    float dout[4];
+    dout[0] = g_sigma[m] * fminf(fmaxf(sigma, 1e-6f), 1e6f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float sg = 1.0f / (1.0f + expf(-o[1 + k]));
+        dout[1 + k] = (g_rgb ? g_rgb[3ull * m + k] : 0.0f) * p.sat_scale * sg * (1.0f - sg);
+    }
+    reinterpret_cast<f32x4*>(ws_do)[m] = f32x4{dout[0], dout[1], dout[2], dout[3]};
+    // ---- hidden layer backward: store relu(h) (for dW2) and dh (for dW1), keep dh in registers -------------------------------------
+#pragma unroll
+    for (int j4 = 0; j4 < HID / 4; ++j4) {
+        f32x4 hr, dh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * j4 + e;
+            const bool on = h[j] > 0.0f;
+            hr[e] = on ? h[j] : 0.0f;
+            float g = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g = fmaf(p.w2[k * HID + j], dout[k], g);
+            dh[e] = on ? g : 0.0f;
+            h[j] = dh[e];
+        }
+        reinterpret_cast<f32x4*>(ws_hr + (size_t)m * HID)[j4] = hr;
+        reinterpret_cast<f32x4*>(ws_dh + (size_t)m * HID)[j4] = dh;
+    }
+    // ---- encoding backward: d enc_l = W1[:, 2l:2l+2]^T dh, scattered to the 8 corners of every level ------------------------------
+#pragma unroll 1
+    for (int l = 0; l < NL; ++l) {
+        const f32x4* wl = reinterpret_cast<const f32x4*>(w1t + l * (HID * 2));
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int j2 = 0; j2 < HID / 2; ++j2) {
+            const f32x4 wv = wl[j2];
+            e0 = fmaf(wv[0], h[2 * j2], e0); e1 = fmaf(wv[1], h[2 * j2], e1);
+            e0 = fmaf(wv[2], h[2 * j2 + 1], e0); e1 = fmaf(wv[3], h[2 * j2 + 1], e1);
+        }
+        level(l, [&](float wt, uint32_t row) {
+            atomicAdd(g_table + 2ull * row, wt * e0);
+            atomicAdd(g_table + 2ull * row + 1, wt * e1);
+        });
+    }
+}
+
+// out[p][q] = sum_m X[m][p] * Y[m][q]  (and colsum: sum_m X[m][p]): per-block partials over 1024-row chunks, reduced in a
+// fixed order by k_xty_reduce -> deterministic.  P, Q <= 64, P * Q <= 2048.
+constexpr int XTY_ROWS = 1024, XTY_STEP = 32;
+__global__ __launch_bounds__(256) void k_xty(const float* __restrict__ X, int P, const float* __restrict__ Y, int Q, uint32_t M,
+                                             float* __restrict__ partial /*[nblk][P*Q + P]*/) {
+    __shared__ float xs[XTY_STEP][64], ys[XTY_STEP][64];
+    const uint32_t r0 = blockIdx.x * XTY_ROWS, r1 = min(M, r0 + XTY_ROWS);
+    const int nout = P * Q;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float cs = 0.f;                                       // threads 0..P-1: column sums of X
+    for (uint32_t r = r0; r < r1; r += XTY_STEP) {
+        for (int i = threadIdx.x; i < XTY_STEP * P; i += 256) { const int rr = i / P, c = i - rr * P; xs[rr][c] = (r + rr < r1) ? X[(size_t)(r + rr) * P + c] : 0.f; }
+        for (int i = threadIdx.x; i < XTY_STEP * Q; i += 256) { const int rr = i / Q, c = i - rr * Q; ys[rr][c] = (r + rr < r1) ? Y[(size_t)(r + rr) * Q + c] : 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int oi = threadIdx.x + 256 * k;
+            if (oi < nout) {
+                const int pi = oi / Q, qi = oi - pi * Q;
+                float a = acc[k];
+                for (int rr = 0; rr < XTY_STEP; ++rr) a = fmaf(xs[rr][pi], ys[rr][qi], a);
+                acc[k] = a;
+            }
+        }
+        if ((int)threadIdx.x < P) for (int rr = 0; rr < XTY_STEP; ++rr) cs += xs[rr][threadIdx.x];
+        __syncthreads();
+    }
+    float* out = partial + (size_t)blockIdx.x * (nout + P);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int oi = threadIdx.x + 256 * k; if (oi < nout) out[oi] = acc[k]; }
+    if ((int)threadIdx.x < P) out[nout + threadIdx.x] = cs;
+}
+__global__ __launch_bounds__(256) void k_xty_reduce(const float* __restrict__ partial, int nblk, int n, int n_mat, float* __restrict__ out_mat,
+                                                    float* __restrict__ out_col) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int b = 0; b < nblk; ++b) a += partial[(size_t)b * n + i];
+    if (i < n_mat) out_mat[i] = a;
+    else if (out_col) out_col[i - n_mat] = a;
+}
+
+// fused Adam (torch.optim.Adam semantics, no weight decay / amsgrad): in place on param, m, v
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
+                                              size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float a = b1 * m1[i] + (1.0f - b1) * gi;
+    const float b = b2 * m2[i] + (1.0f - b2) * gi * gi;
+    m1[i] = a; m2[i] = b;
+    w[i] -= lr * (a / bc1) / (sqrtf(b / bc2) + eps);
+}
+
 template <int NL>
 __global__ __launch_bounds__(NB, 4) void k_point_decode2(DecoderParams p, const float* __restrict__ xyz, uint32_t M,
                                                          float* __restrict__ sigmas, float* __restrict__ rgbs) {
@@ -471,6 +655,69 @@ int mve_hashgrid_mlp_decode(const float* d_xyz, uint32_t M, const float* d_table
     } else if (n_levels == 12) k_point_decode<12><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
     else if (n_levels == 14) k_point_decode<14><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
     else k_point_decode<16><<<grid, NB, 0, s>>>(p, d_xyz, M, d_sigmas, d_rgbs);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+size_t mve_hashgrid_mlp_backward_workspace_bytes(uint32_t M, int n_levels) {
+    const size_t nblk = (M + XTY_ROWS - 1) / XTY_ROWS;
+    return sizeof(float) * ((size_t)M * (HID + HID + 2 * n_levels + 4) + nblk * (size_t)(HID * 2 * n_levels + HID + 4 * HID + 4) + 64);
+}
+
+int mve_hashgrid_mlp_backward(const float* d_xyz, uint32_t M, const float* d_table, int n_levels, const float* level_scale,
+                              const uint32_t* level_res, const uint32_t* level_offset, const uint32_t* level_size, const float* d_w1,
+                              const float* d_b1, const float* d_w2, const float* d_b2, int hidden, float bound, float blob_density,
+                              float blob_radius, float sigmoid_saturation, const float* d_grad_sigma, const float* d_grad_rgb,
+                              float* d_grad_table, float* d_grad_w1, float* d_grad_b1, float* d_grad_w2, float* d_grad_b2,
+                              void* d_workspace, size_t workspace_bytes, void* stream) {
+    MVE_CHECK(d_grad_table && d_grad_w1 && d_grad_b1 && d_grad_w2 && d_grad_b2, MVE_ERR_ARG, "hashgrid_mlp_backward: null gradient output");
+    MVE_CHECK(hidden == HID, MVE_ERR_ARG, "hashgrid_mlp_backward: hidden width must be %d", HID);
+    hipStream_t s = (hipStream_t)stream;
+    const int nin = 2 * n_levels;
+    if (M == 0) {
+        MVE_HIP(hipMemsetAsync(d_grad_w1, 0, sizeof(float) * HID * nin, s));
+        MVE_HIP(hipMemsetAsync(d_grad_b1, 0, sizeof(float) * HID, s));
+        MVE_HIP(hipMemsetAsync(d_grad_w2, 0, sizeof(float) * 4 * HID, s));
+        MVE_HIP(hipMemsetAsync(d_grad_b2, 0, sizeof(float) * 4, s));
+        return MVE_OK;
+    }
+    MVE_CHECK(d_xyz && d_grad_sigma && d_workspace, MVE_ERR_ARG, "hashgrid_mlp_backward: null pointer");
+    MVE_CHECK(workspace_bytes >= mve_hashgrid_mlp_backward_workspace_bytes(M, n_levels), MVE_ERR_NOMEM, "hashgrid_mlp_backward: workspace too small");
+    DecoderParams p;
+    int rc = fill_decoder(p, d_table, n_levels, level_scale, level_res, level_offset, level_size, d_w1, d_b1, d_w2, d_b2, hidden,
+                          bound, blob_density, blob_radius, sigmoid_saturation);
+    if (rc) return rc;
+    float* ws = (float*)d_workspace;
+    float* dh = ws; ws += (size_t)M * HID;
+    float* hr = ws; ws += (size_t)M * HID;
+    float* enc = ws; ws += (size_t)M * nin;
+    float* dout = ws; ws += (size_t)M * 4;
+    float* part = ws;
+    const unsigned grid = mve_cdiv(M, NB);
+    if (n_levels == 12) k_decode_backward<12><<<grid, NB, 0, s>>>(p, d_xyz, M, d_grad_sigma, d_grad_rgb, d_grad_table, dh, hr, enc, dout);
+    else if (n_levels == 14) k_decode_backward<14><<<grid, NB, 0, s>>>(p, d_xyz, M, d_grad_sigma, d_grad_rgb, d_grad_table, dh, hr, enc, dout);
+    else k_decode_backward<16><<<grid, NB, 0, s>>>(p, d_xyz, M, d_grad_sigma, d_grad_rgb, d_grad_table, dh, hr, enc, dout);
+    MVE_LAUNCH_CHECK();
+    const int nblk = (int)mve_cdiv(M, XTY_ROWS);
+    // dW1 [64][2NL] = dh^T enc, db1 = colsum(dh)
+    k_xty<<<nblk, 256, 0, s>>>(dh, HID, enc, nin, M, part);
+    MVE_LAUNCH_CHECK();
+    k_xty_reduce<<<mve_cdiv(HID * nin + HID, 256), 256, 0, s>>>(part, nblk, HID * nin + HID, HID * nin, d_grad_w1, d_grad_b1);
+    MVE_LAUNCH_CHECK();
+    // dW2 [4][64] = do^T relu(h), db2 = colsum(do)
+    k_xty<<<nblk, 256, 0, s>>>(dout, 4, hr, HID, M, part);
+    MVE_LAUNCH_CHECK();
+    k_xty_reduce<<<mve_cdiv(4 * HID + 4, 256), 256, 0, s>>>(part, nblk, 4 * HID + 4, 4 * HID, d_grad_w2, d_grad_b2);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_adam_step(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream) {
+    if (n == 0) return MVE_OK;
+    MVE_CHECK(d_param && d_grad && d_exp_avg && d_exp_avg_sq && step >= 1, MVE_ERR_ARG, "adam_step: bad arguments");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    k_adam<<<mve_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(d_param, d_grad, d_exp_avg, d_exp_avg_sq, n, lr, beta1, beta2, eps, bc1, bc2);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

@@ -73,6 +73,39 @@ class INGPDecoderParams:
                       _lib.stream_ptr(self.device))
         return sigmas, rgbs
 
+    # reconstruct step: gradients and optimiser -------------------------------------------------
+    def parameters(self):
+        return dict(table=self.table, w1=self.w1, b1=self.b1, w2=self.w2, b2=self.b2)
+
+    def point_decode_backward(self, xyzs, grad_sigmas, grad_rgbs=None, grads=None):
+        """Gradients of sum(grad_sigmas * sigma) + sum(grad_rgbs * rgb) w.r.t. parameters().  `grads` (a dict from a previous
+        call) is re-used: its table gradient is accumulated into, the MLP gradients are overwritten."""
+        xyzs = xyzs.to(self.device, torch.float32).contiguous().view(-1, 3)
+        M = xyzs.shape[0]
+        gs = grad_sigmas.to(self.device, torch.float32).contiguous().view(-1)
+        gr = grad_rgbs.to(self.device, torch.float32).contiguous().view(-1, 3) if grad_rgbs is not None else None
+        if grads is None:
+            grads = {k: torch.zeros_like(v) for k, v in self.parameters().items()}
+        nbytes = _lib.raw('mve_hashgrid_mlp_backward_workspace_bytes')(M, self.n_levels)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.call('mve_hashgrid_mlp_backward', _lib.ptr(xyzs), M, *self._grid_args(), *self._mlp_args(), self.bound, self.blob_density,
+                      self.blob_radius, self.sigmoid_saturation, _lib.ptr(gs), _lib.ptr(gr), _lib.ptr(grads['table']), _lib.ptr(grads['w1']),
+                      _lib.ptr(grads['b1']), _lib.ptr(grads['w2']), _lib.ptr(grads['b2']), _lib.ptr(ws), nbytes, _lib.stream_ptr(self.device))
+        return grads
+
+    def adam_step(self, grads, state, lr=1e-2, betas=(0.9, 0.999), eps=1e-15):
+        """One torch.optim.Adam step on every parameter, in place.  `state` is a dict the caller keeps between steps."""
+        state['step'] = state.get('step', 0) + 1
+        with torch.cuda.device(self.device):
+            for k, w in self.parameters().items():
+                if k not in state:
+                    state[k] = (torch.zeros_like(w), torch.zeros_like(w))
+                m1, m2 = state[k]
+                _lib.call('mve_adam_step', _lib.ptr(w), _lib.ptr(grads[k]), _lib.ptr(m1), _lib.ptr(m2), w.numel(), float(lr), float(betas[0]),
+                          float(betas[1]), float(eps), int(state['step']), _lib.stream_ptr(self.device))
+        return state
+
     # VolumeRenderer.forward, eval branch ------------------------------------------------------------------------
     def render_rays(self, rays_o, rays_d, density_bitfield, grid_size, dt_gamma=0.0, T_thresh=1e-2, return_counts=False):
         rays_o = rays_o.to(self.device, torch.float32).contiguous().view(-1, 3)

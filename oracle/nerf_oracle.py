@@ -275,3 +275,69 @@ def train_forward(rays_o, rays_d, bitfield, grid_size, params, noises, dt_gamma=
     sig, rgb = point_decode(xyzs, params, bound)
     weights, ws, depth, image = ORM.composite_rays_train(sig, rgb, ts, rays)
     return dict(weights=weights, weights_sum=ws, depth=depth, image=image, rays=rays, ts=ts, xyzs=xyzs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Decoder backward (the reconstruct step's gradients w.r.t. the hash table and the MLP).
+# torch autograd over a torch restatement of point_decode above; the sigma activation's backward is the reference's own
+# _trunc_exp (lib/ops/activation.py:8-20: grad * clamp(exp(x), 1e-6, 1e6)).
+# ---------------------------------------------------------------------------------------------------
+def decoder_grads_torch(xyzs, params, g_sigma, g_rgb, bound=1.0, blob_density=1.0, blob_radius=0.2, sigmoid_saturation=0.001):
+    """-> dict(table, w1, b1, w2, b2) of float32 numpy gradients of  sum(g_sigma*sigma) + sum(g_rgb*rgb)."""
+    import torch
+
+    class TruncExp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            e = torch.exp(x)
+            ctx.save_for_backward(e)
+            return e
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * ctx.saved_tensors[0].clamp(min=1e-6, max=1e6)
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    x = t(np.asarray(xyzs, np.float32))
+    table = t(params['table']).clone().requires_grad_(True)
+    w1, b1 = t(params['w1']).clone().requires_grad_(True), t(params['b1']).clone().requires_grad_(True)
+    w2, b2 = t(params['w2']).clone().requires_grad_(True), t(params['b2']).clone().requires_grad_(True)
+    meta, _ = grid_meta(params['n_levels'], 16, params['max_resolution'], bound)
+    u = (x + bound) / (2 * bound)
+    feats = []
+    M32 = 0xFFFFFFFF
+    for (scale, res, off, size) in meta:
+        pos = torch.tensor(scale, dtype=torch.float32) * u + 0.5
+        cf = torch.floor(pos)
+        fr = pos - cf
+        w = fr * fr * (3.0 - 2.0 * fr)
+        cell = cf.to(torch.int64) & M32
+        acc = 0
+        dense = res * res * res <= size and res <= size and res * res <= size
+        for corner in range(8):
+            wt = torch.ones(x.shape[0])
+            c = []
+            for d in range(3):
+                if corner & (1 << d):
+                    wt = wt * w[:, d]
+                    c.append((cell[:, d] + 1) & M32)
+                else:
+                    wt = wt * (1.0 - w[:, d])
+                    c.append(cell[:, d])
+            if dense:
+                idx = (c[0] + c[1] * res + c[2] * res * res) & M32
+            else:
+                idx = ((c[0] * 1) & M32) ^ ((c[1] * 2654435761) & M32) ^ ((c[2] * 805459861) & M32)
+            idx = idx % size
+            acc = acc + wt[:, None] * table[off + idx]
+        feats.append(acc)
+    enc = torch.cat(feats, dim=1)
+    h = torch.relu(enc @ w1.t() + b1)
+    o = h @ w2.t() + b2
+    d2 = (x * x).sum(-1).clamp(min=0.2)
+    sigma = TruncExp.apply(o[:, 0] + blob_density * torch.exp(-d2 / (2 * blob_radius ** 2)))
+    rgb = torch.sigmoid(o[:, 1:]) * (1 + 2 * sigmoid_saturation) - sigmoid_saturation
+    loss = (t(np.asarray(g_sigma, np.float32)) * sigma).sum() + (t(np.asarray(g_rgb, np.float32)) * rgb).sum()
+    loss.backward()
+    return dict(table=table.grad.numpy(), w1=w1.grad.numpy(), b1=b1.grad.numpy(), w2=w2.grad.numpy(), b2=b2.grad.numpy(),
+                sigma=sigma.detach().numpy(), rgb=rgb.detach().numpy())
