@@ -31,6 +31,25 @@ def grid_meta(n_levels=12, base_resolution=16, max_resolution=320, bound=1.0, lo
     return meta, off
 
 
+class _PointDecodeFn(torch.autograd.Function):
+    """point_decode as a differentiable op w.r.t. the decoder parameters: native forward, native backward (the forward is
+    recomputed inside the backward kernel, so nothing but the inputs is saved).  Gradients w.r.t. the sample positions are not
+    provided (the reference needs them only for compute_normal in the training branch)."""
+
+    @staticmethod
+    def forward(ctx, dec, xyzs, table, w1, b1, w2, b2):
+        ctx.dec = dec
+        ctx.save_for_backward(xyzs)
+        sigmas, rgbs = dec.point_decode(xyzs)
+        return sigmas, rgbs
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        (xyzs,) = ctx.saved_tensors
+        g = ctx.dec.point_decode_backward(xyzs, g_sigma.contiguous(), g_rgb.contiguous())
+        return None, None, g['table'], g['w1'], g['b1'], g['w2'], g['b2']
+
+
 class INGPDecoderParams:
     """Device-resident state of an iNGPDecoder (hash table + MLP) in the layout the kernels read."""
 
@@ -93,6 +112,11 @@ class INGPDecoderParams:
                       self.blob_radius, self.sigmoid_saturation, _lib.ptr(gs), _lib.ptr(gr), _lib.ptr(grads['table']), _lib.ptr(grads['w1']),
                       _lib.ptr(grads['b1']), _lib.ptr(grads['w2']), _lib.ptr(grads['b2']), _lib.ptr(ws), nbytes, _lib.stream_ptr(self.device))
         return grads
+
+    def point_decode_autograd(self, xyzs):
+        """point_decode whose outputs carry autograd history w.r.t. parameters(): mark the parameter tensors with
+        requires_grad_(True) and use any torch optimiser on them, as the reference's nerf_optim does with tinycudann modules."""
+        return _PointDecodeFn.apply(self, xyzs, self.table, self.w1, self.b1, self.w2, self.b2)
 
     def adam_step(self, grads, state, lr=1e-2, betas=(0.9, 0.999), eps=1e-15):
         """One torch.optim.Adam step on every parameter, in place.  `state` is a dict the caller keeps between steps."""

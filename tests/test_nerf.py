@@ -347,3 +347,33 @@ def test_gpu_native_fitting_loop_reduces_loss(lib):
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
     assert all(np.isfinite(losses))
+
+
+@pytest.mark.gpu
+def test_gpu_point_decode_autograd_with_torch_optimizer(lib):
+    """The decoder as an autograd op: a stock torch.optim.Adam on its parameter tensors, loss.backward() through
+    composite_rays_train and point_decode -- the shape of the reference's nerf_optim inner loop (mvedit_3d_pipeline.py:507-633)."""
+    from mvedit_amd import raymarching as rm
+    p, dec = _decoder(12, 320, table_scale=0.1)
+    H = 64
+    bits = torch.from_numpy(ORM.packbits(sphere_density_grid(H, radius=0.6), 0.5)).cuda()
+    o, d = scene_rays(1, 48, seed=6)
+    o, d = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    nears, fars = rm.near_far_from_aabb(o, d, dec.aabb, dec.min_near)
+    xyzs, dirs, ts, rays = rm.march_rays_train(o, d, dec.bound, bits, 1, H, nears, fars, dt_gamma=0.0, max_steps=256)
+    params = list(dec.parameters().values())
+    for t in params:
+        t.requires_grad_(True)
+    opt = torch.optim.Adam(params, lr=2e-2, eps=1e-15)
+    target = (rays[:, 1] > 0).float()
+    losses = []
+    for it in range(25):
+        opt.zero_grad(set_to_none=True)
+        sig, rgb = dec.point_decode_autograd(xyzs)
+        _, wsum, _, image = rm.composite_rays_train(sig, rgb, ts, rays)
+        loss = ((wsum - target) ** 2).mean() + ((image - 0.5 * target[:, None]) ** 2).mean()
+        loss.backward()
+        assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in params)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.3 * losses[0], (losses[0], losses[-1])
