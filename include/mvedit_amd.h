@@ -453,7 +453,13 @@ MVE_API size_t mve_dmtet_workspace_bytes(size_t n_verts, size_t n_tets);
 MVE_API int mve_dmtet_count(const float* d_sdf, const int32_t* d_tets, size_t n_verts, size_t n_tets, int32_t* d_counts,
                             void* d_workspace, size_t workspace_bytes, void* stream);
 MVE_API int mve_dmtet_write(const float* d_pos, const float* d_sdf, const int32_t* d_tets, size_t n_verts, size_t n_tets,
-                            float* d_out_verts, int32_t* d_out_faces, void* d_workspace, size_t workspace_bytes, void* stream);
+                            float* d_out_verts, int32_t* d_out_faces, int32_t* d_out_edges /* optional [n_out,2]: the grid edge
+                            (a < b) behind every output vertex, what the backward needs */, void* d_workspace,
+                            size_t workspace_bytes, void* stream);
+/* Backward of the vertex interpolation (the part of DMTet.__call__ that carries gradients, base_mesh_renderer.py:167-176):
+ * d_grad_pos [Nv,3] and d_grad_sdf [Nv] are ACCUMULATED into (float atomics; either may be NULL). */
+MVE_API int mve_dmtet_backward(const float* d_pos, const float* d_sdf, const int32_t* d_edges, size_t n_out_verts,
+                               const float* d_grad_verts, float* d_grad_pos, float* d_grad_sdf, void* stream);
 
 #ifdef __cplusplus
 }

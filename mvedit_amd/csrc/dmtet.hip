@@ -148,7 +148,7 @@ __global__ __launch_bounds__(DB) void k_bucket_unique(const int* __restrict__ ba
 
 __global__ __launch_bounds__(DB) void k_interp_verts(const float* __restrict__ pos, const float* __restrict__ sdf, const int* __restrict__ base,
                                                      const int* __restrict__ uniq, const int* __restrict__ ubase, const int* __restrict__ bucket,
-                                                     int Nv, float* __restrict__ verts) {
+                                                     int Nv, float* __restrict__ verts, int32_t* __restrict__ edges) {
     const int a = blockIdx.x * DB + threadIdx.x;
     if (a >= Nv) return;
     const int m = uniq[a];
@@ -160,9 +160,12 @@ __global__ __launch_bounds__(DB) void k_interp_verts(const float* __restrict__ p
         const float nb = sdf[vb] * -1.0f;
         const float den = sa + nb;
         const float wa = nb / den, wb = sa / den;
-        float* o = verts + 3ll * (ubase[a] + j);
+        if (verts) {
+            float* o = verts + 3ll * (ubase[a] + j);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] = pos[3ll * a + k] * wa + pos[3ll * vb + k] * wb;
+            for (int k = 0; k < 3; ++k) o[k] = pos[3ll * a + k] * wa + pos[3ll * vb + k] * wb;
+        }
+        if (edges) { edges[2ll * (ubase[a] + j)] = a; edges[2ll * (ubase[a] + j) + 1] = vb; }
     }
 }
 
@@ -189,6 +192,30 @@ __global__ __launch_bounds__(DB) void k_emit_faces(const float* __restrict__ sdf
         int lo = 0, hi = uniq[a];                           // lower_bound: the table only references crossing edges
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (lst[mid] < b) lo = mid + 1; else hi = mid; }
         faces[3 * row + k] = ubase[a] + lo;
+    }
+}
+
+// d verts -> d pos, d sdf.  v = pa * wa + pb * wb, wa = -sb / (sa - sb), wb = sa / (sa - sb)  (base_mesh_renderer.py:170-176), so
+//   d pa = wa g,  d pb = wb g,  d sa = sb (g . (pa - pb)) / (sa - sb)^2,  d sb = -sa (g . (pa - pb)) / (sa - sb)^2.
+__global__ __launch_bounds__(DB) void k_dmtet_backward(const float* __restrict__ pos, const float* __restrict__ sdf, const int32_t* __restrict__ edges,
+                                                       int n_out, const float* __restrict__ g_verts, float* __restrict__ g_pos,
+                                                       float* __restrict__ g_sdf) {
+    const int k = blockIdx.x * DB + threadIdx.x;
+    if (k >= n_out) return;
+    const int a = edges[2 * k], b = edges[2 * k + 1];
+    const float sa = sdf[a], sb = sdf[b];
+    const float den = sa - sb, wa = -sb / den, wb = sa / den;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = g_verts[3ll * k + c];
+        if (g_pos) { atomicAdd(g_pos + 3ll * a + c, wa * g); atomicAdd(g_pos + 3ll * b + c, wb * g); }
+        dot += g * (pos[3ll * a + c] - pos[3ll * b + c]);
+    }
+    if (g_sdf) {
+        const float r = dot / (den * den);
+        atomicAdd(g_sdf + a, sb * r);
+        atomicAdd(g_sdf + b, -sa * r);
     }
 }
 
@@ -260,21 +287,31 @@ int mve_dmtet_count(const float* d_sdf, const int32_t* d_tets, size_t n_verts, s
 }
 
 int mve_dmtet_write(const float* d_pos, const float* d_sdf, const int32_t* d_tets, size_t n_verts, size_t n_tets, float* d_out_verts,
-                    int32_t* d_out_faces, void* d_workspace, size_t workspace_bytes, void* stream) {
+                    int32_t* d_out_faces, int32_t* d_out_edges, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (n_tets == 0 || n_verts == 0) return MVE_OK;
     MVE_CHECK(d_pos && d_sdf && d_tets && d_workspace, MVE_ERR_ARG, "dmtet_write: null pointer");
     MVE_CHECK(workspace_bytes >= mve_dmtet_workspace_bytes(n_verts, n_tets), MVE_ERR_NOMEM, "dmtet_write: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Layout L = layout(d_workspace, n_verts, n_tets);
     const unsigned gt = (unsigned)((n_tets + DB - 1) / DB), gv = (unsigned)((n_verts + DB - 1) / DB);
-    if (d_out_verts) {
-        k_interp_verts<<<gv, DB, 0, s>>>(d_pos, d_sdf, L.base, L.uniq, L.ubase, L.bucket, (int)n_verts, d_out_verts);
+    if (d_out_verts || d_out_edges) {
+        k_interp_verts<<<gv, DB, 0, s>>>(d_pos, d_sdf, L.base, L.uniq, L.ubase, L.bucket, (int)n_verts, d_out_verts, d_out_edges);
         MVE_LAUNCH_CHECK();
     }
     if (d_out_faces) {
         k_emit_faces<<<gt, DB, 0, s>>>(d_sdf, d_tets, n_tets, L.off, 0ull, L.total_u64, L.base, L.uniq, L.ubase, L.bucket, d_out_faces);
         MVE_LAUNCH_CHECK();
     }
+    return MVE_OK;
+}
+
+int mve_dmtet_backward(const float* d_pos, const float* d_sdf, const int32_t* d_edges, size_t n_out_verts, const float* d_grad_verts,
+                       float* d_grad_pos, float* d_grad_sdf, void* stream) {
+    if (n_out_verts == 0) return MVE_OK;
+    MVE_CHECK(d_pos && d_sdf && d_edges && d_grad_verts && (d_grad_pos || d_grad_sdf), MVE_ERR_ARG, "dmtet_backward: null pointer");
+    k_dmtet_backward<<<(unsigned)((n_out_verts + DB - 1) / DB), DB, 0, (hipStream_t)stream>>>(d_pos, d_sdf, d_edges, (int)n_out_verts, d_grad_verts,
+                                                                                               d_grad_pos, d_grad_sdf);
+    MVE_LAUNCH_CHECK();
     return MVE_OK;
 }
 

@@ -258,22 +258,51 @@ class Mesh:
         self.textureless = albedo is None
 
 
+class _DMTetFn(torch.autograd.Function):
+    """verts = DMTet(pos, sdf) with the native backward (d verts -> d pos, d sdf); faces carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, dm, pos, sdf, tets32):
+        verts, faces, edges = dm._extract(pos, sdf, tets32, want_edges=True)
+        ctx.save_for_backward(pos, sdf, edges)
+        ctx.mark_non_differentiable(faces)
+        return verts, faces
+
+    @staticmethod
+    def backward(ctx, g_verts, _g_faces):
+        pos, sdf, edges = ctx.saved_tensors
+        g_pos, g_sdf = torch.zeros_like(pos), torch.zeros_like(sdf)
+        g = g_verts.float().contiguous()
+        with torch.cuda.device(pos.device):
+            _lib.call('mve_dmtet_backward', _lib.ptr(pos), _lib.ptr(sdf), _lib.ptr(edges), edges.shape[0], _lib.ptr(g), _lib.ptr(g_pos),
+                      _lib.ptr(g_sdf), _lib.stream_ptr(pos.device))
+        return None, g_pos, g_sdf, None
+
+
 class DMTet:
     """Mirror of the reference's DMTet (base_mesh_renderer.py:104-188): `DMTet(device)(pos_nx3, sdf_n, tet_fx4) -> verts, faces`.
-    Inference-only (the reference differentiates verts w.r.t. pos/sdf; the backward is SURVEY section 8(f) rank 1 material)."""
+    When pos or sdf require grad the vertices carry autograd history (native backward), as in the reference's mesh optimisation."""
 
     def __init__(self, device='cuda'):
         self.device = torch.device(device)
         self._tets_key, self._tets32 = None, None
 
     def __call__(self, pos_nx3, sdf_n, tet_fx4):
-        pos = pos_nx3.detach().to(self.device, torch.float32).contiguous()
-        sdf = sdf_n.detach().to(self.device, torch.float32).contiguous()
         key = (tet_fx4.data_ptr(), tuple(tet_fx4.shape), tet_fx4.dtype)
         if key != self._tets_key:                                   # the tet grid is constant across iterations: convert once
             self._tets32 = tet_fx4.to(self.device, torch.int32).contiguous()
             self._tets_key = key
-        tets = self._tets32
+        if torch.is_grad_enabled() and (pos_nx3.requires_grad or sdf_n.requires_grad):
+            pos = pos_nx3.to(self.device, torch.float32).contiguous()
+            sdf = sdf_n.to(self.device, torch.float32).contiguous()
+            verts, faces = _DMTetFn.apply(self, pos, sdf, self._tets32)
+            return verts, faces.long()
+        verts, faces, _ = self._extract(pos_nx3.detach().to(self.device, torch.float32).contiguous(),
+                                        sdf_n.detach().to(self.device, torch.float32).contiguous(), self._tets32)
+        return verts, faces.long()
+
+    def _extract(self, pos, sdf, tets, want_edges=False):
+        pos, sdf = pos.detach(), sdf.detach()
         nv, nt = pos.shape[0], tets.shape[0]
         nbytes = _lib.raw('mve_dmtet_workspace_bytes')(nv, nt)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -284,6 +313,7 @@ class DMTet:
             n_verts, n_faces = (int(x) for x in counts.tolist())     # one host read, as march_rays_train
             verts = torch.empty(n_verts, 3, dtype=torch.float32, device=self.device)
             faces = torch.empty(n_faces, 3, dtype=torch.int32, device=self.device)
+            edges = torch.empty(n_verts, 2, dtype=torch.int32, device=self.device) if want_edges else None
             _lib.call('mve_dmtet_write', _lib.ptr(pos), _lib.ptr(sdf), _lib.ptr(tets), nv, nt, _lib.ptr(verts), _lib.ptr(faces),
-                      _lib.ptr(ws), nbytes, sp)
-        return verts, faces.long()
+                      _lib.ptr(edges), _lib.ptr(ws), nbytes, sp)
+        return verts, faces, edges

@@ -68,3 +68,25 @@ def test_gpu_large_grid_and_edge_cases(lib):
         vo, fo = DO.dmtet(p4.numpy(), s.numpy(), t4.numpy())
         vh, fh = dm(p4, s, t4)
         assert (vh.cpu().numpy() == vo).all() and (fh.cpu().numpy() == fo).all(), code
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,seed', [(10, 0), (16, 1)])
+def test_gpu_backward_matches_reference_autograd(lib, n, seed):
+    """d verts -> d pos, d sdf against the gradients the REFERENCE class produces through torch autograd (golden file)."""
+    from mvedit_amd.mesh_ops import DMTet
+    g = np.load(GOLD)
+    pos, tets = tet_grid(n)
+    tp = torch.from_numpy(pos).cuda().requires_grad_(True)
+    ts = torch.from_numpy(blob_sdf(pos, seed)).cuda().requires_grad_(True)
+    v, f = DMTet('cuda')(tp, ts, torch.from_numpy(tets))
+    assert v.requires_grad and (v.detach().cpu().numpy() == g[f'verts_{n}']).all() and (f.cpu().numpy() == g[f'faces_{n}']).all()
+    R = torch.from_numpy(np.random.default_rng(7).standard_normal(tuple(v.shape)).astype(np.float32)).cuda()
+    (v * R).sum().backward()
+    for got, want, name in ((tp.grad, g[f'grad_pos_{n}'], 'pos'), (ts.grad, g[f'grad_sdf_{n}'], 'sdf')):
+        want_t = torch.from_numpy(want)
+        scale = want_t.abs().max().item()
+        assert scale > 0 and (got.cpu() - want_t).abs().max().item() <= 1e-5 * scale, name      # float atomics: summation order only
+    # no grad requested -> plain tensors
+    v2, _ = DMTet('cuda')(tp.detach(), ts.detach(), torch.from_numpy(tets))
+    assert not v2.requires_grad
