@@ -461,6 +461,18 @@ MVE_API int mve_dmtet_write(const float* d_pos, const float* d_sdf, const int32_
 MVE_API int mve_dmtet_backward(const float* d_pos, const float* d_sdf, const int32_t* d_edges, size_t n_out_verts,
                                const float* d_grad_verts, float* d_grad_pos, float* d_grad_sdf, void* stream);
 
+/* Backward of the render ops w.r.t. their colour-like input (mesh half).  The forward ops are linear in
+ * that input, so these are their exact transposes; geometry (rast, pos) carries no gradient.
+ *   interpolate_backward      : d_grad_attr [Battr,V,A] += barycentric weights * d_grad_out [B,h,w,A]   (accumulates; float atomics)
+ *   texture_bilinear_backward : d_grad_tex [Bt,th,tw,C] += bilinear weights * d_grad_out [n,h,w,C]      (accumulates; float atomics)
+ *   antialias_backward        : d_grad_color [B,h,w,C] = transpose of mve_antialias applied to d_grad_out (overwrites; deterministic) */
+MVE_API int mve_interpolate_backward(const float* d_grad_out, int Battr, int Vattr, int A, const float* d_rast, int B, int H, int W,
+                                     const int32_t* d_tri, int F, float* d_grad_attr, void* stream);
+MVE_API int mve_texture_bilinear_backward(const float* d_grad_out, int Bt, int th, int tw, int C, const float* d_uv, const float* d_rast,
+                                          int n, int h, int w, float* d_grad_tex, void* stream);
+MVE_API int mve_antialias_backward(const float* d_grad_out, int B, int H, int W, int C, const float* d_rast, const float* d_pos, int V,
+                                   const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_color, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

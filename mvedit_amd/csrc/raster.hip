@@ -669,3 +669,124 @@ int mve_box_downsample(const float* d_x, int B, int H, int W, int C, int factor,
 }
 
 }  // extern "C"
+
+// =========================================================================================================
+// Backward of the linear render ops w.r.t. their colour-like input (mesh half): what optimising a
+// texture map or vertex colours through MeshRenderer.forward needs.  All three forward ops are LINEAR in that input, so each
+// backward is the exact transpose (tests check <forward(x), g> == <x, backward(g)>).  Geometry (rast, positions) carries no
+// gradient here.
+//   interpolate : d attr[vertex] += barycentric weight * d out[pixel]                       (float atomics)
+//   texture     : d tex[texel]   += bilinear weight   * d out[pixel]                        (float atomics)
+//   antialias   : gathered per input pixel from its four neighbours -- deterministic, no atomics
+// =========================================================================================================
+namespace {
+
+__global__ __launch_bounds__(RB) void k_interpolate_bwd(const float* __restrict__ g_out, int Battr, int Vattr, int A, const float* __restrict__ rast,
+                                                        int B, size_t npix, const int32_t* __restrict__ tri, int F, float* __restrict__ g_attr) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= (size_t)B * npix) return;
+    const f32x4 r = reinterpret_cast<const f32x4*>(rast)[i];
+    const int id = (int)r[3] - 1;
+    if (id < 0 || id >= F) return;
+    const int b = (int)(i / npix);
+    float* at = g_attr + (Battr > 1 ? (size_t)b * Vattr * A : 0);
+    const float u = r[0], v = r[1], w = 1.0f - u - v;
+    float* a0 = at + (size_t)tri[3 * id] * A;
+    float* a1 = at + (size_t)tri[3 * id + 1] * A;
+    float* a2 = at + (size_t)tri[3 * id + 2] * A;
+    const float* g = g_out + i * A;
+    for (int a = 0; a < A; ++a) {
+        const float ga = g[a];
+        atomicAdd(a0 + a, u * ga); atomicAdd(a1 + a, v * ga); atomicAdd(a2 + a, w * ga);
+    }
+}
+
+__global__ __launch_bounds__(RB) void k_texture_bilinear_bwd(const float* __restrict__ g_out, int Bt, int th, int tw, int C, const float* __restrict__ uv,
+                                                             const float* __restrict__ rast, size_t npix_total, size_t npix_view,
+                                                             float* __restrict__ g_tex) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= npix_total) return;
+    if (rast && !(rast[4 * i + 3] > 0.0f)) return;
+    float* t = g_tex + (Bt > 1 ? (i / npix_view) * (size_t)th * tw * C : 0);
+    int ix[2], iy[2];
+    float wx[2], wy[2];
+    bilinear_taps(uv[2 * i], uv[2 * i + 1], tw, th, ix, iy, wx, wy);
+    const float* g = g_out + i * C;
+    for (int c = 0; c < C; ++c) {
+        const float gc = g[c];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) atomicAdd(t + ((size_t)iy[j] * tw + ix[k]) * C + c, (wx[k] * wy[j]) * gc);
+    }
+}
+
+// forward: out[p] = in[p] + sum_{k: p receives} w_k (in[q_k] - in[p]).  Transpose, gathered at input pixel q:
+//   g_in[q] = g[q] (1 - sum_{k: q receives} w_k) + sum_{neighbours p that receive from q} w(p,q) g[p]
+__global__ __launch_bounds__(RB) void k_antialias_bwd(const float* __restrict__ g_out, int B, int H, int W, int C, const float* __restrict__ rast,
+                                                      const float* __restrict__ pos, int V, const int32_t* __restrict__ tri, int F,
+                                                      const int32_t* __restrict__ opp, float* __restrict__ g_in) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    const size_t npix = (size_t)H * W;
+    if (i >= (size_t)B * npix) return;
+    const int b = (int)(i / npix), y = (int)((i % npix) / W), x = (int)(i % W);
+    AAView a{rast + (size_t)b * npix * 4, pos + (size_t)b * V * 4, tri, opp, V, F, H, W};
+    const float* g = g_out + (size_t)b * npix * C;
+    const float* gs = g + ((size_t)y * W + x) * C;
+    float* dst = g_in + i * C;
+    float keep = 1.0f;
+    for (int c = 0; c < C; ++c) dst[c] = 0.0f;
+    const int ddx[4] = {-1, 1, 0, 0}, ddy[4] = {0, 0, -1, 1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qx = x + ddx[k], qy = y + ddy[k];
+        if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+        bool dst_is_p;
+        float w;
+        if (!aa_pair(a, x, y, qx, qy, dst_is_p, w)) continue;      // the pair rule is symmetric in which pixel asks
+        if (dst_is_p) {
+            keep -= w;                                               // this pixel received from the neighbour
+        } else {
+            const float* gn = g + ((size_t)qy * W + qx) * C;         // the neighbour received from this pixel
+            for (int c = 0; c < C; ++c) dst[c] += w * gn[c];
+        }
+    }
+    for (int c = 0; c < C; ++c) dst[c] += keep * gs[c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int mve_interpolate_backward(const float* d_grad_out, int Battr, int Vattr, int A, const float* d_rast, int B, int H, int W,
+                             const int32_t* d_tri, int F, float* d_grad_attr, void* stream) {
+    const size_t n = (size_t)B * H * W;
+    if (n == 0 || A == 0) return MVE_OK;
+    MVE_CHECK(d_grad_out && d_rast && d_tri && d_grad_attr && (Battr == 1 || Battr == B), MVE_ERR_ARG, "interpolate_backward: bad arguments");
+    k_interpolate_bwd<<<mve_cdiv(n, RB), RB, 0, (hipStream_t)stream>>>(d_grad_out, Battr, Vattr, A, d_rast, B, (size_t)H * W, d_tri, F, d_grad_attr);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_texture_bilinear_backward(const float* d_grad_out, int Bt, int th, int tw, int C, const float* d_uv, const float* d_rast, int n, int h,
+                                  int w, float* d_grad_tex, void* stream) {
+    const size_t total = (size_t)n * h * w;
+    if (total == 0 || C == 0) return MVE_OK;
+    MVE_CHECK(d_grad_out && d_uv && d_grad_tex && th > 0 && tw > 0 && (Bt == 1 || Bt == n), MVE_ERR_ARG, "texture_bilinear_backward: bad arguments");
+    k_texture_bilinear_bwd<<<mve_cdiv(total, RB), RB, 0, (hipStream_t)stream>>>(d_grad_out, Bt, th, tw, C, d_uv, d_rast, total, (size_t)h * w, d_grad_tex);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_antialias_backward(const float* d_grad_out, int B, int H, int W, int C, const float* d_rast, const float* d_pos, int V,
+                           const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_color, void* stream) {
+    const size_t total = (size_t)B * H * W;
+    if (total == 0 || C == 0) return MVE_OK;
+    MVE_CHECK(d_grad_out && d_rast && d_pos && d_tri && d_opp && d_grad_color && d_grad_color != d_grad_out, MVE_ERR_ARG,
+              "antialias_backward: bad arguments");
+    k_antialias_bwd<<<mve_cdiv(total, RB), RB, 0, (hipStream_t)stream>>>(d_grad_out, B, H, W, C, d_rast, d_pos, V, d_tri, F, d_opp, d_grad_color);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+}  // extern "C"

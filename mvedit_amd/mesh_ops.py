@@ -37,9 +37,35 @@ def rasterize(pos, tri, resolution):
     return rast
 
 
+class _InterpolateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri):
+        ctx.save_for_backward(rast, tri)
+        ctx.attr_shape = tuple(attr.shape)
+        return _interpolate_raw(attr, rast, tri)
+
+    @staticmethod
+    def backward(ctx, g):
+        rast, tri = ctx.saved_tensors
+        Ba, V, A = ctx.attr_shape
+        B, h, w, _ = rast.shape
+        g_attr = torch.zeros(Ba, V, A, dtype=torch.float32, device=rast.device)
+        g = g.float().contiguous()
+        with torch.cuda.device(rast.device):
+            _lib.call('mve_interpolate_backward', _lib.ptr(g), Ba, V, A, _lib.ptr(rast), B, h, w, _lib.ptr(tri), tri.shape[0], _lib.ptr(g_attr),
+                      _lib.stream_ptr(rast.device))
+        return g_attr, None, None
+
+
 def interpolate(attr, rast, tri):
-    """dr.interpolate(attr, rast, tri)[0]: attr [1 or B, V, A] -> [B,h,w,A]."""
-    attr = attr.float().contiguous()
+    """dr.interpolate(attr, rast, tri)[0]: attr [1 or B, V, A] -> [B,h,w,A].  Differentiable w.r.t. attr."""
+    if torch.is_grad_enabled() and attr.requires_grad:
+        return _InterpolateFn.apply(attr.float().contiguous(), rast.contiguous(), tri.to(torch.int32).contiguous())
+    return _interpolate_raw(attr, rast, tri)
+
+
+def _interpolate_raw(attr, rast, tri):
+    attr = attr.detach().float().contiguous()
     tri = tri.to(torch.int32).contiguous()
     B, h, w, _ = rast.shape
     out = torch.empty(B, h, w, attr.shape[-1], dtype=torch.float32, device=rast.device)
@@ -61,11 +87,36 @@ def edge_opposites(tri):
     return opp
 
 
+class _AntialiasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, opp):
+        ctx.save_for_backward(rast, pos, tri, opp)
+        return _antialias_raw(color, rast, pos, tri, opp)
+
+    @staticmethod
+    def backward(ctx, g):
+        rast, pos, tri, opp = ctx.saved_tensors
+        g = g.float().contiguous()
+        B, h, w, C = g.shape
+        g_in = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            _lib.call('mve_antialias_backward', _lib.ptr(g), B, h, w, C, _lib.ptr(rast), _lib.ptr(pos), pos.shape[1], _lib.ptr(tri), tri.shape[0],
+                      _lib.ptr(opp), _lib.ptr(g_in), _lib.stream_ptr(g.device))
+        return g_in, None, None, None, None
+
+
 def antialias(color, rast, pos, tri, opp=None):
-    """dr.antialias(color, rast, pos, tri): color [B,h,w,C] -> same shape (rules: oracle/raster_oracle.c)."""
-    color, rast, pos = color.float().contiguous(), rast.contiguous(), pos.float().contiguous()
+    """dr.antialias(color, rast, pos, tri): color [B,h,w,C] -> same shape (rules: oracle/raster_oracle.c).  Differentiable w.r.t. color."""
+    rast, pos = rast.contiguous(), pos.detach().float().contiguous()
     tri = tri.to(torch.int32).contiguous()
     opp = edge_opposites(tri) if opp is None else opp
+    if torch.is_grad_enabled() and color.requires_grad:
+        return _AntialiasFn.apply(color.float().contiguous(), rast, pos, tri, opp)
+    return _antialias_raw(color, rast, pos, tri, opp)
+
+
+def _antialias_raw(color, rast, pos, tri, opp):
+    color = color.detach().float().contiguous()
     B, h, w, C = color.shape
     out = torch.empty_like(color)
     with torch.cuda.device(color.device):
@@ -74,9 +125,36 @@ def antialias(color, rast, pos, tri, opp=None):
     return out
 
 
+class _TextureFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, uv, rast):
+        ctx.save_for_backward(uv, rast)
+        ctx.tex_shape = tuple(tex.shape)
+        return _texture_raw(tex, uv, rast)
+
+    @staticmethod
+    def backward(ctx, g):
+        uv, rast = ctx.saved_tensors
+        Bt, th, tw, C = ctx.tex_shape
+        n, h, w, _ = uv.shape
+        g_tex = torch.zeros(Bt, th, tw, C, dtype=torch.float32, device=uv.device)
+        g = g.float().contiguous()
+        with torch.cuda.device(uv.device):
+            _lib.call('mve_texture_bilinear_backward', _lib.ptr(g), Bt, th, tw, C, _lib.ptr(uv), _lib.ptr(rast), n, h, w, _lib.ptr(g_tex),
+                      _lib.stream_ptr(uv.device))
+        return g_tex, None, None
+
+
 def texture(tex, uv, rast=None):
-    """dr.texture(tex [1|n,th,tw,C], uv [n,h,w,2]) with the bilinear filter, wrap addressing; background -> 0 when rast is given."""
-    tex, uv = tex.float().contiguous(), uv.float().contiguous()
+    """dr.texture(tex [1|n,th,tw,C], uv [n,h,w,2]) with the bilinear filter, wrap addressing; background -> 0 when rast is given.
+    Differentiable w.r.t. tex."""
+    if torch.is_grad_enabled() and tex.requires_grad:
+        return _TextureFn.apply(tex.float().contiguous(), uv.detach().float().contiguous(), rast.contiguous() if rast is not None else None)
+    return _texture_raw(tex, uv, rast)
+
+
+def _texture_raw(tex, uv, rast=None):
+    tex, uv = tex.detach().float().contiguous(), uv.detach().float().contiguous()
     n, h, w, _ = uv.shape
     out = torch.empty(n, h, w, tex.shape[-1], dtype=torch.float32, device=uv.device)
     with torch.cuda.device(uv.device):

@@ -227,3 +227,67 @@ def test_mesh_renderer_forward_vs_oracle(lib, ssaa):
     assert seen['n'] > 100 and abs(seen['r'] - 0.6) < 0.01 and abs(seen['nn'] - 1) < 1e-3
     m = o3['rgba'][..., 3] > (0 if ssaa == 1 else 0.999)
     np.testing.assert_allclose(o2['rgba'][..., :3][m].cpu().numpy(), 0.5 * o3['rgba'][..., :3][m].cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_render_ops_backward_are_exact_transposes(lib):
+    """interpolate / texture / antialias are linear in their colour-like input, so the backward must be the transpose:
+    <forward(x), g> == <x, backward(g)> for random x, g (fp32 accumulation order is the only difference: 1e-5 relative)."""
+    from mvedit_amd.mesh_ops import MeshRenderer, rasterize, interpolate, texture, antialias
+    from scene import icosphere, face_atlas
+    v, f = icosphere(3, 0.6)
+    v = (v * (1 + 0.25 * np.sin(6 * v[:, :1]))).astype(np.float32)
+    vt, ft = face_atlas(f)
+    S, nv = 96, 3
+    poses, intr = _clip_positions(v, nv, S)
+    t = lambda a: torch.from_numpy(a).cuda()
+    mr = MeshRenderer(near=0.01, far=100)
+    _, v_clip, _ = mr.project(t(v), t(poses), t(intr), S, S)
+    rast = rasterize(v_clip, t(f), (S, S))
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).cuda()
+
+    def adjoint(fwd, x):
+        x = x.clone().requires_grad_(True)
+        y = fwd(x)
+        gy = rnd(*y.shape)
+        (y * gy).sum().backward()
+        lhs = (y.detach().double() * gy.double()).sum().item()
+        rhs = (x.detach().double() * x.grad.double()).sum().item()
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+        assert x.grad.abs().sum() > 0
+    adjoint(lambda a: interpolate(a, rast, t(f)), rnd(1, v.shape[0], 5))                     # shared attributes
+    adjoint(lambda a: interpolate(a, rast, t(f)), rnd(nv, v.shape[0], 3))                    # per-view attributes
+    texc = interpolate(t(vt)[None], rast, t(ft))
+    adjoint(lambda tex: texture(tex, texc, rast), rnd(1, 64, 48, 3))
+    adjoint(lambda col: antialias(col, rast, v_clip, t(f)), rnd(nv, S, S, 8))
+
+
+@pytest.mark.gpu
+def test_texture_fitting_through_mesh_renderer(lib):
+    """The texture pipeline's inner loop in miniature: optimise an albedo map through MeshRenderer.forward (texture fetch +
+    antialias, native backward) with a stock torch optimiser until the renders match those of a ground-truth texture."""
+    from mvedit_amd.mesh_ops import MeshRenderer, Mesh
+    from scene import icosphere, face_atlas
+    v, f = icosphere(3, 0.6)
+    vn = (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+    vt, ft = face_atlas(f)
+    S, nv = 64, 6
+    poses, intr = _clip_positions(v, nv, S)
+    t = lambda a: torch.from_numpy(a).cuda()
+    mr = MeshRenderer(near=0.01, far=100)
+    gt = torch.rand(48, 48, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    mk = lambda alb: Mesh(t(v), t(f), t(vt), t(ft), vn=t(vn), fn=t(f), albedo=alb)
+    with torch.no_grad():
+        target = mr([mk(gt)], t(poses)[None], t(intr)[None], S, S)['rgba'][..., :3]
+    tex = torch.full((48, 48, 3), 0.5, device='cuda', requires_grad=True)
+    opt = torch.optim.Adam([tex], lr=5e-2)
+    losses = []
+    for it in range(60):
+        opt.zero_grad()
+        out = mr([mk(tex)], t(poses)[None], t(intr)[None], S, S)['rgba'][..., :3]
+        loss = ((out - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.05 * losses[0], (losses[0], losses[-1])
