@@ -231,7 +231,7 @@ class VolumeRenderer:
     """Mirror of the reference's VolumeRenderer for ONE scene with an iNGP decoder: the eval branch (fused, see
     INGPDecoderParams.render_rays), the train-branch FORWARD (march -> density -> cull -> decode -> composite,
     lib/models/decoders/base_volume_renderer.py:207-262) and `update_extra_state` (:105-177).
-    The backward of the train branch (hash-grid / MLP gradients) is SURVEY section 8(f) rank 1 and not part of this class."""
+    With requires_grad decoder parameters the training forward is differentiable (native decode / composite backward)."""
 
     def __init__(self, decoder, weight_culling_th=1e-3):
         self.decoder = decoder
@@ -287,6 +287,8 @@ class VolumeRenderer:
             sigmas, _ = dec.point_decode(xyzs, density_only=True)
             weights, _, _, _ = rm.batch_composite_rays_train(sigmas, sigmas.new_zeros(sigmas.shape[0], 3), [ts], [rays], [ts.shape[0]])
             xyzs, dirs, ts, rays = rm.cull_samples(weights, self.weight_culling_th, xyzs, dirs, ts, rays)
-        sigmas, rgbs = dec.point_decode(xyzs)
+        # with requires_grad parameters the outputs carry autograd history (native backward for decode and composite)
+        differentiable = torch.is_grad_enabled() and any(t.requires_grad for t in dec.parameters().values())
+        sigmas, rgbs = dec.point_decode_autograd(xyzs) if differentiable else dec.point_decode(xyzs)
         weights, weights_sum, depth, image = rm.batch_composite_rays_train(sigmas, rgbs, [ts], [rays], [ts.shape[0]])
         return dict(weights=weights, weights_sum=weights_sum, depth=depth, image=image, rays=[rays], normal=None, ts=[ts])

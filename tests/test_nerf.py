@@ -377,3 +377,24 @@ def test_gpu_point_decode_autograd_with_torch_optimizer(lib):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.3 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.gpu
+def test_gpu_volume_renderer_training_forward_is_differentiable(lib):
+    """VolumeRenderer.forward in training mode with requires_grad parameters: culling runs without grad (as in the reference,
+    base_volume_renderer.py:223), the final decode + composite carry autograd history down to the hash table."""
+    from mvedit_amd.nerf import VolumeRenderer
+    p, dec = _decoder(12, 320, table_scale=0.5)
+    H = 64
+    bits = torch.from_numpy(ORM.packbits(sphere_density_grid(H, radius=0.55), 0.5)).cuda()
+    o, d = scene_rays(1, 32, seed=8)
+    dec.max_steps = 256
+    for t in dec.parameters().values():
+        t.requires_grad_(True)
+    vr = VolumeRenderer(dec)
+    vr.training = True
+    out = vr.forward(torch.from_numpy(o), torch.from_numpy(d), bits, H, dt_gamma=0.0)
+    loss = out['image'][0].sum() + out['weights_sum'][0].sum() + out['depth'][0].sum()
+    loss.backward()
+    for k, t in dec.parameters().items():
+        assert t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0, k
