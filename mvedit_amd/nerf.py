@@ -284,9 +284,10 @@ class VolumeRenderer:
         xyzs, dirs, ts, rays = rm.march_rays_train(rays_o, rays_d, self.bound, density_bitfield, 1, grid_size, nears, fars,
                                                    perturb=perturb, dt_gamma=float(dt_gamma), max_steps=self.max_steps, noises=noises)
         if self.weight_culling_th > 0:
-            sigmas, _ = dec.point_decode(xyzs, density_only=True)
-            weights, _, _, _ = rm.batch_composite_rays_train(sigmas, sigmas.new_zeros(sigmas.shape[0], 3), [ts], [rays], [ts.shape[0]])
-            xyzs, dirs, ts, rays = rm.cull_samples(weights, self.weight_culling_th, xyzs, dirs, ts, rays)
+            with torch.no_grad():                                      # base_volume_renderer.py:223
+                sigmas, _ = dec.point_decode(xyzs, density_only=True)
+                weights, _, _, _ = rm.batch_composite_rays_train(sigmas, sigmas.new_zeros(sigmas.shape[0], 3), [ts], [rays], [ts.shape[0]])
+                xyzs, dirs, ts, rays = rm.cull_samples(weights, self.weight_culling_th, xyzs, dirs, ts, rays)
         # with requires_grad parameters the outputs carry autograd history (native backward for decode and composite)
         differentiable = torch.is_grad_enabled() and any(t.requires_grad for t in dec.parameters().values())
         sigmas, rgbs = dec.point_decode_autograd(xyzs) if differentiable else dec.point_decode(xyzs)
