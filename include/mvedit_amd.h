@@ -45,7 +45,7 @@ typedef enum {
 } mve_dtype;
 
 MVE_API const char* mve_last_error(void);
-MVE_API int mve_version(void);                 /* ABI version, bumped on breaking change */
+MVE_API int mve_version(void);                 /* ABI version, bumped on breaking change (library housekeeping: no reference counterpart) */
 MVE_API int mve_device_info(int* n_cu, int* wave_size, char* arch, int arch_len); /* hipGetDeviceProperties of the current device */
 
 /* =========================================================================
@@ -166,7 +166,10 @@ MVE_API int mve_density_grid_update(float* d_density_grid, float* d_tmp_grid, ui
 #define MVE_GEMM_NO_SPLITK 8 /* never split K even if a workspace is given */
 #define MVE_GEMM_RES_AFTER_SCALE 16   /* out = (acc + bias) * out_scale + residual (default: residual is added before the scale) */
 
-/* out[m][n] = out_scale * ( sum_k A[m][k]*W[n][k] + bias[n] + rowvec[m/rows_per_vec][n] + residual[m][n] )
+/* Every Linear / 1x1 Conv2d of the UNet (diffusers Attention, FeedForward, ResnetBlock2D shortcut, Transformer2DModel proj_in/out,
+ * TimestepEmbedding; reached through lib/models/architecture/diffusers.py:69-97, :124-162 and the vendored processors,
+ * lib/models/architecture/ip_adapter/attention_processor.py:236-262) with its bias / residual / GEGLU epilogue fused:
+ * out[m][n] = out_scale * ( sum_k A[m][k]*W[n][k] + bias[n] + rowvec[m/rows_per_vec][n] + residual[m][n] )
  * A: [M][lda] dtype, W: [N][ldw] dtype (torch Linear / 1x1-conv layout; ldw > K selects a column block),
  * out: [M][ldc]; bias: [N] f32 or NULL; rowvec: [ceil(M/rows_per_vec)][ldrv] f32 or NULL (the per-image time
  * embedding of ResnetBlock2D); residual: [M][ldr] dtype or NULL.  N, K, lda, ldw, ldr multiples of 8. */
@@ -180,7 +183,7 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int l
  * value only queries.  Returns the previous setting.  The default comes from the environment variable MVE_GEMM_BIG. */
 MVE_API int mve_gemm_tune(int big_min_blocks);
 
-/* Split-K: at the deep UNet levels one image contributes only a few output tiles while K = 9*1280..9*2560; K is then cut
+/* (No reference counterpart: scheduling detail of mve_gemm / mve_conv3x3.)  Split-K: at the deep UNet levels one image contributes only a few output tiles while K = 9*1280..9*2560; K is then cut
  * into slices that run concurrently and are summed in a fixed order by a second launch.  The slice count depends on
  * (rows_per_image, N, K) only -- never on the batch -- so results are bit-identical however views are chunked or
  * partitioned across GPUs.  It needs an fp32 scratch of mve_gemm_workspace_bytes(...) bytes (0 = this shape never
@@ -229,7 +232,8 @@ MVE_API int mve_groupnorm_silu(int dtype, const void* d_x1, int C1, const void* 
                                float eps, const float* d_gamma, const float* d_beta, int silu, void* d_out,
                                void* d_workspace, void* stream);
 
-/* LayerNorm over the last axis of x[M][ldx] (C <= 2048, C % 8 == 0); gamma/beta f32 [C]. */
+/* LayerNorm over the last axis of x[M][ldx] (C <= 2048, C % 8 == 0); gamma/beta f32 [C]: BasicTransformerBlock.norm1/2/3 of
+ * diffusers 0.27.2, reached through the Transformer2DModel calls at lib/models/architecture/diffusers.py:91-96, :128-133, :150-155. */
 MVE_API int mve_layernorm(int dtype, const void* d_x, int ldx, void* d_y, int ldy, int M, int C,
                           const float* d_gamma, const float* d_beta, float eps, void* stream);
 
@@ -270,8 +274,8 @@ MVE_API int mve_unet_load_param(void* handle, const char* name, const void* d_sr
 /* returns the number of diffusers parameters not loaded yet; buf receives the first missing name */
 MVE_API int mve_unet_missing_params(void* handle, char* buf, int buf_len);
 
-/* Builds (and caches) the static op list for this problem size.  flops[5] = analytic 2*MAC counts per class
- * {conv3x3, linear/1x1, attention, norm, other}. */
+/* (No reference counterpart: executor introspection.)  Builds (and caches) the static op list for this problem size.
+ * flops[5] = analytic 2*MAC counts per class {conv3x3, linear/1x1, attention, norm, other}; SURVEY.md section 8(d) quotes their sum. */
 MVE_API int mve_unet_plan(void* handle, int B, int H, int W, int ctx_len, int num_cross_attn_imgs, int has_residuals,
                           int io_dtype, int residuals_nhwc, size_t* workspace_bytes, int* n_ops, double* flops);
 
@@ -322,7 +326,8 @@ MVE_API int mve_unet_set_attention(void* handle, int ip_tokens, float ip_scale, 
                                    void* d_ref_store, size_t ref_store_bytes);
 MVE_API size_t mve_unet_ref_store_bytes(void* handle, int B, int ref_H, int ref_W, int ref_skip);
 
-/* op i of the cached plan: class, flops, label; returns 1 if the op belongs to unet_enc, 2 for unet_dec */
+/* (No reference counterpart: executor introspection, the source of bench.py's per-kernel roofline figures.)
+ * op i of the cached plan: class, flops, label; returns 1 if the op belongs to unet_enc, 2 for unet_dec */
 MVE_API int mve_unet_op_info(void* handle, int i, int* cls, double* flops, char* label, int label_len);
 
 /* =========================================================================
@@ -399,12 +404,14 @@ MVE_API int mve_edge_dilation(const float* d_img, const float* d_mask, int n, in
  *    lib/models/decoders/mesh_renderer/base_mesh_renderer.py:240-252; coverage rules specified in oracle/raster_oracle.c).
  * ========================================================================= */
 
-/* pos: [B][V][4] clip-space f32, tri: [F][3] i32 -> rast [B][H][W][4] = (u, v, z/w, triangle_id+1), 0 where empty.
+/* dr.rasterize(glctx, pos, tri, (H, W)) as called at base_mesh_renderer.py:240-241, :521, :543:
+ * pos: [B][V][4] clip-space f32, tri: [F][3] i32 -> rast [B][H][W][4] = (u, v, z/w, triangle_id+1), 0 where empty.
  * Row 0 is y_ndc = -1 (OpenGL orientation).  d_workspace: >= mve_rasterize_workspace_bytes(B,H,W,F). */
 MVE_API size_t mve_rasterize_workspace_bytes(int B, int H, int W, int F);
 MVE_API int mve_rasterize(const float* d_pos, int B, int V, const int32_t* d_tri, int F, int H, int W, float* d_rast,
                           void* d_workspace, size_t workspace_bytes, void* stream);
-/* dr.interpolate: attr [Battr][Vattr][A] (Battr 1 broadcasts), tri [F][3] indexes attr; out [B][H][W][A], 0 where empty */
+/* dr.interpolate(attr, rast, tri)[0] (base_mesh_renderer.py:246-252, :259, :265, :273, :545, :556, :573):
+ * attr [Battr][Vattr][A] (Battr 1 broadcasts), tri [F][3] indexes attr; out [B][H][W][A], 0 where empty */
 MVE_API int mve_interpolate(const float* d_attr, int Battr, int Vattr, int A, const float* d_rast, int B, int H, int W,
                             const int32_t* d_tri, int F, float* d_out, void* stream);
 
@@ -461,7 +468,9 @@ MVE_API int mve_dmtet_write(const float* d_pos, const float* d_sdf, const int32_
 MVE_API int mve_dmtet_backward(const float* d_pos, const float* d_sdf, const int32_t* d_edges, size_t n_out_verts,
                                const float* d_grad_verts, float* d_grad_pos, float* d_grad_sdf, void* stream);
 
-/* Backward of the render ops w.r.t. their colour-like input (mesh half).  The forward ops are linear in
+/* Backward of the render ops w.r.t. their colour-like input (mesh half): what nvdiffrast's autograd supplies
+ * when the reference optimises textures / vertex colours through MeshRenderer.forward (lib/pipelines/mvedit_3d_pipeline.py:716-847,
+ * lib/pipelines/mvedit_texture_pipeline.py optimisation loop).  The forward ops are linear in
  * that input, so these are their exact transposes; geometry (rast, pos) carries no gradient.
  *   interpolate_backward      : d_grad_attr [Battr,V,A] += barycentric weights * d_grad_out [B,h,w,A]   (accumulates; float atomics)
  *   texture_bilinear_backward : d_grad_tex [Bt,th,tw,C] += bilinear weights * d_grad_out [n,h,w,C]      (accumulates; float atomics)
