@@ -422,7 +422,7 @@ __global__ __launch_bounds__(NB, 4) void k_point_decode2(DecoderParams p, const 
 }
 
 template <int NL>
-__global__ __launch_bounds__(NB, 4) void k_render_rays2(DecoderParams dp, MarchParams mp, const float* __restrict__ rays_o,
+__global__ __launch_bounds__(NB, 3) void k_render_rays2(DecoderParams dp, MarchParams mp, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d, const float* __restrict__ aabb,
                                                         uint32_t N, float min_near, float T_thresh,
                                                         float* __restrict__ weights_sum, float* __restrict__ depth,
