@@ -261,6 +261,78 @@ class MeshRenderer:
     __call__ = forward
 
     # ---------------------------------------------------------------------------------------------------------------
+    def bake_xyz_shading_fun(self, meshes, shading_fun, map_size=1024, force_auto_uv=False, dilation_iters=7):
+        """base_mesh_renderer.py:397-423: evaluate `shading_fun(world_pos=...)` at the surface point behind every texel of the
+        UV atlas and store the result as the albedo map.  (mesh.auto_uv -- xatlas -- is mesh I/O and out of scope: the mesh must
+        carry vt / ft.)"""
+        assert len(meshes) == 1, 'only support one mesh'
+        mesh = meshes[0]
+        assert mesh.vt is not None and not force_auto_uv, 'UV unwrapping (mesh.auto_uv) is not part of this engine'
+        assert len(mesh.ft) == len(mesh.f)
+        vt = mesh.vt.float().contiguous()
+        vt_clip = torch.cat([vt * 2 - 1, vt.new_tensor([[0., 1.]]).expand(vt.size(0), -1)], dim=-1)
+        rast = rasterize(vt_clip[None], mesh.ft, (map_size, map_size))
+        valid = rast[0, ..., 3] > 0
+        xyz = interpolate(mesh.v.detach().float()[None], rast, mesh.f)[0]
+        rgb = shading_fun(world_pos=xyz[valid])
+        albedo = xyz.new_zeros((map_size, map_size, 3))
+        albedo[valid] = rgb.float()
+        albedo = edge_dilation(albedo.permute(2, 0, 1)[None], valid[None, None].float(), iters=dilation_iters)[0].permute(1, 2, 0)
+        mesh.albedo = torch.cat([albedo.clamp(min=0, max=1), torch.ones_like(albedo[..., :1])], dim=-1)
+        mesh.textureless = False
+        return [mesh]
+
+    def _view_batch(self, v, f, vt, ft, poses, intrinsics, alphas, h, w, map_size, cos_weight_pow):
+        """Per-view geometry shared by bake_multiview and get_cam_weights_uv (base_mesh_renderer.py:441-481 == :527-566):
+        -> (visibility u64 fixed point [bs,map,map], eroded cos^pow * alpha weight image [bs,h,w], v_img [bs,V,2])."""
+        dev = v.device
+        bs = poses.shape[0]
+        sp = _lib.stream_ptr(dev)
+        v_cam, v_clip, _ = self.project(v, poses, intrinsics, h, w)
+        rast = rasterize(v_clip, f, (h, w))
+        texc = interpolate(vt[None], rast, ft)
+        depth = 1 / interpolate(-v_cam[..., 2:3].contiguous(), rast, f)[..., 0]
+        depth = depth.masked_fill(~(rast[..., 3] > 0), 0).contiguous()
+        v_img = (v_clip[..., :2] / v_clip[..., 3:] * 0.5 + 0.5).contiguous()
+        vis = torch.empty(bs, map_size, map_size, dtype=torch.int64, device=dev)
+        tmp = torch.empty(bs, h, w, dtype=torch.float32, device=dev)
+        w_img = torch.empty_like(tmp)
+        alpha_b, intr_b = alphas.float().contiguous(), intrinsics.float().contiguous()
+        with torch.cuda.device(dev):
+            _lib.call('mve_splat_visibility', _lib.ptr(texc), _lib.ptr(rast), bs, h, w, map_size, _lib.ptr(vis), sp)
+            _lib.call('mve_view_weight', _lib.ptr(depth), _lib.ptr(alpha_b), _lib.ptr(intr_b), bs, h, w, float(cos_weight_pow),
+                      _lib.ptr(tmp), _lib.ptr(w_img), sp)
+        return vis, w_img, v_img
+
+    def get_cam_weights_uv(self, meshes, poses, intrinsics, alphas=None, render_size=512, map_size=1024, render_bs=8, cos_weight_pow=1.0):
+        """base_mesh_renderer.py:425-505: per-view, per-texel blending weights (cos^pow of the viewing angle, eroded, fetched at the
+        texel's projection, times the texel's visibility footprint) -> (weights [1,n,map,map,1], valid [1,map,map])."""
+        assert len(meshes) == 1, 'only support one mesh'
+        mesh = meshes[0]
+        n = max(poses.size(-3), intrinsics.size(-2))
+        poses = poses[0].expand(n, -1, -1).float()
+        intrinsics = intrinsics[0].expand(n, -1).float().contiguous()
+        if alphas is not None:
+            _, h, w, _ = alphas.size()
+            assert render_size == h == w
+        else:
+            h = w = render_size
+            alphas = torch.ones((n, h, w, 1), device=poses.device, dtype=torch.float32)
+        v, f = mesh.v.detach().float(), mesh.f.to(torch.int32).contiguous()
+        vt, ft = mesh.vt.float().contiguous(), mesh.ft.to(torch.int32).contiguous()
+        vt_clip = torch.cat([vt * 2 - 1, vt.new_tensor([[0., 1.]]).expand(vt.size(0), -1)], dim=-1)
+        tex_rast = rasterize(vt_clip[None], ft, (map_size, map_size))
+        valid = tex_rast[0, ..., 3] > 0
+        out = []
+        for i0 in range(0, n, render_bs):
+            sl = slice(i0, min(i0 + render_bs, n))
+            bs = sl.stop - sl.start
+            vis, w_img, v_img = self._view_batch(v, f, vt, ft, poses[sl], intrinsics[sl], alphas[sl], h, w, map_size, cos_weight_pow)
+            imgc = interpolate(v_img, tex_rast.expand(bs, -1, -1, -1).contiguous(), f)
+            tex = texture(w_img[..., None], imgc)
+            out.append(tex * (vis.double() / 4294967296.0).float()[..., None])
+        return torch.cat(out, dim=0)[None], valid[None]
+
     def bake_multiview(self, meshes, images, alphas, poses, intrinsics, map_size=1024, cos_weight_pow=8.0, base_weight=0.0,
                        render_bs=8, return_debug=False):
         """Texture back-projection with the reference's signature (base_mesh_renderer.py:507-603).

@@ -291,3 +291,49 @@ def test_texture_fitting_through_mesh_renderer(lib):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.05 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.gpu
+def test_bake_xyz_shading_fun_and_cam_weights_uv(lib):
+    """The two remaining public methods of the reference MeshRenderer (base_mesh_renderer.py:397-505) against the oracle pieces."""
+    from mvedit_amd.mesh_ops import MeshRenderer, Mesh
+    from oracle import raster as OR, bake_oracle as BO
+    from scene import icosphere, face_atlas
+    v, f = icosphere(2, 0.6)
+    v = (v * (1 + 0.15 * np.sin(5 * v[:, :1]))).astype(np.float32)
+    vt, ft = face_atlas(f)
+    t = lambda a: torch.from_numpy(a).cuda()
+    mr = MeshRenderer(near=0.01, far=100)
+    map_size = 96
+    # ---- bake_xyz_shading_fun: colour = affine function of the surface position ----------------------------------------------
+    mesh = Mesh(t(v), t(f), t(vt), t(ft))
+    (mesh,) = mr.bake_xyz_shading_fun([mesh], lambda world_pos: world_pos * 0.5 + 0.5, map_size=map_size, dilation_iters=2)
+    vt_clip = np.concatenate([vt * 2 - 1, np.tile(np.array([[0., 1.]], np.float32), (vt.shape[0], 1))], -1)[None]
+    tex_rast = OR.rasterize(vt_clip, ft, (map_size, map_size))
+    valid = tex_rast[0, ..., 3] > 0
+    xyz = OR.interpolate(v[None], tex_rast, f)[0]
+    alb = mesh.albedo.cpu().numpy()
+    assert alb.shape == (map_size, map_size, 4) and (alb[..., 3] == 1).all() and mesh.textureless is False
+    np.testing.assert_allclose(alb[valid][:, :3], np.clip(xyz[valid] * 0.5 + 0.5, 0, 1), rtol=0, atol=2e-6)
+    assert (alb[~valid][:, :3].sum(-1) > 0).mean() > 0.3            # dilation filled texels next to the charts
+    # ---- get_cam_weights_uv ----------------------------------------------------------------------------------------------------
+    S, nv = 64, 5
+    poses, intr = _clip_positions(v, nv, S)
+    v_cam, v_clip, _ = mr.project(t(v), t(poses), t(intr), S, S)
+    wts, val = mr.get_cam_weights_uv([mesh], t(poses)[None], t(intr)[None], render_size=S, map_size=map_size, render_bs=2, cos_weight_pow=2.0)
+    assert wts.shape == (1, nv, map_size, map_size, 1) and (val[0].cpu().numpy() == valid).all()
+    vc, vcl = v_cam.cpu().numpy(), v_clip.cpu().numpy()
+    rast = OR.rasterize(vcl, f, (S, S))
+    texc = OR.interpolate(vt[None], rast, ft)
+    fg = rast[..., 3] > 0
+    with np.errstate(divide='ignore'):
+        depth = (1 / OR.interpolate(-vc[..., 2:3], rast, f)[..., 0]).astype(np.float32)
+    depth[~fg] = 0
+    wimg, _ = BO.view_weight(depth, np.ones((nv, S, S), np.float32), intr, 2.0)
+    v_img = (vcl[..., :2] / vcl[..., 3:] * 0.5 + 0.5).astype(np.float32)
+    for i in range(nv):
+        vis = BO.splat_visibility(texc[i], fg[i], map_size).astype(np.float32)
+        imgc = OR.interpolate(v_img[i:i + 1], tex_rast, f)[0]
+        ref = BO.texture_bilinear(wimg[i][..., None], imgc)[..., 0] * vis
+        np.testing.assert_allclose(wts[0, i, ..., 0].cpu().numpy(), ref, rtol=1e-3, atol=2e-5)
+    assert (wts > 0).float().mean() > 0.01
