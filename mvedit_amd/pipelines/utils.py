@@ -1,0 +1,52 @@
+"""Host-side camera bookkeeping that decides how many views a step has -- and therefore how `mvedit_amd.parallel` re-partitions
+them across GPUs: mirrors of `get_camera_dists` / `prune_cameras`
+(lib/pipelines/utils.py:350-379 of the reference, called at lib/pipelines/mvedit_3d_pipeline.py:1180-1215).  Pure torch, tiny
+tensors ([V, V] with V <= 64): no kernel here, just the same decisions as the reference so that every rank prunes identically."""
+import torch
+
+
+def rotation_to_unit_quaternion(R):
+    """R [..., 3, 3] -> unit quaternions [..., 4] (w, x, y, z), best-conditioned branch of Shepperd's method.  The sign of the
+    result is arbitrary; callers only use |q1 . q2|."""
+    m = R.reshape(R.shape[:-2] + (9,))
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.unbind(-1)
+    four = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], dim=-1)
+    cand = torch.stack([
+        torch.stack([four[..., 0], m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, four[..., 1], m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, four[..., 2], m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, four[..., 3]], dim=-1)], dim=-2)
+    best = four.argmax(dim=-1)
+    q = torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4))).squeeze(-2)
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def get_camera_dists(camera_poses, cam_weights, device):
+    """Pairwise camera distance = position distance + 4 * half the relative rotation angle, scaled by the row camera's weight,
+    with a huge diagonal so that a camera is never its own nearest neighbour (lib/pipelines/utils.py:350-363)."""
+    n = camera_poses.size(0)
+    pos = camera_poses[:, :3, 3]
+    q = rotation_to_unit_quaternion(camera_poses[:, :3, :3])
+    half_theta = torch.acos((q @ q.t()).abs().clamp(max=1))
+    dists = (pos[:, None] - pos[None]).norm(dim=-1) + 4 * half_theta
+    if cam_weights is not None:
+        dists = dists * cam_weights[:, None]
+    return dists + 999999 * torch.eye(n, dtype=dists.dtype, device=device)
+
+
+def prune_cameras(dists, num_keep_views, max_num_cameras, device, pixel_dist=None):
+    """Greedily drop the view closest to another view (never one of the first num_keep_views) until max_num_cameras remain
+    (lib/pipelines/utils.py:366-379).  Returns (keep_ids into the original numbering, reduced dists)."""
+    keep_ids = torch.arange(dists.size(0), device=device)
+    if pixel_dist is not None:
+        pixel_dist = pixel_dist.clone()
+    for _ in range(dists.size(0) - max_num_cameras):
+        importance = dists[num_keep_views:].amin(dim=1)
+        if pixel_dist is not None:
+            importance = importance - pixel_dist[num_keep_views:] * 0.05
+        remove = int(importance.argmin()) + num_keep_views
+        mask = torch.arange(len(keep_ids), device=device) != remove
+        keep_ids, dists = keep_ids[mask], dists[mask][:, mask]
+        if pixel_dist is not None:
+            pixel_dist = pixel_dist[mask]
+    return keep_ids, dists

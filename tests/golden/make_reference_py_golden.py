@@ -77,6 +77,28 @@ def main():
     out['dil_mask'] = mask.numpy()
     out['dil_out_r3_i7'] = mod.edge_dilation(img, mask, radius=3, iters=7).numpy()
     out['dil_out_r1_i2'] = mod.edge_dilation(img, mask, radius=1, iters=2).numpy()
+    # camera pruning bookkeeping (lib/pipelines/utils.py:350-379; needs matrix_to_quaternion from lib/ops/rotation_conversions.py)
+    ns = dict(torch=torch, F=F, np=np, math=math)
+    for path, names in ((os.path.join(REF, 'lib/ops/rotation_conversions.py'), ['_sqrt_positive_part', 'matrix_to_quaternion']),
+                        (os.path.join(REF, 'lib/pipelines/utils.py'), ['get_camera_dists', 'prune_cameras'])):
+        tree = ast.parse(open(path).read())
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef) and node.name in names:
+                exec(compile(ast.Module([node], []), path, 'exec'), ns)
+    torch.manual_seed(3)
+    poses32 = random_surround_views(3.7, 32, -0.3, 0.6, use_linspace=True)
+    poses32 = poses32[torch.randperm(32)]
+    cw = 0.5 + torch.rand(32)
+    pd = torch.rand(32)
+    out['prune_poses'] = poses32.numpy()
+    out['prune_cam_weights'] = cw.numpy()
+    out['prune_pixel_dist'] = pd.numpy()
+    d = ns['get_camera_dists'](poses32, cw, 'cpu')
+    out['prune_dists'] = d.numpy()
+    k1, d1 = ns['prune_cameras'](d.clone(), 1, 16, 'cpu')
+    k2, d2 = ns['prune_cameras'](d.clone(), 4, 9, 'cpu', pixel_dist=pd.clone())
+    out['prune_keep_16'], out['prune_dists_16'] = k1.numpy(), d1.numpy()
+    out['prune_keep_9'], out['prune_dists_9'] = k2.numpy(), d2.numpy()
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, os.path.getsize(OUT), 'bytes;', {k: v.shape for k, v in out.items()})
 

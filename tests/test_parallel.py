@@ -52,3 +52,49 @@ def _worker(rank, world, port, V, keep):
 def test_all_gather_and_repartition_gloo(world, V):
     keep = sorted(set(range(0, V, 2)) | {1})
     mp.spawn(_worker, args=(world, _free_port(), V, keep), nprocs=world, join=True)
+
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'reference_py.npz')
+
+
+def test_camera_pruning_matches_reference_output():
+    """get_camera_dists / prune_cameras (lib/pipelines/utils.py:350-379) against outputs of the reference's own functions
+    (tests/golden/make_reference_py_golden.py): same distances, same pruning decisions."""
+    import numpy as np
+    from mvedit_amd.pipelines.utils import get_camera_dists, prune_cameras
+    g = np.load(GOLD)
+    poses, cw, pd = (torch.from_numpy(g[k]) for k in ('prune_poses', 'prune_cam_weights', 'prune_pixel_dist'))
+    d = get_camera_dists(poses, cw, 'cpu')
+    np.testing.assert_allclose(d.numpy(), g['prune_dists'], rtol=0, atol=2e-5)
+    k16, d16 = prune_cameras(torch.from_numpy(g['prune_dists']).clone(), 1, 16, 'cpu')
+    k9, d9 = prune_cameras(torch.from_numpy(g['prune_dists']).clone(), 4, 9, 'cpu', pixel_dist=pd)
+    assert (k16.numpy() == g['prune_keep_16']).all() and (k9.numpy() == g['prune_keep_9']).all()
+    assert (d16.numpy() == g['prune_dists_16']).all() and (d9.numpy() == g['prune_dists_9']).all()
+    assert set(range(4)) <= set(k9.tolist()), 'keep_views are never pruned'
+
+
+def _prune_worker(rank, world, port):
+    """Every rank prunes from the same replicated camera set (identical decisions), then the per-view state is re-partitioned."""
+    import numpy as np
+    from mvedit_amd.pipelines.utils import get_camera_dists, prune_cameras
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = np.load(GOLD)
+        poses, cw = torch.from_numpy(g['prune_poses']), torch.from_numpy(g['prune_cam_weights'])
+        V = poses.shape[0]
+        keep, _ = prune_cameras(get_camera_dists(poses, cw, 'cpu'), 1, 16, 'cpu')
+        gathered = [torch.empty_like(keep) for _ in range(world)]
+        dist.all_gather(gathered, keep)
+        assert all(torch.equal(k, keep) for k in gathered), 'ranks must agree on the surviving views'
+        latents = torch.arange(V * 4, dtype=torch.float32).reshape(V, 4)
+        lo, hi = partition_views(V, world, rank)
+        mine = repartition(latents[lo:hi].clone(), V, keep.tolist())
+        lo2, hi2 = partition_views(len(keep), world, rank)
+        assert torch.equal(mine, latents[keep][lo2:hi2])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prune_then_repartition_gloo():
+    mp.spawn(_prune_worker, args=(2, _free_port()), nprocs=2, join=True)
