@@ -164,6 +164,7 @@ MVE_API int mve_density_grid_update(float* d_density_grid, float* d_tmp_grid, ui
 #define MVE_GEMM_OUT_F32 2   /* out is float32 instead of `dtype` */
 #define MVE_CONV_W_CHUNK64 4 /* conv weight is [Cout][Cin/64][3][3][64] (needs C1, C2 multiples of 64) */
 #define MVE_GEMM_NO_SPLITK 8 /* never split K even if a workspace is given */
+#define MVE_CONV_PAD_BR 32    /* stride-2 conv padded on the bottom / right only: diffusers Downsample2D(padding=0) = F.pad(x, (0,1,0,1)) + conv */
 #define MVE_GEMM_RES_AFTER_SCALE 16   /* out = (acc + bias) * out_scale + residual (default: residual is added before the scale) */
 
 /* Every Linear / 1x1 Conv2d of the UNet (diffusers Attention, FeedForward, ResnetBlock2D shortcut, Transformer2DModel proj_in/out,
@@ -246,9 +247,17 @@ MVE_API int mve_nhwc_to_nchw(int dst_dtype, int src_dtype, const void* d_x, int 
 MVE_API int mve_timestep_embedding(int dtype, const float* d_t, int B, int dim, void* d_out, void* stream);
 MVE_API int mve_silu(int dtype, const void* d_x, void* d_y, size_t n, void* stream);
 MVE_API int mve_axpy(int dtype, const void* d_a, const void* d_b, float alpha, void* d_y, size_t n, void* stream); /* y = a + alpha*b */
+/* probs[m][:N] = softmax(scores[m][:N]) (fp32 in, `dtype` out): the softmax of the VAE mid-block attention (diffusers Attention with
+ * heads = 1, dim_head = 512, reached through self.vae.decode / .encode, lib/pipelines/mvedit_3d_pipeline.py:1260, :1441), which
+ * runs as scores = mve_gemm(Q, K) -> mve_softmax_rows -> mve_gemm(P, V^T). */
+MVE_API int mve_softmax_rows(int dtype, const float* d_scores, size_t lds, int M, int N, void* d_probs, size_t ldp, void* stream);
 /* classifier-free guidance, adapter3d_mixin.py:130-134: out = g*text + (1-g)*uncond (f32) */
 MVE_API int mve_cfg_combine(const float* d_uncond, const float* d_text, float guidance_scale, float* d_out, size_t n,
                             void* stream);
+/* x0 = (latents_scaled - sqrt(1-abar_t) * noise_pred) / sqrt(abar_t): `pred_original_sample` of the reference's denoise loop
+ * (lib/pipelines/mvedit_3d_pipeline.py:1253-1255), fp32 in / out. */
+MVE_API int mve_x0_prediction(const float* d_latents_scaled, const float* d_noise_pred, float sqrt_alpha_bar,
+                              float sqrt_one_minus_alpha_bar, size_t n, float* d_x0, void* stream);
 
 /* =========================================================================
  * 3. UNet2DCondition executor (native runtime behind the reference's UNet seam).
@@ -307,6 +316,24 @@ MVE_API int mve_controlnet_forward(void* handle, const void* d_sample, int io_dt
                                    const void* d_cond, int B, int H, int W, int ctx_len, float conditioning_scale, int accumulate,
                                    void* const* d_outputs, void* d_workspace, size_t workspace_bytes,
                                    float* op_ms /* optional host array [n_ops]: per-op milliseconds (synchronises) */, void* stream);
+
+/* AutoencoderKL halves (diffusers==0.27.2 autoencoders/vae.py Decoder / Encoder with post_quant_conv / quant_conv), replacing
+ *   self.vae.decode(x0 / scaling_factor, return_dict=False)[0]   lib/pipelines/mvedit_3d_pipeline.py:1258-1262, adapter3d_mixin.py:327-338
+ *   self.vae.encode(images * 2 - 1, ...)                          lib/pipelines/mvedit_3d_pipeline.py:1118-1120, :1439-1443
+ * half 1: [B, in_channels = latent, H, W] -> [B, out_channels, H * 2^(n-1), W * 2^(n-1)];
+ * half 2: [B, in_channels = image, H, W] -> [B, out_channels = 2 * latent, H / 2^(n-1), W / 2^(n-1)] = cat(mean, logvar) (the
+ *         DiagonalGaussianDistribution arithmetic on those moments stays with the caller).
+ * The handle is an executor handle: parameters arrive through mve_unet_load_param under their AutoencoderKL state-dict names
+ * (`decoder.*` + `post_quant_conv.*` for half 1, `encoder.*` + `quant_conv.*` for half 2; a name of the other half is an error),
+ * mve_unet_missing_params / mve_unet_op_info / mve_unet_destroy apply unchanged.  ResnetBlock2D without time embedding, eps as
+ * given (1e-6 in diffusers); mid-block Attention (1 head of width C) = GEMM q k^T (fp32 scores) -> mve_softmax_rows -> GEMM P V;
+ * Downsample2D(padding=0) = MVE_CONV_PAD_BR.  in/out channels <= 8.  d_in / d_out are NCHW in io_dtype (f32 | f16 | bf16).
+ * One call handles B images whose widest full-resolution activation has < 2^31 elements (8 images at 512 x 512 for the SD VAE). */
+MVE_API int mve_vae_create(void** handle, int dtype, int half, int in_channels, int out_channels, int n_levels,
+                           const int* block_out_channels, int layers_per_block, int norm_num_groups, float norm_eps);
+MVE_API int mve_vae_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, double* flops);
+MVE_API int mve_vae_forward(void* handle, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
+                            size_t workspace_bytes, float* op_ms, void* stream);
 
 /* Tuning knob for engines created AFTER the call: 1 (default) folds every ResnetBlock2D conv_shortcut into conv2's K loop
  * (mve_conv3x3_shortcut), 0 keeps the separate 1x1 GEMMs; negative only queries.  Returns the previous setting. */

@@ -82,6 +82,65 @@ __global__ __launch_bounds__(NT) void k_cfg(const float* __restrict__ uncond, co
 
 }  // namespace
 
+namespace {
+// pred_original_sample of the reference's denoise loop (lib/pipelines/mvedit_3d_pipeline.py:1253-1255)
+__global__ __launch_bounds__(256) void k_x0_prediction(const float* __restrict__ x, const float* __restrict__ e, float sa, float sb, size_t n,
+                                                       float* __restrict__ out) {
+#pragma clang fp contract(off)      // no fma: bit-equal to the host expression evaluated op by op
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (x[i] - sb * e[i]) / sa;
+}
+}  // namespace
+
+namespace {
+// Row softmax of fp32 scores into the 16-bit probabilities the P.V GEMM consumes (single-head attention of the VAE mid block,
+// whose head dim of 512 is outside the fused attention kernel's range): one block per row, fp32 max / sum, exp2 arithmetic.
+template <class Tag>
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ S, size_t lds, int N, typename Tag::T* __restrict__ P,
+                                                      size_t ldp) {
+    __shared__ float red[4];
+    const float* s = S + (size_t)blockIdx.x * lds;
+    typename Tag::T* o = P + (size_t)blockIdx.x * ldp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto all_max = [&](float v) {
+        for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    };
+    auto all_sum = [&](float v) {
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    float mx = -INFINITY;
+    for (int i = threadIdx.x * 4; i < N; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + i);
+        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    mx = all_max(mx);
+    constexpr float LOG2E = 1.44269504088896340736f;
+    float sum = 0.f;
+    for (int i = threadIdx.x * 4; i < N; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + i);
+        sum += (exp2f((v[0] - mx) * LOG2E) + exp2f((v[1] - mx) * LOG2E)) + (exp2f((v[2] - mx) * LOG2E) + exp2f((v[3] - mx) * LOG2E));
+    }
+    sum = all_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int i = threadIdx.x * 4; i < N; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + i);
+        typedef typename Tag::T T4 __attribute__((ext_vector_type(4)));
+        T4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = Tag::from_f32(exp2f((v[e] - mx) * LOG2E) * inv);
+        *reinterpret_cast<T4*>(o + i) = r;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int mve_nchw_to_nhwc(int dst_dtype, int src_dtype, const void* x, int B, int C, int H, int W, int Cpad, void* y, void* stream) {
@@ -171,6 +230,26 @@ int mve_cfg_combine(const float* uncond, const float* text, float guidance_scale
     if (n == 0) return MVE_OK;
     MVE_CHECK(uncond && text && out, MVE_ERR_ARG, "cfg_combine: null pointer");
     k_cfg<<<mve_cdiv(n, NT), NT, 0, (hipStream_t)stream>>>(uncond, text, guidance_scale, out, n);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_x0_prediction(const float* d_latents_scaled, const float* d_noise_pred, float sqrt_alpha_bar, float sqrt_one_minus_alpha_bar, size_t n,
+                      float* d_x0, void* stream) {
+    if (n == 0) return MVE_OK;
+    MVE_CHECK(d_latents_scaled && d_noise_pred && d_x0 && sqrt_alpha_bar > 0.0f, MVE_ERR_ARG, "x0_prediction: bad arguments");
+    k_x0_prediction<<<mve_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(d_latents_scaled, d_noise_pred, sqrt_alpha_bar, sqrt_one_minus_alpha_bar, n, d_x0);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_softmax_rows(int dtype, const float* d_scores, size_t lds, int M, int N, void* d_probs, size_t ldp, void* stream) {
+    if (M == 0) return MVE_OK;
+    MVE_CHECK(d_scores && d_probs && N > 0 && N % 4 == 0 && lds % 4 == 0 && ldp % 4 == 0 && lds >= (size_t)N && ldp >= (size_t)N, MVE_ERR_ARG,
+              "softmax_rows: N, lds, ldp must be multiples of 4 (N=%d)", N);
+    if (dtype == MVE_F16) k_softmax_rows<F16Tag><<<M, 256, 0, (hipStream_t)stream>>>(d_scores, lds, N, (f16*)d_probs, ldp);
+    else if (dtype == MVE_BF16) k_softmax_rows<BF16Tag><<<M, 256, 0, (hipStream_t)stream>>>(d_scores, lds, N, (bf16*)d_probs, ldp);
+    else { mve_set_error("softmax_rows: unsupported dtype %d", dtype); return MVE_ERR_ARG; }
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

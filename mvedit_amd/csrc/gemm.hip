@@ -102,8 +102,8 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
             const int b = m / hw, r = m - b * hw;
             const int y = r / p.g.Wo;
             cb[j] = b;
-            cy[j] = y * p.g.stride - 1;
-            cx[j] = (r - y * p.g.Wo) * p.g.stride - 1;
+            cy[j] = y * p.g.stride - p.g.pad;
+            cx[j] = (r - y * p.g.Wo) * p.g.stride - p.g.pad;
         }
     }
     const T* w_row[B_PASSES];
@@ -443,6 +443,9 @@ static int conv3x3_impl(int dtype, const void* x1, int C1, const void* x2, int C
     p.g.ups = upsample ? 1 : 0;
     p.g.Hv = Hs << p.g.ups; p.g.Wv = Ws << p.g.ups;
     p.g.stride = stride;
+    p.g.pad = (flags & MVE_CONV_PAD_BR) ? 0 : 1;        // one output size either way: the window only shifts by a pixel
+    MVE_CHECK(p.g.pad == 1 || (stride == 2 && !upsample && Hs % 2 == 0 && Ws % 2 == 0), MVE_ERR_ARG,
+              "conv3x3: MVE_CONV_PAD_BR is the stride-2 downsampler of an even-sized input");
     p.g.Ho = (p.g.Hv + 2 - 3) / stride + 1;
     p.g.Wo = (p.g.Wv + 2 - 3) / stride + 1;
     p.g.C1 = C1; p.g.C2 = C2;

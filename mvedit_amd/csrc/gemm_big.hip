@@ -68,8 +68,8 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
             const int b = m / hw, r = m - b * hw;
             const int y = r / p.g.Wo;
             cb[j] = b;
-            cy[j] = y * p.g.stride - 1;
-            cx[j] = (r - y * p.g.Wo) * p.g.stride - 1;
+            cy[j] = y * p.g.stride - p.g.pad;
+            cx[j] = (r - y * p.g.Wo) * p.g.stride - p.g.pad;
             if constexpr (FAST) {     // per-row pixel base and 9-bit halo mask; cb/cy/cx are dead after this in the fast kernel
                 pix[j] = (cb[j] * p.g.Hs + cy[j]) * p.g.Ws + cx[j];
                 unsigned mk = 0;

@@ -18,6 +18,7 @@ struct ConvGeom {
     int Hs, Ws, Hv, Wv, Ho, Wo;
     int C1, C2;        // channels of source 1 / source 2 (C2 = 0: no concat)
     int stride;        // 1 or 2
+    int pad;           // rows / columns of zero padding before the first pixel: 1 (symmetric), 0 (MVE_CONV_PAD_BR: bottom/right only)
     int ups;           // 0 or 1 (nearest 2x)
     int chunk64;       // 1: K order is (channel slab of 64, tap, channel in slab)
     // fused 1x1 shortcut (ResnetBlock2D conv2 + conv_shortcut in ONE K loop): after the nk_main tiles of the 3x3 part, K continues

@@ -40,6 +40,7 @@ int mve_nhwc_to_nchw(int, int, const void*, int, int, int, int, int, void*, void
 int mve_timestep_embedding(int, const float*, int, int, void*, void*);
 int mve_silu(int, const void*, void*, size_t, void*);
 int mve_axpy(int, const void*, const void*, float, void*, size_t, void*);
+int mve_softmax_rows(int, const float*, size_t, int, int, void*, size_t, void*);
 }
 
 namespace {
@@ -106,6 +107,8 @@ constexpr int CN_EMB[4] = {16, 32, 96, 256};      // diffusers ControlNetModel c
 
 struct Config {
     int controlnet = 0, cond_ch = 3;   // ControlNetModel: encoder + mid of the UNet, conditioning embedding, zero convolutions
+    int vae = 0;                       // AutoencoderKL half: 1 = post_quant_conv + Decoder, 2 = Encoder + quant_conv (no time embedding,
+                                       // no transformers; in_ch / out_ch are the half's own input / output channels, both <= 8)
     int dtype, in_ch, out_ch, n_levels, layers_per_block, ctx_dim, groups, linear_proj;
     float eps;
     int ch[MAX_LEVELS], attn[MAX_LEVELS], heads[MAX_LEVELS], tlayers[MAX_LEVELS];
@@ -257,6 +260,29 @@ struct XfDesc { std::string name; int c, heads, layers; };
 
 void enumerate(const Config& c, std::vector<ResnetDesc>& rs, std::vector<XfDesc>& xs) {
     const int n = c.n_levels, L = c.layers_per_block;
+    if (c.vae) {      // diffusers Encoder / Decoder (autoencoders/vae.py): resnets only, one attention in the mid block
+        const int Cm = c.ch[n - 1];
+        if (c.vae == 2) {
+            int cin = c.ch[0];
+            for (int i = 0; i < n; ++i) {
+                for (int j = 0; j < L; ++j)
+                    rs.push_back({"down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? cin : c.ch[i], c.ch[i]});
+                cin = c.ch[i];
+            }
+        }
+        rs.push_back({"mid_block.resnets.0", Cm, Cm});
+        rs.push_back({"mid_block.resnets.1", Cm, Cm});
+        if (c.vae == 1) {
+            int cin = Cm;
+            for (int i = 0; i < n; ++i) {
+                const int cout = c.ch[n - 1 - i];
+                for (int j = 0; j < L + 1; ++j)
+                    rs.push_back({"up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? cin : cout, cout});
+                cin = cout;
+            }
+        }
+        return;
+    }
     int cin = c.ch[0];
     for (int i = 0; i < n; ++i) {
         for (int j = 0; j < L; ++j) {
@@ -309,6 +335,53 @@ void layout_params(Unet& u) {
     u.fuse_sc = g_fuse_shortcut != 0;
     for (int i = 0; i < c.n_levels; ++i) u.fuse_sc = u.fuse_sc && (c.ch[i] % 64 == 0);
     auto need = [&](const std::string& n) { u.expected.push_back(n); };
+    if (c.vae) {
+        // names are the half's own (mve_unet_load_param strips `decoder.` / `encoder.`; (post_)quant_conv is `pq_conv`)
+        const int n = c.n_levels, Cm = c.ch[n - 1], Cin0 = c.vae == 1 ? Cm : c.ch[0], Cout0 = c.vae == 1 ? c.ch[0] : Cm;
+        sb.add("pq_conv.w", 8 * 8, false); need("pq_conv.weight");
+        sb.add("pq_conv.b", 8, true); need("pq_conv.bias");
+        sb.add("conv_in.w", (size_t)Cin0 * 9 * 8, false); need("conv_in.weight");
+        sb.add("conv_in.b", Cin0, true); need("conv_in.bias");
+        for (auto& r : rs) {
+            sb.add(r.name + ".norm1.g", r.cin, true); need(r.name + ".norm1.weight");
+            sb.add(r.name + ".norm1.b", r.cin, true); need(r.name + ".norm1.bias");
+            sb.add(r.name + ".conv1.w", (size_t)r.cout * 9 * r.cin, false); need(r.name + ".conv1.weight");
+            sb.add(r.name + ".conv1.b", r.cout, true); need(r.name + ".conv1.bias");
+            sb.add(r.name + ".norm2.g", r.cout, true); need(r.name + ".norm2.weight");
+            sb.add(r.name + ".norm2.b", r.cout, true); need(r.name + ".norm2.bias");
+            const bool sc = r.cin != r.cout;
+            sb.add(r.name + ".conv2.w", (size_t)r.cout * (9 * r.cout + (sc && u.fuse_sc ? r.cin : 0)), false); need(r.name + ".conv2.weight");
+            sb.add(r.name + ".conv2.b", r.cout, true); need(r.name + ".conv2.bias");
+            if (sc) {
+                u.sc_cin[r.name] = r.cin;
+                if (!u.fuse_sc) sb.add(r.name + ".sc.w", (size_t)r.cout * r.cin, false);
+                need(r.name + ".conv_shortcut.weight");
+                sb.add(r.name + ".sc.b", r.cout, true); need(r.name + ".conv_shortcut.bias");
+            }
+        }
+        const std::string a = "mid_block.attentions.0";
+        const size_t C = Cm;
+        sb.add(a + ".group_norm.g", C, true); need(a + ".group_norm.weight");
+        sb.add(a + ".group_norm.b", C, true); need(a + ".group_norm.bias");
+        sb.add(a + ".qk.w", 2 * C * C, false); need(a + ".to_q.weight"); need(a + ".to_k.weight");
+        sb.add(a + ".qk.b", 2 * C, true); need(a + ".to_q.bias"); need(a + ".to_k.bias");
+        sb.add(a + ".v.w", C * C, false); need(a + ".to_v.weight");
+        sb.add(a + ".v.b", C, true); need(a + ".to_v.bias");
+        sb.add(a + ".o.w", C * C, false); need(a + ".to_out.0.weight");
+        sb.add(a + ".o.b", C, true); need(a + ".to_out.0.bias");
+        for (int i = 0; i + 1 < n; ++i) {
+            const size_t Cs = c.vae == 1 ? c.ch[n - 1 - i] : c.ch[i];
+            const std::string sn = (c.vae == 1 ? "up_blocks." + std::to_string(i) + ".upsamplers" : "down_blocks." + std::to_string(i) + ".downsamplers") + ".0.conv";
+            sb.add(sn + ".w", Cs * 9 * Cs, false); need(sn + ".weight");
+            sb.add(sn + ".b", Cs, true); need(sn + ".bias");
+        }
+        sb.add("norm_out.g", Cout0, true); need("conv_norm_out.weight");
+        sb.add("norm_out.b", Cout0, true); need("conv_norm_out.bias");
+        sb.add("conv_out.w", (size_t)8 * 9 * Cout0, false); need("conv_out.weight");
+        sb.add("conv_out.b", 8, true); need("conv_out.bias");
+        u.slab_bytes = sb.top;
+        return;
+    }
     sb.add("conv_in.w", (size_t)c.ch[0] * 9 * 8, false); need("conv_in.weight");
     sb.add("conv_in.b", c.ch[0], true); need("conv_in.bias");
     sb.add("time.w1", (size_t)T * c.ch[0], false); need("time_embedding.linear_1.weight");
@@ -466,7 +539,34 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
     };
     int rc = MVE_ERR_ARG;
     const int T = c.temb_dim();
-    if (name == "conv_in.weight") {
+    const int Cm_ = c.ch[c.n_levels - 1];
+    const int vin = c.vae == 1 ? Cm_ : c.ch[0], vout = c.vae == 1 ? c.ch[0] : Cm_;     // widths after conv_in / before conv_out
+    const std::string va = "mid_block.attentions.0";
+    if (c.vae && name == "conv_in.weight") {
+        MVE_HIP(hipMemsetAsync(dstp(P("conv_in.w"), 0), 0, P("conv_in.w")->bytes, s));
+        rc = conv(P("conv_in.w"), vin, c.in_ch, vin, 8);
+    } else if (c.vae && name == "conv_in.bias") rc = vec(P("conv_in.b"), 0, vin, 1);
+    else if (c.vae && name == "conv_norm_out.weight") rc = vec(P("norm_out.g"), 0, vout, 1);
+    else if (c.vae && name == "conv_norm_out.bias") rc = vec(P("norm_out.b"), 0, vout, 1);
+    else if (c.vae && name == "conv_out.weight") {
+        MVE_HIP(hipMemsetAsync(dstp(P("conv_out.w"), 0), 0, P("conv_out.w")->bytes, s));
+        rc = conv(P("conv_out.w"), c.out_ch, vout, 8, vout);
+    } else if (c.vae && name == "pq_conv.weight") {      // (post_)quant_conv: 1x1 over <= 8 channels, zero-padded to 8 x 8
+        const int nq = c.vae == 1 ? c.in_ch : c.out_ch;
+        MVE_HIP(hipMemsetAsync(dstp(P("pq_conv.w"), 0), 0, P("pq_conv.w")->bytes, s));
+        rc = mat(P("pq_conv.w"), 0, nq, nq, 8);
+    } else if (c.vae && name == "pq_conv.bias") {
+        MVE_HIP(hipMemsetAsync(dstp(P("pq_conv.b"), 0), 0, P("pq_conv.b")->bytes, s));
+        rc = vec(P("pq_conv.b"), 0, c.vae == 1 ? c.in_ch : c.out_ch, 1);
+    } else if (c.vae && (name == va + ".to_q.weight" || name == va + ".to_k.weight"))
+        rc = mat(P(va + ".qk.w"), name[va.size() + 4] == 'q' ? 0 : (size_t)Cm_ * Cm_, Cm_, Cm_, Cm_);
+    else if (c.vae && (name == va + ".to_q.bias" || name == va + ".to_k.bias"))
+        rc = vec(P(va + ".qk.b"), name[va.size() + 4] == 'q' ? 0 : Cm_, Cm_, 1);
+    else if (c.vae && name == va + ".to_v.weight") rc = mat(P(va + ".v.w"), 0, Cm_, Cm_, Cm_);
+    else if (c.vae && name == va + ".to_v.bias") rc = vec(P(va + ".v.b"), 0, Cm_, 1);
+    else if (c.vae && name == va + ".to_out.0.weight") rc = mat(P(va + ".o.w"), 0, Cm_, Cm_, Cm_);
+    else if (c.vae && name == va + ".to_out.0.bias") rc = vec(P(va + ".o.b"), 0, Cm_, 1);
+    else if (name == "conv_in.weight") {
         MVE_HIP(hipMemsetAsync(dstp(P("conv_in.w"), 0), 0, P("conv_in.w")->bytes, s));
         rc = conv(P("conv_in.w"), c.ch[0], c.in_ch, c.ch[0], 8);
     } else if (name == "conv_in.bias") rc = vec(P("conv_in.b"), 0, c.ch[0], 1);
@@ -622,7 +722,7 @@ struct Builder {
 
     int rows_img = 0;        // rows per image of the level being emitted (split-K granularity); 0: never split
     void gemm(Ref A, int lda, Ref W, int ldw, Ref out, int ldc, int M, int N, int K, Ref bias, Ref rowvec, int ldrv,
-              int rpv, Ref res, int ldr, int flags, const char* what) {
+              int rpv, Ref res, int ldr, int flags, const char* what, float out_scale = 1.0f) {
         const int rimg = rows_img;
         const int d = dt;
         live(A, what); live(out, what); live(res, what); live(rowvec, what);
@@ -630,7 +730,7 @@ struct Builder {
         Ref sk = skb ? ws(skb) : Ref();
         op(OC_LINEAR, 2.0 * M * N * K, what, [=](const Run& r) {
             return mve_gemm(d, r.p(A), lda, r.p(W), ldw, r.p(out), ldc, M, N, K, (const float*)r.p(bias), (const float*)r.p(rowvec),
-                            ldrv, rpv, r.p(res), ldr, flags, 1.0f, r.p(sk), skb, rimg, r.stream);
+                            ldrv, rpv, r.p(res), ldr, flags, out_scale, r.p(sk), skb, rimg, r.stream);
         });
         rel(sk);
     }
@@ -711,7 +811,7 @@ struct Builder {
         Ref h0 = ws((size_t)M * Cin * e);
         gn(x, C1, skip, C2, B, H * W, c.eps, wt(name + ".norm1.g"), wt(name + ".norm1.b"), 1, h0, "resnet.norm1+silu");
         Ref h1 = ws((size_t)M * Cout * e);
-        Ref tv = at(tproj, (size_t)u.temb_off[name] * 4);
+        Ref tv = c.vae ? Ref() : at(tproj, (size_t)u.temb_off[name] * 4);      // the VAE's resnets have no time embedding
         conv(h0, Cin, B, H, W, 1, 0, wt(name + ".conv1.w"), Cout, h1, wt(name + ".conv1.b"), tv, ld_temb, Ref(), 0, "resnet.conv1");
         rel(h0);
         Ref h2 = ws((size_t)M * Cout * e);
@@ -831,6 +931,152 @@ struct Builder {
         gemm(h, C, wt(name + ".proj_out.w"), C, out, C, M, C, C, wt(name + ".proj_out.b"), Ref(), 0, 0, x, C, 0, "transformer.proj_out+residual");
         rel(h);
         return out;
+    }
+
+    // diffusers Attention of the VAE mid block (heads = 1, dim_head = C, residual_connection, bias everywhere, GroupNorm eps =
+    // resnet eps): x + to_out(softmax(q k^T / sqrt(C)) v).  Head dim C = 512 is outside the fused attention kernel's range, so the
+    // block runs on the GEMM kernel: scores (fp32) = q k^T, row softmax, P (V^T)^T with V^T produced directly by a GEMM whose "A"
+    // operand is the weight matrix.  to_v's bias is added after P.V (rows of P sum to one).  Images are processed one after the
+    // other through one [L, L] score buffer.
+    Ref vae_attention(const std::string& name, Ref x, int C, int H, int W) {
+        const int L = H * W, M = B * L, e = 2, d = dt;
+        rows_img = 0;
+        Ref n0 = ws((size_t)M * C * e);
+        gn(x, C, Ref(), 0, B, L, c.eps, wt(name + ".group_norm.g"), wt(name + ".group_norm.b"), 0, n0, "vae attention.group_norm");
+        Ref qk = ws((size_t)M * 2 * C * e);
+        gemm(n0, C, wt(name + ".qk.w"), C, qk, 2 * C, M, 2 * C, C, wt(name + ".qk.b"), Ref(), 0, 0, Ref(), 0, 0, "vae attention.to_q,to_k");
+        Ref vT = ws((size_t)B * C * L * e);
+        for (int b = 0; b < B; ++b)
+            gemm(wt(name + ".v.w"), C, at(n0, (size_t)b * L * C * e), C, at(vT, (size_t)b * C * L * e), L, C, L, C, Ref(), Ref(), 0, 0, Ref(), 0, 0,
+                 "vae attention.to_v (transposed)");
+        rel(n0);
+        Ref S = ws((size_t)L * L * 4), P = ws((size_t)L * L * e), a = ws((size_t)M * C * e);
+        const float scale = 1.0f / sqrtf((float)C);
+        for (int b = 0; b < B; ++b) {
+            Ref q = at(qk, (size_t)b * L * 2 * C * e);
+            gemm(q, 2 * C, at(q, (size_t)C * e), 2 * C, S, L, L, L, C, Ref(), Ref(), 0, 0, Ref(), 0, MVE_GEMM_OUT_F32, "vae attention.q k^T", scale);
+            live(S, "vae attention.softmax"); live(P, "vae attention.softmax");
+            op(OC_ATTN, 0, "vae attention.softmax", [=](const Run& r) {
+                return mve_softmax_rows(d, (const float*)r.p(S), (size_t)L, L, L, r.p(P), (size_t)L, r.stream);
+            });
+            gemm(P, L, at(vT, (size_t)b * C * L * e), L, at(a, (size_t)b * L * C * e), C, L, C, L, wt(name + ".v.b"), Ref(), 0, 0, Ref(), 0, 0,
+                 "vae attention.P V");
+        }
+        rel(S); rel(P); rel(qk); rel(vT);
+        Ref out = ws((size_t)M * C * e);
+        gemm(a, C, wt(name + ".o.w"), C, out, C, M, C, C, wt(name + ".o.b"), Ref(), 0, 0, x, C, 0, "vae attention.to_out+residual");
+        rel(a);
+        return out;
+    }
+
+    // AutoencoderKL half (diffusers 0.27.2 autoencoders/vae.py Decoder / Encoder, as called at lib/pipelines/mvedit_3d_pipeline.py:1260
+    // and :1441 of the reference).  H x W is the size of the half's INPUT (latent for the decoder, image for the encoder).
+    int build_vae(int B_, int H, int W, int io_dtype) {
+        B = B_; dt = c.dtype;
+        const int Bb = B_;
+        pl = Plan();
+        pl.B = Bb; pl.H = H; pl.W = W; pl.n_img = 1; pl.io_dtype = io_dtype;
+        const int e = 2, n = c.n_levels, L = c.layers_per_block, d = dt, Cm = c.ch[n - 1];
+        ld_temb = 0; ld_kv = 0;
+        const int f = 1 << (n - 1);
+        MVE_CHECK((H * W) % 8 == 0, MVE_ERR_ARG, "vae: input size %dx%d must have a multiple of 8 pixels", H, W);
+        if (c.vae == 2) MVE_CHECK(H % f == 0 && W % f == 0 && ((H / f) * (W / f)) % 8 == 0, MVE_ERR_ARG, "vae: image size %dx%d must be divisible by %d", H, W, f);
+        const int wide = n > 1 && c.ch[1] > c.ch[0] ? c.ch[1] : c.ch[0];      // widest tensor at image resolution
+        MVE_CHECK((size_t)Bb * H * W * (c.vae == 1 ? (size_t)f * f : 1) * wide < ((size_t)1 << 31), MVE_ERR_ARG,
+                  "vae: batch %d at this size overflows 32-bit activation indexing; decode / encode in smaller batches", Bb);
+        const int M0 = Bb * H * W;
+        Ref x_in = ws((size_t)M0 * 8 * e);
+        {
+            Ref src; src.kind = Ref::SAMPLE;
+            const int in_ch = c.in_ch;
+            op(OC_OTHER, 0, "nchw->nhwc", [=](const Run& r) { return mve_nchw_to_nhwc(d, io_dtype, r.p(src), Bb, in_ch, H, W, 8, r.p(x_in), r.stream); });
+        }
+        rows_img = H * W;
+        int h = H, w = W;
+        Ref x;
+        if (c.vae == 1) {
+            Ref z = ws((size_t)M0 * 8 * e);
+            gemm(x_in, 8, wt("pq_conv.w"), 8, z, 8, M0, 8, 8, wt("pq_conv.b"), Ref(), 0, 0, Ref(), 0, 0, "post_quant_conv");
+            rel(x_in);
+            x = ws((size_t)M0 * Cm * e);
+            conv(z, 8, Bb, H, W, 1, 0, wt("conv_in.w"), Cm, x, wt("conv_in.b"), Ref(), 0, Ref(), 0, "conv_in");
+            rel(z);
+        } else {
+            x = ws((size_t)M0 * c.ch[0] * e);
+            conv(x_in, 8, Bb, H, W, 1, 0, wt("conv_in.w"), c.ch[0], x, wt("conv_in.b"), Ref(), 0, Ref(), 0, "conv_in");
+            rel(x_in);
+            int cin = c.ch[0];
+            for (int i = 0; i < n; ++i) {
+                for (int j = 0; j < L; ++j) {
+                    Ref y = resnet("down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), x, cin, Ref(), 0, c.ch[i], h, w);
+                    rel(x);
+                    x = y; cin = c.ch[i];
+                }
+                if (i + 1 < n) {
+                    const std::string dn = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
+                    Ref y = ws((size_t)Bb * (h / 2) * (w / 2) * cin * e);
+                    rows_img = (h / 2) * (w / 2);
+                    conv(x, cin, Bb, h, w, 2, 0, wt(dn + ".w"), cin, y, wt(dn + ".b"), Ref(), 0, Ref(), MVE_CONV_PAD_BR, "downsample (pad bottom/right)");
+                    rel(x);
+                    h /= 2; w /= 2;
+                    x = y;
+                }
+            }
+        }
+        {
+            Ref y = resnet("mid_block.resnets.0", x, Cm, Ref(), 0, Cm, h, w);
+            rel(x);
+            Ref z = vae_attention("mid_block.attentions.0", y, Cm, h, w);
+            rel(y);
+            x = resnet("mid_block.resnets.1", z, Cm, Ref(), 0, Cm, h, w);
+            rel(z);
+        }
+        int cur = Cm;
+        if (c.vae == 1) {
+            for (int i = 0; i < n; ++i) {
+                const int cout = c.ch[n - 1 - i];
+                for (int j = 0; j < L + 1; ++j) {
+                    Ref y = resnet("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), x, cur, Ref(), 0, cout, h, w);
+                    rel(x);
+                    x = y; cur = cout;
+                }
+                if (i + 1 < n) {
+                    const std::string un = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
+                    Ref y = ws((size_t)Bb * (2 * h) * (2 * w) * cout * e);
+                    rows_img = 4 * h * w;
+                    conv(x, cout, Bb, h, w, 1, 1, wt(un + ".w"), cout, y, wt(un + ".b"), Ref(), 0, Ref(), 0, "upsample+conv");
+                    rel(x);
+                    h *= 2; w *= 2;
+                    x = y;
+                }
+            }
+        }
+        // ---- head: GroupNorm + SiLU, conv_out (N padded to 8), for the encoder quant_conv on the 8 moments channels ------------
+        const int Mo = Bb * h * w;
+        rows_img = h * w;
+        Ref hn = ws((size_t)Mo * cur * e);
+        gn(x, cur, Ref(), 0, Bb, h * w, c.eps, wt("norm_out.g"), wt("norm_out.b"), 1, hn, "conv_norm_out+silu");
+        rel(x);
+        Ref o8 = ws((size_t)Mo * 8 * 4);
+        if (c.vae == 1) {
+            conv(hn, cur, Bb, h, w, 1, 0, wt("conv_out.w"), 8, o8, wt("conv_out.b"), Ref(), 0, Ref(), MVE_GEMM_OUT_F32, "conv_out");
+            rel(hn);
+        } else {
+            Ref m8 = ws((size_t)Mo * 8 * e);
+            conv(hn, cur, Bb, h, w, 1, 0, wt("conv_out.w"), 8, m8, wt("conv_out.b"), Ref(), 0, Ref(), 0, "conv_out");
+            rel(hn);
+            gemm(m8, 8, wt("pq_conv.w"), 8, o8, 8, Mo, 8, 8, wt("pq_conv.b"), Ref(), 0, 0, Ref(), 0, MVE_GEMM_OUT_F32, "quant_conv");
+            rel(m8);
+        }
+        {
+            Ref dst; dst.kind = Ref::OUT;
+            const int oc = c.out_ch, ho = h, wo = w;
+            op(OC_OTHER, 0, "nhwc->nchw", [=](const Run& r) { return mve_nhwc_to_nchw(io_dtype, MVE_F32, r.p(o8), 8, Bb, oc, ho, wo, r.p(dst), r.stream); });
+        }
+        pl.enc_end = pl.ops.size();
+        pl.ws_bytes = ar.peak + 256;
+        if (!u.err.empty()) { mve_set_error("vae plan: %s", u.err.c_str()); u.err.clear(); return MVE_ERR_STATE; }
+        return MVE_OK;
     }
 
     int build(int B_, int H, int W, int n_img, int has_res, int io_dtype, int res_nhwc) {
@@ -1114,7 +1360,7 @@ int ensure_plan(Unet& u, int B, int H, int W, int n_img, int has_res, int io_dty
     Builder b(u, *np);
     b.ctx_rows_per_img = ctx_len;
     u.cur = nullptr;
-    const int rc = b.build(B, H, W, n_img, has_res, io_dtype, res_nhwc);
+    const int rc = u.cfg.vae ? b.build_vae(B, H, W, io_dtype) : b.build(B, H, W, n_img, has_res, io_dtype, res_nhwc);
     if (rc != MVE_OK) return rc;
     np->ctx_len = ctx_len;
     np->last_use = u.tick;
@@ -1234,6 +1480,84 @@ int mve_controlnet_forward(void* handle, const void* d_sample, int io_dtype, con
     return MVE_OK;
 }
 
+int mve_vae_create(void** handle, int dtype, int half, int in_channels, int out_channels, int n_levels, const int* block_out_channels,
+                   int layers_per_block, int norm_num_groups, float norm_eps) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "vae_create: null handle");
+    MVE_CHECK(dtype == MVE_F16 || dtype == MVE_BF16, MVE_ERR_ARG, "vae_create: dtype must be f16 or bf16");
+    MVE_CHECK(half == 1 || half == 2, MVE_ERR_ARG, "vae_create: half must be 1 (decoder) or 2 (encoder)");
+    MVE_CHECK(n_levels >= 1 && n_levels <= MAX_LEVELS && layers_per_block >= 1, MVE_ERR_ARG, "vae_create: bad topology");
+    MVE_CHECK(in_channels >= 1 && in_channels <= 8 && out_channels >= 1 && out_channels <= 8, MVE_ERR_ARG,
+              "vae_create: in/out channels must be <= 8 (encoder: out_channels = 2 * latent_channels)");
+    Unet* u = new Unet();
+    Config& c = u->cfg;
+    c.vae = half;
+    c.dtype = dtype; c.in_ch = in_channels; c.out_ch = out_channels; c.n_levels = n_levels; c.layers_per_block = layers_per_block;
+    c.ctx_dim = 8; c.groups = norm_num_groups; c.eps = norm_eps; c.linear_proj = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        c.ch[i] = block_out_channels[i]; c.attn[i] = 0; c.heads[i] = 1; c.tlayers[i] = 0;
+        if (c.ch[i] % 8 != 0 || c.groups <= 0 || c.ch[i] % c.groups != 0) {
+            delete u;
+            mve_set_error("vae_create: channel count %d incompatible with %d groups", block_out_channels[i], norm_num_groups);
+            return MVE_ERR_ARG;
+        }
+    }
+    layout_params(*u);
+    *handle = u;
+    return MVE_OK;
+}
+
+int mve_vae_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, double* flops) {
+    MVE_CHECK(handle && B > 0 && H > 0 && W > 0, MVE_ERR_ARG, "vae_plan: bad arguments");
+    Unet* u = (Unet*)handle;
+    MVE_CHECK(u->cfg.vae, MVE_ERR_ARG, "vae_plan: handle is not a VAE half");
+    int rc = ensure_plan(*u, B, H, W, 1, 0, io_dtype, 0, 0);
+    if (rc) return rc;
+    if (workspace_bytes) *workspace_bytes = u->cur->ws_bytes;
+    if (n_ops) *n_ops = (int)u->cur->ops.size();
+    if (flops) for (int i = 0; i < OC_COUNT; ++i) flops[i] = u->cur->flops[i];
+    return MVE_OK;
+}
+
+int mve_vae_forward(void* handle, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
+                    size_t workspace_bytes, float* op_ms, void* stream) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "vae_forward: null handle");
+    Unet* u = (Unet*)handle;
+    MVE_CHECK(u->cfg.vae, MVE_ERR_ARG, "vae_forward: handle is not a VAE half");
+    {
+        char first[256];
+        const int miss = mve_unet_missing_params(handle, first, sizeof(first));
+        MVE_CHECK(miss == 0, MVE_ERR_STATE, "vae_forward: %d parameters not loaded (first: %s)", miss, first);
+    }
+    MVE_CHECK(d_in && d_out, MVE_ERR_ARG, "vae_forward: null pointer");
+    int rc = ensure_plan(*u, B, H, W, 1, 0, io_dtype, 0, 0);
+    if (rc) return rc;
+    const Plan& pl = *u->cur;
+    MVE_CHECK(d_workspace && workspace_bytes >= pl.ws_bytes, MVE_ERR_NOMEM, "vae_forward: workspace %zu < required %zu", workspace_bytes,
+              pl.ws_bytes);
+    Run r;
+    r.ws = (unsigned char*)d_workspace; r.wt = u->slab;
+    r.sample = d_in; r.timesteps = nullptr; r.ctx = nullptr; r.out = d_out;
+    r.down_res = nullptr; r.mid_res = nullptr; r.ref_store = nullptr;
+    r.stream = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev;
+    if (op_ms) {
+        ev.resize(pl.ops.size() + 1);
+        for (auto& e : ev) MVE_HIP(hipEventCreate(&e));
+        MVE_HIP(hipEventRecord(ev[0], r.stream));
+    }
+    for (size_t i = 0; i < pl.ops.size(); ++i) {
+        rc = pl.ops[i].fn(r);
+        if (rc) return rc;
+        if (op_ms) MVE_HIP(hipEventRecord(ev[i + 1], r.stream));
+    }
+    if (op_ms) {
+        MVE_HIP(hipStreamSynchronize(r.stream));
+        for (size_t i = 0; i < pl.ops.size(); ++i) MVE_HIP(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return MVE_OK;
+}
+
 int mve_unet_tune(int fuse_shortcut) {
     const int old = g_fuse_shortcut;
     if (fuse_shortcut >= 0) g_fuse_shortcut = fuse_shortcut ? 1 : 0;
@@ -1262,7 +1586,17 @@ int mve_unet_load_param(void* handle, const char* name, const void* d_src, int s
             return MVE_ERR_HIP;
         }
     }
-    return load_param(*u, name, d_src, src_dtype, ndim, shape, (hipStream_t)stream);
+    std::string nm = name;
+    if (u->cfg.vae) {     // AutoencoderKL state-dict names -> the half's own
+        const std::string own = u->cfg.vae == 1 ? "decoder." : "encoder.", pq = u->cfg.vae == 1 ? "post_quant_conv." : "quant_conv.";
+        if (nm.compare(0, own.size(), own) == 0) nm = nm.substr(own.size());
+        else if (nm.compare(0, pq.size(), pq) == 0) nm = "pq_conv." + nm.substr(pq.size());
+        else {
+            mve_set_error("vae_load_param: %s does not belong to the %s", name, u->cfg.vae == 1 ? "decoder" : "encoder");
+            return MVE_ERR_ARG;
+        }
+    }
+    return load_param(*u, nm, d_src, src_dtype, ndim, shape, (hipStream_t)stream);
 }
 
 int mve_unet_missing_params(void* handle, char* buf, int buf_len) {
@@ -1294,7 +1628,7 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
                      float* op_ms /* optional host array [n_ops]: per-op milliseconds (synchronises) */, void* stream) {
     MVE_CHECK(handle, MVE_ERR_ARG, "unet_forward: null handle");
     Unet* u = (Unet*)handle;
-    MVE_CHECK(!u->cfg.controlnet, MVE_ERR_ARG, "unet_forward: handle is a ControlNet (use mve_controlnet_forward)");
+    MVE_CHECK(!u->cfg.controlnet && !u->cfg.vae, MVE_ERR_ARG, "unet_forward: handle is a ControlNet / VAE (use mve_controlnet_forward / mve_vae_forward)");
     {
         char first[256];
         const int miss = mve_unet_missing_params(handle, first, sizeof(first));

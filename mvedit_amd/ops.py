@@ -10,6 +10,7 @@ from . import _lib
 GEGLU = 1
 OUT_F32 = 2
 W_CHUNK64 = 4
+PAD_BR = 32         # MVE_CONV_PAD_BR: stride-2 conv padded bottom/right only (diffusers Downsample2D(padding=0))
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.int32: 3, torch.uint8: 4}
 
@@ -192,4 +193,14 @@ def cfg_combine(uncond, text, guidance_scale):
     with torch.cuda.device(uncond.device):
         _lib.call('mve_cfg_combine', _lib.ptr(uncond), _lib.ptr(text), float(guidance_scale), _lib.ptr(out),
                   uncond.numel(), _s(uncond))
+    return out
+
+
+def softmax_rows(scores, dtype):
+    """Row softmax of fp32 scores [M, N] into 16-bit probabilities (the VAE mid-block attention between its two GEMMs)."""
+    assert scores.dtype == torch.float32 and scores.dim() == 2 and scores.is_contiguous()
+    M, N = scores.shape
+    out = torch.empty(M, N, dtype=dtype, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.call('mve_softmax_rows', dt(dtype), _lib.ptr(scores), N, M, N, _lib.ptr(out), N, _s(scores))
     return out

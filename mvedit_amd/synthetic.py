@@ -147,3 +147,68 @@ def make_controlnet_state_dict(cfg, seed=777, dtype=torch.float32, cond_channels
             t = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(3.0 / math.prod(shape[1:]))
         sd[name] = t.to(dtype)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# AutoencoderKL (diffusers 0.27.2 state-dict names); tests/test_vae.py checks the inventory against the oracle's
+# ---------------------------------------------------------------------------------------------------------------------------
+def vae_param_shapes(cfg):
+    ch, L, lat = tuple(cfg['block_out_channels']), cfg['layers_per_block'], cfg['latent_channels']
+    n = len(ch)
+
+    def resnet(p, cin, cout):
+        s = {k: v for k, v in _resnet_shapes(p, cin, cout, 1).items() if '.time_emb_proj.' not in k}
+        return s
+
+    def mid(p, c):
+        s = resnet(f'{p}.resnets.0', c, c)
+        a = f'{p}.attentions.0'
+        s[f'{a}.group_norm.weight'] = (c,)
+        s[f'{a}.group_norm.bias'] = (c,)
+        for nm in ('to_q', 'to_k', 'to_v', 'to_out.0'):
+            s[f'{a}.{nm}.weight'] = (c, c)
+            s[f'{a}.{nm}.bias'] = (c,)
+        s.update(resnet(f'{p}.resnets.1', c, c))
+        return s
+
+    s = {'encoder.conv_in.weight': (ch[0], cfg['in_channels'], 3, 3), 'encoder.conv_in.bias': (ch[0],)}
+    cin = ch[0]
+    for i, cout in enumerate(ch):
+        for j in range(L):
+            s.update(resnet(f'encoder.down_blocks.{i}.resnets.{j}', cin if j == 0 else cout, cout))
+        if i < n - 1:
+            s[f'encoder.down_blocks.{i}.downsamplers.0.conv.weight'] = (cout, cout, 3, 3)
+            s[f'encoder.down_blocks.{i}.downsamplers.0.conv.bias'] = (cout,)
+        cin = cout
+    s.update(mid('encoder.mid_block', ch[-1]))
+    s.update({'encoder.conv_norm_out.weight': (ch[-1],), 'encoder.conv_norm_out.bias': (ch[-1],),
+              'encoder.conv_out.weight': (2 * lat, ch[-1], 3, 3), 'encoder.conv_out.bias': (2 * lat,),
+              'decoder.conv_in.weight': (ch[-1], lat, 3, 3), 'decoder.conv_in.bias': (ch[-1],)})
+    s.update(mid('decoder.mid_block', ch[-1]))
+    cin = ch[-1]
+    for i, cout in enumerate(ch[::-1]):
+        for j in range(L + 1):
+            s.update(resnet(f'decoder.up_blocks.{i}.resnets.{j}', cin if j == 0 else cout, cout))
+        if i < n - 1:
+            s[f'decoder.up_blocks.{i}.upsamplers.0.conv.weight'] = (cout, cout, 3, 3)
+            s[f'decoder.up_blocks.{i}.upsamplers.0.conv.bias'] = (cout,)
+        cin = cout
+    s.update({'decoder.conv_norm_out.weight': (ch[0],), 'decoder.conv_norm_out.bias': (ch[0],),
+              'decoder.conv_out.weight': (cfg['out_channels'], ch[0], 3, 3), 'decoder.conv_out.bias': (cfg['out_channels'],),
+              'quant_conv.weight': (2 * lat, 2 * lat, 1, 1), 'quant_conv.bias': (2 * lat,),
+              'post_quant_conv.weight': (lat, lat, 1, 1), 'post_quant_conv.bias': (lat,)})
+    return s
+
+
+def make_vae_state_dict(cfg, seed=4321, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in vae_param_shapes(cfg).items():
+        if name.endswith('.bias'):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = torch.randn(shape, generator=g) / math.sqrt(math.prod(shape[1:]))
+        sd[name] = t.to(dtype)
+    return sd

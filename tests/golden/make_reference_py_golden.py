@@ -6,6 +6,8 @@ container (they cannot travel to the GPU box, the vectors can):
        extracted from the file with `ast` and executed verbatim in a namespace holding torch / F / np)
   lib/core/utils/camera_utils.py   : look_at, random_surround_views (same extraction)
   lib/ops/edge_dilation.py         : edge_dilation (imported as a module: it only needs torch)
+  lib/core/diffusion.py            : get_noise_scales (extracted)
+  lib/pipelines/utils.py           : get_camera_dists, prune_cameras (extracted, with lib/ops/rotation_conversions.py helpers)
 
 Nothing is copied into the repo; the reference sources are read where they lie under /root/reference.
 Run from the repo root (needs /root/reference):  python tests/golden/make_reference_py_golden.py
@@ -99,6 +101,18 @@ def main():
     k2, d2 = ns['prune_cameras'](d.clone(), 4, 9, 'cpu', pixel_dist=pd.clone())
     out['prune_keep_16'], out['prune_dists_16'] = k1.numpy(), d1.numpy()
     out['prune_keep_9'], out['prune_dists_9'] = k2.numpy(), d2.numpy()
+    # noise scales of integer / fractional timesteps (lib/core/diffusion.py:4-21)
+    (gns,) = extract(os.path.join(REF, 'lib/core/diffusion.py'), ['get_noise_scales'])
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2      # SD's scaled-linear schedule
+    ab = torch.cumprod(1 - betas, dim=0)
+    out['ns_alphas_bar'] = ab.numpy()
+    ti = torch.tensor([0, 1, 17, 500, 998, 999])
+    tf = torch.tensor([0.0, 0.25, 17.5, 499.999, 998.75, 999.0])
+    out['ns_t_int'], out['ns_t_float'] = ti.numpy(), tf.numpy()
+    a, b = gns(ab, ti, 1000)
+    out['ns_int_a'], out['ns_int_b'] = a.numpy(), b.numpy()
+    a, b = gns(ab, tf, 1000)
+    out['ns_float_a'], out['ns_float_b'] = a.numpy(), b.numpy()
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, os.path.getsize(OUT), 'bytes;', {k: v.shape for k, v in out.items()})
 

@@ -174,3 +174,4 @@ def test_two_pass_with_reference_latents(lib):
     # pass 2 decodes again with ControlNet residuals and still reads the decoder-side reference tokens
     n2 = p.get_noise_pred_p2([lat.cuda()], [emb.cuda()], dec_args, dec_kwargs, 400, 5.0, [img], 0.5)
     assert n2.shape == n1.shape and torch.isfinite(n2).all() and not torch.equal(n1, n2)
+

@@ -336,3 +336,48 @@ def test_conv3x3_with_fused_shortcut(lib, B, H, C1, C3, C4):
         check('conv3x3 + shortcut', outs[0], to_nhwc(ref), dtype)
     finally:
         tune(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,C,Cout', [(2, 16, 12, 64, 64), (1, 64, 64, 128, 128), (2, 8, 8, 32, 32)])
+def test_conv3x3_downsample_pad_bottom_right(lib, B, H, W, C, Cout):
+    """diffusers Downsample2D(padding=0) of the VAE encoder: F.pad(x, (0, 1, 0, 1)) then a stride-2 conv without padding
+    (MVE_CONV_PAD_BR); both weight layouts, both kernels bit-identical."""
+    from mvedit_amd import ops, _lib
+    dtype = torch.float16
+    x = rnd((B, C, H, W), dtype, 1)
+    w = rnd((Cout, C, 3, 3), dtype, 2, (9 * C) ** -0.5)
+    bias = rnd((Cout,), torch.float32, 3)
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), bias, stride=2)
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        for chunk64 in ([False, True] if C % 64 == 0 else [False]):
+            w_k, wflag = ops.pack_conv_weight(w, chunk64)
+            outs = []
+            for big in (0, 1):
+                tune(1 if big else 0)
+                out, Ho, Wo = ops.conv3x3(to_nhwc(x).cuda(), w_k.cuda(), B, H, W, stride=2, bias=bias.cuda(), flags=wflag | ops.PAD_BR)
+                assert (Ho, Wo) == (H // 2, W // 2)
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1])
+            check('conv3x3 pad_br', outs[0], to_nhwc(ref), dtype, f'chunk64={chunk64}')
+    finally:
+        tune(old)
+    with pytest.raises(_lib.MveError):      # the flag only exists for the stride-2 downsampler
+        ops.conv3x3(to_nhwc(x).cuda(), w_k.cuda(), B, H, W, stride=1, bias=bias.cuda(), flags=wflag | ops.PAD_BR)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('M,N', [(64, 128), (7, 4096), (3, 1028)])
+def test_softmax_rows(lib, dtype, M, N):
+    from mvedit_amd import ops
+    s = rnd((M, N), torch.float32, 1) * 6
+    s[0, :4] = 60.0                                               # a dominated row: everything else underflows to zero
+    out = ops.softmax_rows(s.cuda(), dtype)
+    ref = torch.softmax(s, dim=-1)
+    assert out.dtype == dtype and out.shape == (M, N)
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert ((out.float().cpu() - ref).abs() <= eps * ref + 1e-7).all()
+    assert (out.float().sum(-1).cpu() - 1).abs().max() < 4 * eps
