@@ -196,6 +196,15 @@ def secondary(dev):
     db = tets.shape[0] * (16 + 8 + 8) + pos.shape[0] * 24
     out['dmtet'] = dict(ms=round(t * 1e3, 3), tets=int(tets.shape[0]), verts_out=int(vv.shape[0]), faces_out=int(ff.shape[0]),
                         mtets_per_s=round(tets.shape[0] / t / 1e6, 1), algorithmic_GBps=round(db / t / 1e9, 1))
+    # ---- SD VAE: decode the V views' x0 latents to 512^2 images / encode them back (mvedit_3d_pipeline.py:1258-1262, :1439-1443) --------
+    from mvedit_amd.vae import AutoencoderKLEngine, SD_VAE_CONFIG
+    vae = AutoencoderKLEngine.from_state_dict(SY.make_vae_state_dict(dict(SD_VAE_CONFIG), dtype=torch.float16), dict(SD_VAE_CONFIG), torch.float16, dev)
+    zs = torch.randn(VIEWS, 4, LATENT, LATENT, device=dev, dtype=torch.float16)
+    im = torch.rand(VIEWS, 3, 8 * LATENT, 8 * LATENT, device=dev, dtype=torch.float16) * 2 - 1
+    for name, half, inp in (('vae_decode', vae.decoder, zs), ('vae_encode', vae.encoder, im)):
+        t = timed(lambda: half.run(inp, 8), it=2)
+        fl = sum(half.plan(8, inp.shape[2], inp.shape[3], torch.float16)['flops'].values()) / 8 * VIEWS
+        out[name] = dict(ms=round(t * 1e3, 2), views=VIEWS, ms_per_view=round(t * 1e3 / VIEWS, 3), tflops_per_s=round(fl / t / 1e12, 1))
     return out
 
 
@@ -324,7 +333,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         if world == 1 and not args.no_secondary:
-            line['secondary'] = secondary(dev)
+            try:
+                line['secondary'] = secondary(dev)
+            except Exception as e:      # a secondary figure must never take the headline line with it
+                line['secondary'] = {'error': repr(e)[:300]}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -344,8 +344,13 @@ int gemm_big_min_blocks() {
     return g_big_min_blocks;
 }
 
+// The 320-wide tile only pays when most of its columns are live: N = 128 (the VAE's image-resolution convs) or N = 8 (conv_out)
+// would spend 60 % / 97 % of the MFMA work on dead columns, and the 128 x {64,128,160} kernel gives bit-identical results.
+bool big_tile_fits(int N) { return (long long)N * 4 >= (long long)((N + 319) / 320) * 320 * 3; }
+
 template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
+    if (!big_tile_fits(p.N)) return launch_v<Tag, MODE>(p, s);
     // enough 256 x 320 tiles to fill the chip WITHOUT cutting K: one block per tile walks the slices one after the other and
     // reproduces the split-K rounding exactly (GemmParams::splitk_seq) -- no partial tiles, no reducer launch
     if (gemm_big_min_blocks() > 0 && p.splitk > 1 && g_seq_splitk && mve_gemm_big_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&

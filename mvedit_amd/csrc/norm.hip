@@ -16,8 +16,9 @@
 
 namespace {
 
-constexpr int GN_TX = 64;   // chunks (of 8 channels) handled side by side by one block
-constexpr int GN_TY = 4;    // rows in flight per block
+// A block is 256 threads: TX chunks (of 8 channels) side by side x TY = 256 / TX rows in flight.  TX = 64 for the UNet's widths
+// (C >= 320); the VAE's 128 / 256-channel tensors at image resolution use TX = 16 / 32 so that no lane idles.
+constexpr int GN_THREADS = 256;
 
 template <class Tag>
 __device__ __forceinline__ void load8(const typename Tag::T* p, float (&v)[8]) {
@@ -41,8 +42,9 @@ __device__ __forceinline__ const typename Tag::T* gn_chunk_ptr(const GNSrc& s, i
     return reinterpret_cast<const T*>(s.x2) + ((size_t)b * s.HW + r) * s.C2 + (ch - s.C1);
 }
 
-template <class Tag>
-__global__ __launch_bounds__(GN_TX* GN_TY) void k_gn_partial(GNSrc s, int nsplit, float* __restrict__ partial) {
+template <class Tag, int GN_TX>
+__global__ __launch_bounds__(GN_THREADS) void k_gn_partial(GNSrc s, int nsplit, float* __restrict__ partial) {
+    constexpr int GN_TY = GN_THREADS / GN_TX;
     // partial: [B][nsplit][C][2]
     __shared__ float red[GN_TY][GN_TX][16];
     const int C = s.C1 + s.C2;
@@ -103,10 +105,11 @@ __global__ void k_gn_finalize(const float* __restrict__ partial, int B, int nspl
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-template <class Tag>
-__global__ __launch_bounds__(GN_TX* GN_TY) void k_gn_apply(GNSrc s, int nsplit, int G, const float* __restrict__ stats,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int silu, void* __restrict__ out) {
+template <class Tag, int GN_TX>
+__global__ __launch_bounds__(GN_THREADS) void k_gn_apply(GNSrc s, int nsplit, int G, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int silu, void* __restrict__ out) {
+    constexpr int GN_TY = GN_THREADS / GN_TX;
     typedef typename Tag::T T;
     typedef typename Tag::V8 V8;
     const int C = s.C1 + s.C2;
@@ -196,7 +199,14 @@ __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, i
     }
 }
 
-int gn_nsplit(int B, int HW, int ncolgroups) {
+int gn_tx(int C) { return C <= 128 ? 16 : (C <= 256 ? 32 : 64); }
+
+int gn_nsplit(int B, int HW, int C) {
+    if (gn_tx(C) < 64) {      // narrow tensors are the large-image ones: ~512 rows per block, independent of the batch
+        const int ns = HW / 512;
+        return ns < 1 ? 1 : (ns > 512 ? 512 : ns);
+    }
+    const int ncolgroups = (C / 8 + 63) / 64;
     // enough blocks to fill 256 CUs several times over, but at least 32 rows per block
     int want = (256 * 8 + B * ncolgroups - 1) / (B * ncolgroups);
     int maxsplit = HW / 32 > 0 ? HW / 32 : 1;
@@ -208,16 +218,21 @@ template <class Tag>
 int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* beta, int silu, void* out, float* ws,
            hipStream_t st) {
     const int C = s.C1 + s.C2;
-    const int ncg = (C / 8 + GN_TX - 1) / GN_TX;
-    const int ns = gn_nsplit(s.B, s.HW, ncg);
+    const int tx = gn_tx(C);
+    const int ncg = (C / 8 + tx - 1) / tx;
+    const int ns = gn_nsplit(s.B, s.HW, C);
     float* partial = ws;
     float* stats = ws + (size_t)s.B * ns * C * 2;
-    dim3 grid(ns, ncg, s.B), block(GN_TX, GN_TY);
-    k_gn_partial<Tag><<<grid, block, 0, st>>>(s, ns, partial);
+    dim3 grid(ns, ncg, s.B), block(tx, GN_THREADS / tx);
+    if (tx == 16) k_gn_partial<Tag, 16><<<grid, block, 0, st>>>(s, ns, partial);
+    else if (tx == 32) k_gn_partial<Tag, 32><<<grid, block, 0, st>>>(s, ns, partial);
+    else k_gn_partial<Tag, 64><<<grid, block, 0, st>>>(s, ns, partial);
     MVE_LAUNCH_CHECK();
     k_gn_finalize<<<mve_cdiv(s.B * G, 4), 256, 0, st>>>(partial, s.B, ns, C, G, s.HW, eps, stats);
     MVE_LAUNCH_CHECK();
-    k_gn_apply<Tag><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+    if (tx == 16) k_gn_apply<Tag, 16><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+    else if (tx == 32) k_gn_apply<Tag, 32><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+    else k_gn_apply<Tag, 64><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }
@@ -241,8 +256,7 @@ extern "C" {
 
 size_t mve_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
     if (B <= 0 || HW <= 0 || C <= 0) return 64;
-    const int ncg = (C / 8 + GN_TX - 1) / GN_TX;
-    const int ns = gn_nsplit(B, HW, ncg);
+    const int ns = gn_nsplit(B, HW, C);
     return sizeof(float) * ((size_t)B * ns * C * 2 + (size_t)B * G * 2 + 16);
 }
 

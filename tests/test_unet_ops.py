@@ -142,7 +142,10 @@ def test_conv3x3_resblock_epilogue(lib):
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('B,HW,C1,C2,silu,eps', [(2, 64 * 64, 320, 0, True, 1e-5), (3, 16 * 16, 1280, 640, True, 1e-5),
                                                   (2, 8 * 8, 2560, 0, True, 1e-5), (2, 32 * 32, 640, 0, False, 1e-6),
-                                                  (1, 33, 640, 320, True, 1e-5)])
+                                                  (1, 33, 640, 320, True, 1e-5),
+                                                  # the VAE's narrow tensors (16- and 32-lane layouts, many row splits)
+                                                  (2, 96 * 96, 128, 0, True, 1e-6), (1, 64 * 64, 256, 0, False, 1e-6),
+                                                  (2, 700, 64, 64, True, 1e-6), (3, 231, 32, 0, True, 1e-6)])
 def test_groupnorm(lib, dtype, B, HW, C1, C2, silu, eps):
     from mvedit_amd import ops
     C = C1 + C2
@@ -339,7 +342,7 @@ def test_conv3x3_with_fused_shortcut(lib, B, H, C1, C3, C4):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,H,W,C,Cout', [(2, 16, 12, 64, 64), (1, 64, 64, 128, 128), (2, 8, 8, 32, 32)])
+@pytest.mark.parametrize('B,H,W,C,Cout', [(2, 16, 12, 64, 64), (1, 64, 64, 128, 320), (2, 8, 8, 32, 32)])
 def test_conv3x3_downsample_pad_bottom_right(lib, B, H, W, C, Cout):
     """diffusers Downsample2D(padding=0) of the VAE encoder: F.pad(x, (0, 1, 0, 1)) then a stride-2 conv without padding
     (MVE_CONV_PAD_BR); both weight layouts, both kernels bit-identical."""
