@@ -150,19 +150,20 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     // ---- staging ---------------------------------------------------------------------------------
     // fast conv addressing for the slab-major K order without upsample (see gemm_big.hip): uniform tap / slab arithmetic,
     // one multiply-add per row, the halo test is a bit of a per-row mask computed once
-    const bool fast = MODE == 1 && p.g.chunk64 && !p.g.ups;
+    const bool fast = MODE == 1 && p.g.chunk64;
     int pix[A_PASSES];
     unsigned vmask[A_PASSES];
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
-            pix[j] = (cb[j] * p.g.Hs + cy[j]) * p.g.Ws + cx[j];
+            pix[j] = (cb[j] * p.g.Hs + (cy[j] >> p.g.ups)) * p.g.Ws + (cx[j] >> p.g.ups);     // upsample: see gemm_big.hip
             unsigned mk = 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int yi = cy[j] + t / 3, xi = cx[j] + t % 3;
                 if (yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv) mk |= 1u << t;
             }
+            if (p.g.ups) mk |= ((unsigned)(cy[j] & 1) << 9) | ((unsigned)(cx[j] & 1) << 10);
             vmask[j] = mk;
         }
     }
@@ -184,11 +185,13 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
                 cs = second ? p.g.C4 : p.g.C3;
                 ch = (second ? c0 - p.g.C3 : c0) + lc * 8;
             }
-            const int dy = t_ / 3;
-            const int toff = dy * p.g.Ws + (t_ - dy * 3);
+            const int dy = t_ / 3, dx = t_ - dy * 3;
+            const int toff = dy * p.g.Ws + dx;
 #pragma unroll
             for (int j = 0; j < A_PASSES; ++j) {
-                const unsigned off = (unsigned)((pix[j] + toff) * cs + ch);
+                int to = toff;
+                if (p.g.ups) to = (int)((((vmask[j] >> 9) & 1u) + dy) >> 1) * p.g.Ws + (int)((((vmask[j] >> 10) & 1u) + dx) >> 1);
+                const unsigned off = (unsigned)((pix[j] + to) * cs + ch);
                 const T* s = ((vmask[j] >> t_) & 1u) ? src + off : zero;
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES), 16, 0, 0);
             }
@@ -344,16 +347,17 @@ int gemm_big_min_blocks() {
     return g_big_min_blocks;
 }
 
-// The 320-wide tile only pays when most of its columns are live: N = 128 (the VAE's image-resolution convs) or N = 8 (conv_out)
-// would spend 60 % / 97 % of the MFMA work on dead columns, and the 128 x {64,128,160} kernel gives bit-identical results.
-bool big_tile_fits(int N) { return (long long)N * 4 >= (long long)((N + 319) / 320) * 320 * 3; }
+// The big-tile kernel exists 320 columns wide (every UNet width) and 256 wide (the VAE's 256 / 512-channel convs; no split-K
+// variants).  Any other N -- 128 at image resolution, 8 for conv_out -- would leave most of a big tile dead and takes the
+// 128 x {64,128,160} kernel, whose results are bit-identical.
+bool big_tile_fits(int N, int splitk) { return N % 320 == 0 || (N % 256 == 0 && splitk <= 1); }
 
 template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
-    if (!big_tile_fits(p.N)) return launch_v<Tag, MODE>(p, s);
+    if (!big_tile_fits(p.N, p.splitk)) return launch_v<Tag, MODE>(p, s);
     // enough 256 x 320 tiles to fill the chip WITHOUT cutting K: one block per tile walks the slices one after the other and
     // reproduces the split-K rounding exactly (GemmParams::splitk_seq) -- no partial tiles, no reducer launch
-    if (gemm_big_min_blocks() > 0 && p.splitk > 1 && g_seq_splitk && mve_gemm_big_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&
+    if (gemm_big_min_blocks() > 0 && p.splitk > 1 && p.N % 320 == 0 && g_seq_splitk && mve_gemm_big_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&
         (size_t)mve_gemm_big_blocks(p.M, p.N, 1) * 256 * 320 <= (size_t)p.splitk * p.M * p.N) {
         GemmParams q = p;
         q.splitk_seq = p.splitk;

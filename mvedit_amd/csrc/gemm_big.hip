@@ -15,21 +15,26 @@
 
 namespace {
 
-constexpr int BM2 = 256, BN2 = 320, NTH = 512;
+// The tile width BN2 is a template parameter: 320 (wave tile 128 x 80, every UNet width is a multiple of 320) or 256 (wave tile
+// 128 x 64: the VAE's 256 / 512-channel convolutions, whose N is not a multiple of 320).
+constexpr int BM2 = 256, NTH = 512;
 constexpr int WAVES_N = 4;
-constexpr int WTM = 128, WTN = 80;
-constexpr int MF = WTM / 16, NF = WTN / 16;          // 8 x 5 fragments per wave
+constexpr int WTM = 128;
+constexpr int MF = WTM / 16;                         // 8 fragments per wave along M
 constexpr int RPP = NTH / 8;                         // 64 rows per load pass
-constexpr int A_PASSES = BM2 / RPP, B_PASSES = BN2 / RPP;   // 4, 5
-constexpr int A_STAGE = BM2 * ROW_BYTES, B_STAGE = BN2 * ROW_BYTES, STAGE = A_STAGE + B_STAGE;
-constexpr int CS_LD = BN2 + 4;
-constexpr int SMEM_BIG = 2 * STAGE;                  // 147456 B; the fp32 epilogue tile (64 x 324 x 4 B) lives inside it
-static_assert(64 * CS_LD * 4 <= SMEM_BIG, "epilogue staging must fit");
+constexpr int A_PASSES = BM2 / RPP;                  // 4
+constexpr int A_STAGE = BM2 * ROW_BYTES;
+constexpr int smem_big(int bn2) { return 2 * (A_STAGE + bn2 * ROW_BYTES); }      // 320: 147456 B; the fp32 epilogue tile lives inside it
+static_assert(64 * (320 + 4) * 4 <= smem_big(320) && 64 * (256 + 4) * 4 <= smem_big(256), "epilogue staging must fit");
 
-template <class Tag, int MODE, bool SEQ, bool FAST>      // FAST (conv only): slab-major K order without upsample
+template <class Tag, int MODE, bool SEQ, bool FAST, int BN2>      // FAST (conv only): slab-major K order
 __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
+    constexpr int WTN = BN2 / WAVES_N, NF = WTN / 16;          // 80 -> 5 fragments, 64 -> 4
+    constexpr int B_PASSES = BN2 / RPP;                        // 5 | 4
+    constexpr int STAGE = A_STAGE + BN2 * ROW_BYTES;
+    constexpr int CS_LD = BN2 + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -71,13 +76,16 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
             cy[j] = y * p.g.stride - p.g.pad;
             cx[j] = (r - y * p.g.Wo) * p.g.stride - p.g.pad;
             if constexpr (FAST) {     // per-row pixel base and 9-bit halo mask; cb/cy/cx are dead after this in the fast kernel
-                pix[j] = (cb[j] * p.g.Hs + cy[j]) * p.g.Ws + cx[j];
+                // nearest 2x upsample: the source pixel of virtual (y, x) is (y >> 1, x >> 1); bits 9 / 10 keep the parities of the
+                // window origin, from which a tap's source offset is ((parity + d) >> 1)
+                pix[j] = (cb[j] * p.g.Hs + (cy[j] >> p.g.ups)) * p.g.Ws + (cx[j] >> p.g.ups);
                 unsigned mk = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int yi = cy[j] + t / 3, xi = cx[j] + t % 3;
                     if (yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv) mk |= 1u << t;
                 }
+                if (p.g.ups) mk |= ((unsigned)(cy[j] & 1) << 9) | ((unsigned)(cx[j] & 1) << 10);
                 vmask[j] = mk;
             }
         }
@@ -126,11 +134,13 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
                 cs = second ? p.g.C4 : p.g.C3;
                 ch = (second ? c0 - p.g.C3 : c0) + lc * 8;
             }
-            const int dy = t_ / 3;
-            const int toff = dy * p.g.Ws + (t_ - dy * 3);
+            const int dy = t_ / 3, dx = t_ - dy * 3;
+            const int toff = dy * p.g.Ws + dx;
 #pragma unroll
             for (int j = 0; j < A_PASSES; ++j) {
-                const unsigned off = (unsigned)((pix[j] + toff) * cs + ch);
+                int to = toff;
+                if (p.g.ups) to = (int)((((vmask[j] >> 9) & 1u) + dy) >> 1) * p.g.Ws + (int)((((vmask[j] >> 10) & 1u) + dx) >> 1);
+                const unsigned off = (unsigned)((pix[j] + to) * cs + ch);
                 const T* s = ((vmask[j] >> t_) & 1u) ? src + off : zero;
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * RPP + wid * 8) * ROW_BYTES), 16, 0, 0);
             }
@@ -288,38 +298,46 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
     }
 }
 
-template <class Tag, int MODE, bool SEQ, bool FAST>
+int big_bn(int N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : 0); }
+
+template <class Tag, int MODE, bool SEQ, bool FAST, int BN2>
 int launch_big3(const GemmParams& p, hipStream_t s) {
     static bool configured[64] = {};             // the attribute is per device; one process may drive several
     int dev = 0;
     MVE_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !configured[dev]) {
-        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big<Tag, MODE, SEQ, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BIG));
+        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_big<Tag, MODE, SEQ, FAST, BN2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    smem_big(BN2)));
         configured[dev] = true;
     }
     const unsigned grid = (unsigned)mve_cdiv(p.M, BM2) * (unsigned)mve_cdiv(p.N, BN2) * (unsigned)(p.splitk > 1 ? p.splitk : 1);
-    k_gemm_big<Tag, MODE, SEQ, FAST><<<grid, NTH, SMEM_BIG, s>>>(p);
+    k_gemm_big<Tag, MODE, SEQ, FAST, BN2><<<grid, NTH, smem_big(BN2), s>>>(p);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }
-template <class Tag, int MODE, bool SEQ>
+template <class Tag, int MODE, bool SEQ, int BN2>
 int launch_big2(const GemmParams& p, hipStream_t s) {
     if constexpr (MODE == 1) {
-        if (p.g.chunk64 && !p.g.ups) return launch_big3<Tag, MODE, SEQ, true>(p, s);
+        if (p.g.chunk64) return launch_big3<Tag, MODE, SEQ, true, BN2>(p, s);
     }
-    return launch_big3<Tag, MODE, SEQ, false>(p, s);
+    return launch_big3<Tag, MODE, SEQ, false, BN2>(p, s);
 }
 template <class Tag, int MODE>
 int launch_big(const GemmParams& p, hipStream_t s) {
-    return p.splitk_seq > 1 ? launch_big2<Tag, MODE, true>(p, s) : launch_big2<Tag, MODE, false>(p, s);
+    if (big_bn(p.N) == 256) {      // no split-K variants of the 256-wide tile (mve_gemm_big_blocks reports such shapes as not eligible)
+        MVE_CHECK(p.splitk <= 1 && p.splitk_seq <= 1, MVE_ERR_ARG, "gemm_big: the 256-wide tile does not split K");
+        return launch_big2<Tag, MODE, false, 256>(p, s);
+    }
+    return p.splitk_seq > 1 ? launch_big2<Tag, MODE, true, 320>(p, s) : launch_big2<Tag, MODE, false, 320>(p, s);
 }
 
 }  // namespace
 
 // number of blocks the 256 x 320 kernel would launch (0: shape not eligible)
 long long mve_gemm_big_blocks(int M, int N, int splitk) {
-    if (N % BN2 != 0 || M < 64) return 0;
-    return (long long)mve_cdiv(M, BM2) * (N / BN2) * (splitk > 1 ? splitk : 1);
+    const int bn = big_bn(N);
+    if (bn == 0 || M < 64 || (bn == 256 && splitk > 1)) return 0;
+    return (long long)mve_cdiv(M, BM2) * (N / bn) * (splitk > 1 ? splitk : 1);
 }
 
 // main loop + epilogue (or split-K partials; the caller runs the reducer)

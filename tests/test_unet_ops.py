@@ -384,3 +384,58 @@ def test_softmax_rows(lib, dtype, M, N):
     eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
     assert ((out.float().cpu() - ref).abs() <= eps * ref + 1e-7).all()
     assert (out.float().sum(-1).cpu() - 1).abs().max() < 4 * eps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('B,H,W,C1,C2,Cout,stride,ups', [
+    (2, 10, 6, 128, 0, 320, 1, True),        # Upsample2D through the per-row fast addressing, odd-ish non-square size
+    (1, 16, 16, 64, 64, 256, 1, True),       # ... with a concatenated input, 256-wide big tile
+    (2, 16, 16, 128, 0, 256, 1, False),      # 256-wide big tile (the VAE's widths), plain
+    (2, 16, 16, 128, 0, 512, 2, False),
+])
+def test_conv3x3_big_tiles_and_upsample_addressing(lib, dtype, B, H, W, C1, C2, Cout, stride, ups):
+    """The 256 x {320, 256} kernels against the 128-row kernel (bit-identical, forced through mve_gemm_tune) and the reference:
+    nearest-2x upsample in the slab-major fast addressing path, and the 256-wide tile used for N = 256 / 512."""
+    from mvedit_amd import ops, _lib
+    x1 = rnd((B, C1, H, W), dtype, 1)
+    x2 = rnd((B, C2, H, W), dtype, 2) if C2 else None
+    C = C1 + C2
+    w = rnd((Cout, C, 3, 3), dtype, 3, (9 * C) ** -0.5)
+    bias = rnd((Cout,), torch.float32, 4)
+    ref = conv_ref(torch.cat([x1, x2], 1) if C2 else x1, w, bias, stride, ups)
+    w_k, wflag = ops.pack_conv_weight(w, True)
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        outs = []
+        for big in (0, 1):
+            tune(1 if big else 0)
+            out, Ho, Wo = ops.conv3x3(to_nhwc(x1).cuda(), w_k.cuda(), B, H, W, x2=to_nhwc(x2).cuda() if C2 else None, stride=stride,
+                                      upsample=ups, bias=bias.cuda(), flags=wflag)
+            outs.append(out)
+        assert (Ho, Wo) == tuple(ref.shape[2:])
+        assert torch.equal(outs[0], outs[1])
+        check('conv3x3 big/upsample', outs[0], to_nhwc(ref), dtype, f'{(B, H, W, C1, C2, Cout, stride, ups)}')
+    finally:
+        tune(old)
+
+
+@pytest.mark.gpu
+def test_gemm_256_wide_tile_matches_small_kernel(lib):
+    from mvedit_amd import ops, _lib
+    dtype = torch.float16
+    M, N, K = 700, 512, 328
+    a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    bias = rnd((N,), torch.float32, 3)
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        outs = []
+        for big in (0, 1):
+            tune(1 if big else 0)
+            outs.append(ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda()))
+        assert torch.equal(outs[0], outs[1])
+        check('gemm 256-wide', outs[0], a.float() @ w.float().t() + bias, dtype)
+    finally:
+        tune(old)
