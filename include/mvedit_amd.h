@@ -335,6 +335,23 @@ MVE_API int mve_vae_plan(void* handle, int B, int H, int W, int io_dtype, size_t
 MVE_API int mve_vae_forward(void* handle, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
                             size_t workspace_bytes, float* op_ms, void* stream);
 
+/* SRVGGNetCompact (`image_enhancer` of the pipelines: lib/models/decoders/image_space_ss.py:8-70, built at lib/pipelines/utils.py:212-215
+ * with num_feat 64, num_conv 32, upscale 4, PReLU; called on every batch of rendered views below 512 x 512,
+ * lib/pipelines/mvedit_3d_pipeline.py:1399-1400).  [B, C, H, W] -> [B, C, H * r, W * r]: conv3x3 + per-channel PReLU stack at the
+ * input resolution, conv to C * r * r channels, PixelShuffle(r), plus the nearest-upsampled input.  An executor handle: parameters
+ * through mve_unet_load_param under the module's own state-dict names (`body.<i>.weight|bias`), mve_unet_missing_params /
+ * mve_unet_op_info / mve_unet_destroy apply.  num_out_ch == num_in_ch <= 8, num_feat % 8 == 0. */
+MVE_API int mve_srvgg_create(void** handle, int dtype, int num_in_ch, int num_out_ch, int num_feat, int num_conv, int upscale);
+MVE_API int mve_srvgg_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, double* flops);
+MVE_API int mve_srvgg_forward(void* handle, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
+                              size_t workspace_bytes, float* op_ms, void* stream);
+/* y = x >= 0 ? x : slope[c] * x over NHWC rows (nn.PReLU(num_parameters=C), image_space_ss.py:41-56); n = rows * C elements */
+MVE_API int mve_prelu(int dtype, const void* d_x, const float* d_slope, int C, void* d_y, size_t n, void* stream);
+/* out[b][c][y*r+i][x*r+j] = src[(b,y,x)][c*r*r + i*r + j] + base[b][c][y][x]: nn.PixelShuffle(r) of an NHWC fp32 tensor (row stride ld)
+ * plus F.interpolate(base, scale_factor=r, mode='nearest') (image_space_ss.py:66-69); base and out NCHW in io_dtype. */
+MVE_API int mve_pixel_shuffle_add(int io_dtype, const float* d_src, int ld, const void* d_base, int B, int C, int H, int W, int r,
+                                  void* d_out, void* stream);
+
 /* Tuning knob for engines created AFTER the call: 1 (default) folds every ResnetBlock2D conv_shortcut into conv2's K loop
  * (mve_conv3x3_shortcut), 0 keeps the separate 1x1 GEMMs; negative only queries.  Returns the previous setting. */
 MVE_API int mve_unet_tune(int fuse_shortcut);

@@ -141,6 +141,57 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
 }
 }  // namespace
 
+namespace {
+// per-channel PReLU on NHWC rows (nn.PReLU(num_parameters=C) of SRVGGNetCompact, lib/models/decoders/image_space_ss.py:41-56)
+template <class Tag>
+__global__ __launch_bounds__(NT) void k_prelu(const typename Tag::T* __restrict__ x, const float* __restrict__ slope, int c8,
+                                              typename Tag::T* __restrict__ y, size_t n8) {
+    typedef typename Tag::V8 V8;
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n8) return;
+    const int c0 = (int)(i % (size_t)c8) * 8;
+    const V8 v = reinterpret_cast<const V8*>(x)[i];
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(slope + c0), a1 = *reinterpret_cast<const f32x4*>(slope + c0 + 4);
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float f = Tag::to_f32(v[e]);
+        o[e] = Tag::from_f32(f >= 0.f ? f : f * (e < 4 ? a0[e] : a1[e - 4]));
+    }
+    reinterpret_cast<V8*>(y)[i] = o;
+}
+
+// nn.PixelShuffle(r) of an NHWC fp32 tensor + the nearest-upsampled network input (image_space_ss.py:63-70):
+//   out[b][c][y*r+i][x*r+j] = src[(b,y,x)][c*r*r + i*r + j] + base[b][c][y][x],  NCHW output in the caller's dtype
+template <class Dst, class Base>
+__global__ __launch_bounds__(NT) void k_pixel_shuffle_add(const float* __restrict__ src, int ld, const Base* __restrict__ base, int B, int C,
+                                                          int H, int W, int r, Dst* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;          // over the output, x fastest
+    const int Wo = W * r, Ho = H * r;
+    const size_t total = (size_t)B * C * Ho * Wo;
+    if (i >= total) return;
+    const int X = (int)(i % Wo);
+    const size_t t = i / Wo;
+    const int Y = (int)(t % Ho);
+    const size_t u = t / Ho;
+    const int c = (int)(u % C), b = (int)(u / C);
+    const int y = Y / r, x = X / r, ii = Y - y * r, jj = X - x * r;
+    const float v = src[(((size_t)b * H + y) * W + x) * ld + c * r * r + ii * r + jj] + (float)base[(((size_t)b * C + c) * H + y) * W + x];
+    out[i] = (Dst)v;
+}
+
+template <class Dst>
+int pixel_shuffle_add_dst(int base_dtype, const float* src, int ld, const void* base, int B, int C, int H, int W, int r, Dst* out, hipStream_t s) {
+    const unsigned grid = mve_cdiv((size_t)B * C * H * r * W * r, NT);
+    if (base_dtype == MVE_F32) k_pixel_shuffle_add<Dst, float><<<grid, NT, 0, s>>>(src, ld, (const float*)base, B, C, H, W, r, out);
+    else if (base_dtype == MVE_F16) k_pixel_shuffle_add<Dst, f16><<<grid, NT, 0, s>>>(src, ld, (const f16*)base, B, C, H, W, r, out);
+    else if (base_dtype == MVE_BF16) k_pixel_shuffle_add<Dst, bf16><<<grid, NT, 0, s>>>(src, ld, (const bf16*)base, B, C, H, W, r, out);
+    else { mve_set_error("pixel_shuffle_add: bad dtype"); return MVE_ERR_ARG; }
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int mve_nchw_to_nhwc(int dst_dtype, int src_dtype, const void* x, int B, int C, int H, int W, int Cpad, void* y, void* stream) {
@@ -252,6 +303,29 @@ int mve_softmax_rows(int dtype, const float* d_scores, size_t lds, int M, int N,
     else { mve_set_error("softmax_rows: unsupported dtype %d", dtype); return MVE_ERR_ARG; }
     MVE_LAUNCH_CHECK();
     return MVE_OK;
+}
+
+int mve_prelu(int dtype, const void* x, const float* slope, int C, void* y, size_t n, void* stream) {
+    if (n == 0) return MVE_OK;
+    MVE_CHECK(x && y && slope && C > 0 && C % 8 == 0 && n % (size_t)C == 0, MVE_ERR_ARG, "prelu: C must be a multiple of 8 dividing n");
+    const unsigned grid = mve_cdiv(n / 8, NT);
+    if (dtype == MVE_F16) k_prelu<F16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const f16*)x, slope, C / 8, (f16*)y, n / 8);
+    else if (dtype == MVE_BF16) k_prelu<BF16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const bf16*)x, slope, C / 8, (bf16*)y, n / 8);
+    else { mve_set_error("prelu: bad dtype"); return MVE_ERR_ARG; }
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_pixel_shuffle_add(int io_dtype, const float* d_src, int ld, const void* d_base, int B, int C, int H, int W, int r, void* d_out,
+                          void* stream) {
+    if (B == 0) return MVE_OK;
+    MVE_CHECK(d_src && d_base && d_out && C > 0 && r > 0 && ld >= C * r * r, MVE_ERR_ARG, "pixel_shuffle_add: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (io_dtype == MVE_F32) return pixel_shuffle_add_dst<float>(io_dtype, d_src, ld, d_base, B, C, H, W, r, (float*)d_out, s);
+    if (io_dtype == MVE_F16) return pixel_shuffle_add_dst<f16>(io_dtype, d_src, ld, d_base, B, C, H, W, r, (f16*)d_out, s);
+    if (io_dtype == MVE_BF16) return pixel_shuffle_add_dst<bf16>(io_dtype, d_src, ld, d_base, B, C, H, W, r, (bf16*)d_out, s);
+    mve_set_error("pixel_shuffle_add: bad dtype");
+    return MVE_ERR_ARG;
 }
 
 }  // extern "C"

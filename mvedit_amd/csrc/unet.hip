@@ -41,6 +41,8 @@ int mve_timestep_embedding(int, const float*, int, int, void*, void*);
 int mve_silu(int, const void*, void*, size_t, void*);
 int mve_axpy(int, const void*, const void*, float, void*, size_t, void*);
 int mve_softmax_rows(int, const float*, size_t, int, int, void*, size_t, void*);
+int mve_prelu(int, const void*, const float*, int, void*, size_t, void*);
+int mve_pixel_shuffle_add(int, const float*, int, const void*, int, int, int, int, int, void*, void*);
 }
 
 namespace {
@@ -107,6 +109,7 @@ constexpr int CN_EMB[4] = {16, 32, 96, 256};      // diffusers ControlNetModel c
 
 struct Config {
     int controlnet = 0, cond_ch = 3;   // ControlNetModel: encoder + mid of the UNet, conditioning embedding, zero convolutions
+    int sr = 0, sr_scale = 4;          // SRVGGNetCompact (lib/models/decoders/image_space_ss.py): ch[0] = num_feat, layers_per_block = num_conv
     int vae = 0;                       // AutoencoderKL half: 1 = post_quant_conv + Decoder, 2 = Encoder + quant_conv (no time embedding,
                                        // no transformers; in_ch / out_ch are the half's own input / output channels, both <= 8)
     int dtype, in_ch, out_ch, n_levels, layers_per_block, ctx_dim, groups, linear_proj;
@@ -260,6 +263,7 @@ struct XfDesc { std::string name; int c, heads, layers; };
 
 void enumerate(const Config& c, std::vector<ResnetDesc>& rs, std::vector<XfDesc>& xs) {
     const int n = c.n_levels, L = c.layers_per_block;
+    if (c.sr) return;     // a plain conv stack
     if (c.vae) {      // diffusers Encoder / Decoder (autoencoders/vae.py): resnets only, one attention in the mid block
         const int Cm = c.ch[n - 1];
         if (c.vae == 2) {
@@ -335,6 +339,20 @@ void layout_params(Unet& u) {
     u.fuse_sc = g_fuse_shortcut != 0;
     for (int i = 0; i < c.n_levels; ++i) u.fuse_sc = u.fuse_sc && (c.ch[i] % 64 == 0);
     auto need = [&](const std::string& n) { u.expected.push_back(n); };
+    if (c.sr) {
+        // body.0: conv in_ch -> F; body.(2k), k = 1..num_conv: conv F -> F; body.(2k+1): PReLU slopes; last: conv F -> out_ch * r * r
+        const size_t F = c.ch[0];
+        const int last = 2 * (c.layers_per_block + 1), opad = (c.out_ch * c.sr_scale * c.sr_scale + 7) & ~7;
+        for (int k = 0; k <= c.layers_per_block + 1; ++k) {
+            const std::string b = "body." + std::to_string(2 * k);
+            const size_t rows = 2 * k == last ? (size_t)opad : F, cin = k == 0 ? 8 : F;
+            sb.add(b + ".w", rows * 9 * cin, false); need(b + ".weight");
+            sb.add(b + ".b", rows, true); need(b + ".bias");
+            if (2 * k != last) { sb.add("body." + std::to_string(2 * k + 1) + ".a", F, true); need("body." + std::to_string(2 * k + 1) + ".weight"); }
+        }
+        u.slab_bytes = sb.top;
+        return;
+    }
     if (c.vae) {
         // names are the half's own (mve_unet_load_param strips `decoder.` / `encoder.`; (post_)quant_conv is `pq_conv`)
         const int n = c.n_levels, Cm = c.ch[n - 1], Cin0 = c.vae == 1 ? Cm : c.ch[0], Cout0 = c.vae == 1 ? c.ch[0] : Cm;
@@ -542,7 +560,29 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
     const int Cm_ = c.ch[c.n_levels - 1];
     const int vin = c.vae == 1 ? Cm_ : c.ch[0], vout = c.vae == 1 ? c.ch[0] : Cm_;     // widths after conv_in / before conv_out
     const std::string va = "mid_block.attentions.0";
-    if (c.vae && name == "conv_in.weight") {
+    if (c.sr) {
+        MVE_CHECK(name.compare(0, 5, "body.") == 0, MVE_ERR_ARG, "load_param: %s is not a parameter of SRVGGNetCompact", name.c_str());
+        const int idx = atoi(name.c_str() + 5), last = 2 * (c.layers_per_block + 1);
+        const long long F = c.ch[0], nout = (long long)c.out_ch * c.sr_scale * c.sr_scale;
+        const std::string b = "body." + std::to_string(idx);
+        MVE_CHECK(idx >= 0 && idx <= last && name.size() > b.size(), MVE_ERR_ARG, "load_param: no layer %s", name.c_str());
+        const std::string leaf = name.substr(b.size());
+        if (idx % 2 == 1 && leaf == ".weight") rc = vec(P(b + ".a"), 0, F, 1);                      // PReLU slopes
+        else if (idx % 2 == 0 && leaf == ".weight") {
+            Param* pw = P(b + ".w");
+            MVE_CHECK(pw, MVE_ERR_ARG, "load_param: no slot for %s", name.c_str());
+            MVE_HIP(hipMemsetAsync(dstp(pw, 0), 0, pw->bytes, s));
+            rc = idx == 0 ? conv(pw, F, c.in_ch, F, 8) : conv(pw, idx == last ? nout : F, F, 0, F);
+        } else if (idx % 2 == 0 && leaf == ".bias") {
+            Param* pb = P(b + ".b");
+            MVE_CHECK(pb, MVE_ERR_ARG, "load_param: no slot for %s", name.c_str());
+            MVE_HIP(hipMemsetAsync(dstp(pb, 0), 0, pb->bytes, s));
+            rc = vec(pb, 0, idx == last ? nout : F, 1);
+        } else {
+            mve_set_error("load_param: %s is not a parameter of SRVGGNetCompact", name.c_str());
+            return MVE_ERR_ARG;
+        }
+    } else if (c.vae && name == "conv_in.weight") {
         MVE_HIP(hipMemsetAsync(dstp(P("conv_in.w"), 0), 0, P("conv_in.w")->bytes, s));
         rc = conv(P("conv_in.w"), vin, c.in_ch, vin, 8);
     } else if (c.vae && name == "conv_in.bias") rc = vec(P("conv_in.b"), 0, vin, 1);
@@ -969,6 +1009,56 @@ struct Builder {
         return out;
     }
 
+    // SRVGGNetCompact.forward (lib/models/decoders/image_space_ss.py:63-70): conv + PReLU stack at the input resolution, last conv to
+    // out_ch * r * r channels, PixelShuffle(r), plus the nearest-upsampled input.  H x W is the input size.
+    int build_sr(int B_, int H, int W, int io_dtype) {
+        B = B_; dt = c.dtype;
+        const int Bb = B_;
+        pl = Plan();
+        pl.B = Bb; pl.H = H; pl.W = W; pl.n_img = 1; pl.io_dtype = io_dtype;
+        const int e = 2, d = dt, F = c.ch[0], r = c.sr_scale, last = 2 * (c.layers_per_block + 1);
+        const int opad = (c.out_ch * r * r + 7) & ~7;
+        ld_temb = 0; ld_kv = 0;
+        MVE_CHECK((size_t)Bb * H * W * (size_t)(F > opad * 2 ? F : opad * 2) < ((size_t)1 << 31), MVE_ERR_ARG,
+                  "srvgg: batch %d at %dx%d overflows 32-bit activation indexing; enhance in smaller batches", Bb, H, W);
+        const int M = Bb * H * W;
+        rows_img = H * W;
+        Ref src; src.kind = Ref::SAMPLE;
+        Ref cur = ws((size_t)M * 8 * e);
+        {
+            const int in_ch = c.in_ch;
+            Ref x_in = cur;
+            op(OC_OTHER, 0, "nchw->nhwc", [=](const Run& rr) { return mve_nchw_to_nhwc(d, io_dtype, rr.p(src), Bb, in_ch, H, W, 8, rr.p(x_in), rr.stream); });
+        }
+        int cin = 8;
+        for (int k = 0; k <= c.layers_per_block; ++k) {
+            const std::string b = "body." + std::to_string(2 * k);
+            Ref y = ws((size_t)M * F * e);
+            conv(cur, cin, Bb, H, W, 1, 0, wt(b + ".w"), F, y, wt(b + ".b"), Ref(), 0, Ref(), 0, "conv");
+            rel(cur);
+            Ref a = wt("body." + std::to_string(2 * k + 1) + ".a");
+            const size_t nel = (size_t)M * F;
+            op(OC_OTHER, 0, "prelu", [=](const Run& rr) { return mve_prelu(d, rr.p(y), (const float*)rr.p(a), F, rr.p(y), nel, rr.stream); });
+            cur = y; cin = F;
+        }
+        Ref o = ws((size_t)M * opad * 4);
+        conv(cur, F, Bb, H, W, 1, 0, wt("body." + std::to_string(last) + ".w"), opad, o, wt("body." + std::to_string(last) + ".b"), Ref(), 0, Ref(),
+             MVE_GEMM_OUT_F32, "conv (to r*r sub-pixels)");
+        rel(cur);
+        {
+            Ref dst; dst.kind = Ref::OUT;
+            const int oc = c.out_ch;
+            live(o, "pixel shuffle");
+            op(OC_OTHER, 0, "pixel shuffle + nearest-upsampled input", [=](const Run& rr) {
+                return mve_pixel_shuffle_add(io_dtype, (const float*)rr.p(o), opad, rr.p(src), Bb, oc, H, W, r, rr.p(dst), rr.stream);
+            });
+        }
+        pl.enc_end = pl.ops.size();
+        pl.ws_bytes = ar.peak + 256;
+        if (!u.err.empty()) { mve_set_error("srvgg plan: %s", u.err.c_str()); u.err.clear(); return MVE_ERR_STATE; }
+        return MVE_OK;
+    }
+
     // AutoencoderKL half (diffusers 0.27.2 autoencoders/vae.py Decoder / Encoder, as called at lib/pipelines/mvedit_3d_pipeline.py:1260
     // and :1441 of the reference).  H x W is the size of the half's INPUT (latent for the decoder, image for the encoder).
     int build_vae(int B_, int H, int W, int io_dtype) {
@@ -1360,7 +1450,7 @@ int ensure_plan(Unet& u, int B, int H, int W, int n_img, int has_res, int io_dty
     Builder b(u, *np);
     b.ctx_rows_per_img = ctx_len;
     u.cur = nullptr;
-    const int rc = u.cfg.vae ? b.build_vae(B, H, W, io_dtype) : b.build(B, H, W, n_img, has_res, io_dtype, res_nhwc);
+    const int rc = u.cfg.sr ? b.build_sr(B, H, W, io_dtype) : u.cfg.vae ? b.build_vae(B, H, W, io_dtype) : b.build(B, H, W, n_img, has_res, io_dtype, res_nhwc);
     if (rc != MVE_OK) return rc;
     np->ctx_len = ctx_len;
     np->last_use = u.tick;
@@ -1506,10 +1596,11 @@ int mve_vae_create(void** handle, int dtype, int half, int in_channels, int out_
     return MVE_OK;
 }
 
-int mve_vae_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, double* flops) {
-    MVE_CHECK(handle && B > 0 && H > 0 && W > 0, MVE_ERR_ARG, "vae_plan: bad arguments");
+// image networks (VAE halves, SRVGGNetCompact): one NCHW tensor in, one out, no conditioning
+static int imgnet_plan(void* handle, bool want_vae, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, double* flops) {
+    MVE_CHECK(handle && B > 0 && H > 0 && W > 0, MVE_ERR_ARG, "plan: bad arguments");
     Unet* u = (Unet*)handle;
-    MVE_CHECK(u->cfg.vae, MVE_ERR_ARG, "vae_plan: handle is not a VAE half");
+    MVE_CHECK(want_vae ? u->cfg.vae != 0 : u->cfg.sr != 0, MVE_ERR_ARG, "plan: handle is not %s", want_vae ? "a VAE half" : "an SRVGGNetCompact");
     int rc = ensure_plan(*u, B, H, W, 1, 0, io_dtype, 0, 0);
     if (rc) return rc;
     if (workspace_bytes) *workspace_bytes = u->cur->ws_bytes;
@@ -1518,21 +1609,21 @@ int mve_vae_plan(void* handle, int B, int H, int W, int io_dtype, size_t* worksp
     return MVE_OK;
 }
 
-int mve_vae_forward(void* handle, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
-                    size_t workspace_bytes, float* op_ms, void* stream) {
-    MVE_CHECK(handle, MVE_ERR_ARG, "vae_forward: null handle");
+static int imgnet_forward(void* handle, bool want_vae, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
+                          size_t workspace_bytes, float* op_ms, void* stream) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "forward: null handle");
     Unet* u = (Unet*)handle;
-    MVE_CHECK(u->cfg.vae, MVE_ERR_ARG, "vae_forward: handle is not a VAE half");
+    MVE_CHECK(want_vae ? u->cfg.vae != 0 : u->cfg.sr != 0, MVE_ERR_ARG, "forward: handle is not %s", want_vae ? "a VAE half" : "an SRVGGNetCompact");
     {
         char first[256];
         const int miss = mve_unet_missing_params(handle, first, sizeof(first));
-        MVE_CHECK(miss == 0, MVE_ERR_STATE, "vae_forward: %d parameters not loaded (first: %s)", miss, first);
+        MVE_CHECK(miss == 0, MVE_ERR_STATE, "forward: %d parameters not loaded (first: %s)", miss, first);
     }
-    MVE_CHECK(d_in && d_out, MVE_ERR_ARG, "vae_forward: null pointer");
+    MVE_CHECK(d_in && d_out, MVE_ERR_ARG, "forward: null pointer");
     int rc = ensure_plan(*u, B, H, W, 1, 0, io_dtype, 0, 0);
     if (rc) return rc;
     const Plan& pl = *u->cur;
-    MVE_CHECK(d_workspace && workspace_bytes >= pl.ws_bytes, MVE_ERR_NOMEM, "vae_forward: workspace %zu < required %zu", workspace_bytes,
+    MVE_CHECK(d_workspace && workspace_bytes >= pl.ws_bytes, MVE_ERR_NOMEM, "forward: workspace %zu < required %zu", workspace_bytes,
               pl.ws_bytes);
     Run r;
     r.ws = (unsigned char*)d_workspace; r.wt = u->slab;
@@ -1556,6 +1647,38 @@ int mve_vae_forward(void* handle, const void* d_in, int io_dtype, int B, int H, 
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return MVE_OK;
+}
+
+int mve_vae_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, double* flops) {
+    return imgnet_plan(handle, true, B, H, W, io_dtype, workspace_bytes, n_ops, flops);
+}
+int mve_vae_forward(void* handle, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
+                    size_t workspace_bytes, float* op_ms, void* stream) {
+    return imgnet_forward(handle, true, d_in, io_dtype, B, H, W, d_out, d_workspace, workspace_bytes, op_ms, stream);
+}
+
+int mve_srvgg_create(void** handle, int dtype, int num_in_ch, int num_out_ch, int num_feat, int num_conv, int upscale) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "srvgg_create: null handle");
+    MVE_CHECK(dtype == MVE_F16 || dtype == MVE_BF16, MVE_ERR_ARG, "srvgg_create: dtype must be f16 or bf16");
+    MVE_CHECK(num_in_ch >= 1 && num_in_ch <= 8 && num_out_ch == num_in_ch, MVE_ERR_ARG,
+              "srvgg_create: 1..8 channels, num_out_ch == num_in_ch (the input is added to the output, image_space_ss.py:68-69)");
+    MVE_CHECK(num_feat >= 8 && num_feat % 8 == 0 && num_conv >= 0 && upscale >= 1 && upscale <= 8, MVE_ERR_ARG, "srvgg_create: bad topology");
+    Unet* u = new Unet();
+    Config& c = u->cfg;
+    c.sr = 1; c.sr_scale = upscale;
+    c.dtype = dtype; c.in_ch = num_in_ch; c.out_ch = num_out_ch; c.n_levels = 1; c.layers_per_block = num_conv;
+    c.ctx_dim = 8; c.groups = 1; c.eps = 0.f; c.linear_proj = 0;
+    c.ch[0] = num_feat; c.attn[0] = 0; c.heads[0] = 1; c.tlayers[0] = 0;
+    layout_params(*u);
+    *handle = u;
+    return MVE_OK;
+}
+int mve_srvgg_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, double* flops) {
+    return imgnet_plan(handle, false, B, H, W, io_dtype, workspace_bytes, n_ops, flops);
+}
+int mve_srvgg_forward(void* handle, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
+                      size_t workspace_bytes, float* op_ms, void* stream) {
+    return imgnet_forward(handle, false, d_in, io_dtype, B, H, W, d_out, d_workspace, workspace_bytes, op_ms, stream);
 }
 
 int mve_unet_tune(int fuse_shortcut) {
@@ -1628,7 +1751,7 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
                      float* op_ms /* optional host array [n_ops]: per-op milliseconds (synchronises) */, void* stream) {
     MVE_CHECK(handle, MVE_ERR_ARG, "unet_forward: null handle");
     Unet* u = (Unet*)handle;
-    MVE_CHECK(!u->cfg.controlnet && !u->cfg.vae, MVE_ERR_ARG, "unet_forward: handle is a ControlNet / VAE (use mve_controlnet_forward / mve_vae_forward)");
+    MVE_CHECK(!u->cfg.controlnet && !u->cfg.vae && !u->cfg.sr, MVE_ERR_ARG, "unet_forward: handle is a ControlNet / VAE / SRVGG (use their own forward calls)");
     {
         char first[256];
         const int miss = mve_unet_missing_params(handle, first, sizeof(first));
