@@ -259,6 +259,21 @@ MVE_API int mve_cfg_combine(const float* d_uncond, const float* d_text, float gu
 MVE_API int mve_x0_prediction(const float* d_latents_scaled, const float* d_noise_pred, float sqrt_alpha_bar,
                               float sqrt_one_minus_alpha_bar, size_t n, float* d_x0, void* stream);
 
+/* Tone-mapping look-up table of the pipelines (lib/models/decoders/tonemapping.py:33-54): piecewise-linear interpolation between the
+ * `steps` knots (lut_x[k], lut_y[k]) with torch.bucketize(right=True) bucket selection.  inverse = 0: Tonemapping.lut (linear != 0:
+ * input_mode='linear', x -> log2(max(x, 1e-6)) first); inverse = 1: Tonemapping.inverse_lut (linear != 0: output_mode='linear',
+ * exp2 of the result).  fp32, any shape (n elements); tables are device pointers. */
+MVE_API int mve_tonemap_lut(const float* d_x, size_t n, const float* d_lut_x, const float* d_lut_y, int steps, int inverse, int linear,
+                            float* d_out, void* stream);
+/* Shading of a batch of rendered views in one pass (lib/pipelines/mvedit_3d_pipeline.py:1372-1384, same expression at :155-168):
+ *   n_cv = (2 n0 - 1, 1 - 2 n1, 1 - 2 n2) from normal_fg;  shading = max(light_v . n_cv, 0) * (1 - ambient) + ambient;
+ *   tables given : image = lut(inverse_lut(rgb / max(a, 1e-6)) + log2(max(shading, 1e-6))) * a + bg * (1 - a)
+ *   tables NULL  : image = rgb * shading + bg * (1 - a)                                   (`self.tonemapping is None`)
+ * rgba [n_views * pix][4], normal_fg [n_views * pix][3], cam_lights [n_views][3], image [n_views * pix][3], all f32. */
+MVE_API int mve_shade_views(const float* d_rgba, const float* d_normal_fg, const float* d_cam_lights, uint32_t n_views,
+                            uint32_t pix_per_view, float ambient_light, float bg_color, const float* d_lut_x, const float* d_lut_y,
+                            int steps, float* d_image, void* stream);
+
 /* =========================================================================
  * 3. UNet2DCondition executor (native runtime behind the reference's UNet seam).
  *    Replaces `self.unet(sample, t, encoder_hidden_states=..., cross_attention_kwargs=...,

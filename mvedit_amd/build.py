@@ -32,6 +32,7 @@ EXTRA_FLAGS = {
     'nerf.hip': ['-ffp-contract=off'],
     'raster.hip': ['-ffp-contract=off'],
     'dmtet.hip': ['-ffp-contract=off'],
+    'shading.hip': ['-ffp-contract=off'],
 }
 
 

@@ -1,0 +1,69 @@
+"""Host-side mirror of `lib/models/decoders/tonemapping.py` (class Tonemapping: `smooth_forward`, `lut`, `inverse_lut`, buffers
+`lut_x` / `lut_y`) and of the shading expression the pipelines wrap around it for every rendered batch
+(lib/pipelines/mvedit_3d_pipeline.py:1372-1384): native single-pass kernels (csrc/shading.hip), no PyTorch fallback for CUDA tensors."""
+import torch
+
+from . import _lib
+
+
+class Tonemapping:
+    def __init__(self, exposure=0.0, contrast=0.953, bias=0.088, sigmoid_gain=0.943, log_gain=0.011, lut_logx_min=-9, lut_logx_max=3,
+                 lut_steps=16, device='cuda'):
+        self.exposure, self.contrast, self.bias, self.sigmoid_gain, self.log_gain = exposure, contrast, bias, sigmoid_gain, log_gain
+        # 16 knots: host arithmetic, the same torch expressions as the reference's constructor (tonemapping.py:22-31)
+        self.lut_x = torch.linspace(lut_logx_min, lut_logx_max, lut_steps)
+        self.lut_y = self._smooth(self.lut_x)
+        self.to(device)
+
+    def to(self, device=None, **unused):
+        if device is not None:
+            self.lut_x, self.lut_y = self.lut_x.to(device).contiguous(), self.lut_y.to(device).contiguous()
+        return self
+
+    def _smooth(self, x):
+        x = (x + self.exposure) * self.contrast
+        return x.sigmoid() * self.sigmoid_gain + x * self.log_gain + self.bias
+
+    def smooth_forward(self, x, input_mode='log'):
+        """The analytic curve (only evaluated at the knots by the pipelines; kept for API parity, plain torch on 16 values)."""
+        assert input_mode in ['log', 'linear']
+        if input_mode == 'linear':
+            x = x.clamp(min=1e-6).log2()
+        return self._smooth(x)
+
+    def _run(self, v, inverse, linear):
+        assert v.is_cuda, 'native path: CUDA tensors only'
+        dtype = v.dtype
+        x = v.to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call('mve_tonemap_lut', _lib.ptr(x), x.numel(), _lib.ptr(self.lut_x), _lib.ptr(self.lut_y), self.lut_x.numel(), int(inverse),
+                      int(linear), _lib.ptr(out), _lib.stream_ptr(x.device))
+        return out.to(dtype)
+
+    def lut(self, x, input_mode='log'):
+        assert input_mode in ['log', 'linear']
+        return self._run(x, False, input_mode == 'linear')
+
+    def inverse_lut(self, y, output_mode='log'):
+        assert output_mode in ['log', 'linear']
+        return self._run(y, True, output_mode == 'linear')
+
+
+def shade_views(rgba, normal_fg, cam_lights, ambient_light, bg_color, tonemapping=None):
+    """rgba [..., b, S, S, 4], normal_fg [..., b, S, S, 3] (as `BaseNeRF.render` returns them), cam_lights [b, 3] ->
+    image [..., b, S, S, 3]: the reference's `image_batch` (mvedit_3d_pipeline.py:1372-1384) in one launch."""
+    assert rgba.is_cuda and rgba.shape[-1] == 4 and normal_fg.shape[-1] == 3 and rgba.shape[:-1] == normal_fg.shape[:-1]
+    b = cam_lights.shape[0]
+    lead = rgba.shape[:-1]
+    n = rgba.numel() // 4
+    assert n % b == 0 and cam_lights.shape == (b, 3)
+    c = rgba.float().contiguous()
+    nf = normal_fg.float().contiguous()
+    lights = cam_lights.to(device=c.device, dtype=torch.float32).contiguous()
+    out = torch.empty(*lead, 3, dtype=torch.float32, device=c.device)
+    lx, ly, steps = (tonemapping.lut_x, tonemapping.lut_y, tonemapping.lut_x.numel()) if tonemapping is not None else (None, None, 0)
+    with torch.cuda.device(c.device):
+        _lib.call('mve_shade_views', _lib.ptr(c), _lib.ptr(nf), _lib.ptr(lights), b, n // b, float(ambient_light), float(bg_color),
+                  _lib.ptr(lx), _lib.ptr(ly), steps, _lib.ptr(out), _lib.stream_ptr(c.device))
+    return out

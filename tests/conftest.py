@@ -22,6 +22,11 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# GPU tests written after the round's GPU budget was spent: they have never run on hardware.  Non-strict xfail keeps an unexpected
+# failure from hiding the verified tests behind `-x`; a pass is reported as XPASS.  Remove the mark once a GPU run has confirmed them.
+pending_first_gpu_run = pytest.mark.xfail(strict=False, reason='written after the round-1 GPU budget was exhausted: not yet run on an MI355X')
+
+
 @pytest.fixture(scope='session')
 def lib():
     """The C-ABI library, built in-tree if needed (hipcc cross-compiles without a GPU)."""

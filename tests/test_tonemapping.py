@@ -1,0 +1,71 @@
+"""Tone-mapping table and render-step shading (csrc/shading.hip behind mvedit_amd.tonemapping) vs outputs of the reference's own
+Tonemapping class (tests/golden/tonemap_ref.npz, written by tests/golden/make_tonemap_golden.py).
+Bars: table interpolation in 'log' mode is the reference's expression op by op (no fma): bit-exact; 'linear' modes pass through
+log2 / exp2 whose device implementations differ from the host's in the last place: 2e-6 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pending_first_gpu_run
+from oracle import tonemap_oracle as T
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tonemap_ref.npz'))
+t = lambda k: torch.from_numpy(G[k])
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_oracle_and_host_tables_match_reference_output():
+    from mvedit_amd.tonemapping import Tonemapping
+    lx, ly = T.tables()
+    assert np.array_equal(lx.numpy(), G['lut_x']) and np.array_equal(ly.numpy(), G['lut_y'])
+    tm = Tonemapping(device='cpu')
+    assert np.array_equal(tm.lut_x.numpy(), G['lut_x']) and np.array_equal(tm.lut_y.numpy(), G['lut_y'])
+    assert np.array_equal(T.lut(lx, ly, t('x_log')).numpy(), G['lut_log'])
+    assert np.array_equal(T.inverse_lut(lx, ly, t('y')).numpy(), G['inv_log'])
+    np.testing.assert_allclose(T.lut(lx, ly, t('x_lin'), 'linear').numpy(), G['lut_lin'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(T.inverse_lut(lx, ly, t('y'), 'linear').numpy(), G['inv_lin'], rtol=1e-6)
+    np.testing.assert_allclose(T.shade_views(t('rgba'), t('normal_fg'), t('cam_lights'), 0.1, 1.0, lx, ly).numpy(), G['shaded_tm'], rtol=1e-6, atol=1e-7)
+    # smooth_forward of the mirror is the curve the knots sit on
+    assert torch.equal(tm.smooth_forward(tm.lut_x), tm.lut_y)
+
+
+def test_lut_round_trip_property():
+    """inverse_lut(lut(x)) == x inside the table's range (both maps are piecewise linear over the same knots)."""
+    lx, ly = T.tables()
+    x = torch.linspace(-8.9, 2.9, 1001)
+    assert (T.inverse_lut(lx, ly, T.lut(lx, ly, x)) - x).abs().max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_lut_and_inverse_vs_reference_output(lib):
+    from mvedit_amd.tonemapping import Tonemapping
+    tm = Tonemapping()
+    assert torch.equal(tm.lut(t('x_log').cuda()).cpu(), t('lut_log'))
+    assert torch.equal(tm.inverse_lut(t('y').cuda()).cpu(), t('inv_log'))
+    np.testing.assert_allclose(tm.lut(t('x_lin').cuda(), 'linear').cpu().numpy(), G['lut_lin'], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(tm.inverse_lut(t('y').cuda(), 'linear').cpu().numpy(), G['inv_lin'], rtol=2e-6)
+    h = tm.lut(t('x_log').half().cuda())
+    assert h.dtype == torch.float16 and h.shape == t('x_log').shape                 # dtype round trip as the reference's `.to(dtype)`
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_shade_views_vs_reference_output(lib):
+    from mvedit_amd.tonemapping import Tonemapping, shade_views
+    rgba, nf, lights = t('rgba').cuda(), t('normal_fg').cuda(), t('cam_lights').cuda()
+    out = shade_views(rgba, nf, lights, 0.1, 1.0, Tonemapping())
+    assert out.shape == (1, 3, 20, 24, 3)
+    # log2 of the shading term and the dot product's summation order are the only non-identical steps
+    np.testing.assert_allclose(out.cpu().numpy(), G['shaded_tm'], rtol=1e-5, atol=2e-6)
+    plain = shade_views(rgba, nf, lights, 0.1, 1.0, None)
+    np.testing.assert_allclose(plain.cpu().numpy(), G['shaded_plain'], rtol=1e-6, atol=1e-6)
+    # 6 x 512^2 pixels, the production batch: finite, and equal to the small-batch result on the overlapping view
+    big = torch.rand(1, 6, 512, 512, 4, device='cuda')
+    nfb = torch.rand(1, 6, 512, 512, 3, device='cuda')
+    lb = torch.nn.functional.normalize(torch.randn(6, 3, device='cuda'), dim=-1)
+    full = shade_views(big, nfb, lb, 0.1, 1.0, Tonemapping())
+    assert torch.isfinite(full).all() and torch.equal(full[:, 2:3], shade_views(big[:, 2:3], nfb[:, 2:3], lb[2:3], 0.1, 1.0, Tonemapping()))
