@@ -205,6 +205,14 @@ def secondary(dev):
         t = timed(lambda: half.run(inp, 8), it=2)
         fl = sum(half.plan(8, inp.shape[2], inp.shape[3], torch.float16)['flops'].values()) / 8 * VIEWS
         out[name] = dict(ms=round(t * 1e3, 2), views=VIEWS, ms_per_view=round(t * 1e3 / VIEWS, 3), tflops_per_s=round(fl / t / 1e12, 1))
+    # ---- SRVGGNetCompact x4 image enhancer on the views rendered at 128^2 / 256^2 (mvedit_3d_pipeline.py:1399-1400; 64 features, 32 convs) ----
+    from mvedit_amd.image_enhancer import SRVGGNetCompactEngine
+    enh = SRVGGNetCompactEngine(3, 3, 64, 32, 4, dtype=torch.float16, device=dev).load_state_dict(SY.make_srvgg_state_dict(dtype=torch.float16))
+    for side in (128, 256):
+        lo_res = torch.rand(VIEWS, 3, side, side, device=dev, dtype=torch.float16)
+        t = timed(lambda: enh(lo_res), it=2)
+        fl = enh.plan(VIEWS, side, side, torch.float16)['flops']['conv']
+        out[f'image_enhancer_{side}'] = dict(ms=round(t * 1e3, 2), views=VIEWS, ms_per_view=round(t * 1e3 / VIEWS, 3), tflops_per_s=round(fl / t / 1e12, 1))
     return out
 
 

@@ -212,3 +212,32 @@ def make_vae_state_dict(cfg, seed=4321, dtype=torch.float32):
             t = torch.randn(shape, generator=g) / math.sqrt(math.prod(shape[1:]))
         sd[name] = t.to(dtype)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# SRVGGNetCompact (lib/models/decoders/image_space_ss.py state-dict names); tests/test_image_enhancer.py checks the inventory
+# ---------------------------------------------------------------------------------------------------------------------------
+def srvgg_param_shapes(num_in_ch=3, num_out_ch=3, num_feat=64, num_conv=32, upscale=4):
+    s = {'body.0.weight': (num_feat, num_in_ch, 3, 3), 'body.0.bias': (num_feat,), 'body.1.weight': (num_feat,)}
+    for k in range(1, num_conv + 1):
+        s[f'body.{2 * k}.weight'] = (num_feat, num_feat, 3, 3)
+        s[f'body.{2 * k}.bias'] = (num_feat,)
+        s[f'body.{2 * k + 1}.weight'] = (num_feat,)
+    last = 2 * (num_conv + 1)
+    s[f'body.{last}.weight'] = (num_out_ch * upscale ** 2, num_feat, 3, 3)
+    s[f'body.{last}.bias'] = (num_out_ch * upscale ** 2,)
+    return s
+
+
+def make_srvgg_state_dict(seed=99, dtype=torch.float32, **kw):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in srvgg_param_shapes(**kw).items():
+        if name.endswith('.bias'):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            t = 0.25 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = torch.randn(shape, generator=g) * math.sqrt(1.6 / (shape[1] * 9))
+        sd[name] = t.to(dtype)
+    return sd

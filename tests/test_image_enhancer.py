@@ -41,6 +41,8 @@ def test_plan_flops_and_inventory(lib):
     assert abs(info['flops']['conv'] - want) < 1e-6 * want and info['n_ops'] == 1 + 33 * 2 + 1 + 1
     buf = ctypes.create_string_buffer(256)
     assert _lib.raw('mve_unet_missing_params')(eng._h, buf, 256) == len(S.param_shapes(3, 3, 64, 32, 4))
+    from mvedit_amd import synthetic as SY
+    assert SY.srvgg_param_shapes(3, 3, 64, 32, 4) == S.param_shapes(3, 3, 64, 32, 4)
     with pytest.raises(_lib.MveError):
         SRVGGNetCompactEngine(3, 1, 64, 2, 4, dtype=torch.float16, device='cpu')          # the residual needs out == in channels
 
