@@ -360,6 +360,42 @@ MVE_API int mve_srvgg_create(void** handle, int dtype, int num_in_ch, int num_ou
 MVE_API int mve_srvgg_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, double* flops);
 MVE_API int mve_srvgg_forward(void* handle, const void* d_in, int io_dtype, int B, int H, int W, void* d_out, void* d_workspace,
                               size_t workspace_bytes, float* op_ms, void* stream);
+/* LPIPS(net='vgg') perceptual loss, forward and backward w.r.t. the prediction: the `patch_loss` of the reference's reconstruct step
+ * (lib/models/losses/lpips_loss.py:8-42 -> lpips==0.1.4 `LPIPS.forward`; lib/models/autoencoders/base_nerf.py:337-344, 8 patches of
+ * 128 x 128 per optimisation iteration).  An executor handle: parameters through mve_unet_load_param under lpips' own state-dict
+ * names (`net.slice<k>.<idx>.weight|bias` = torchvision VGG16 features, `lin<k>.model.1.weight` (or `lins.<k>...`),
+ * `scaling_layer.shift|scale`).  normalize_inputs: pred / target arrive in [0, 1] and are mapped to [-1, 1] first (LPIPSLoss default).
+ *   forward : loss[n] = sum_l mean_hw sum_c w_lc (u_pred - u_target)^2, u = f / (|f|_c + 1e-10), f = relu{1_2,2_2,3_3,4_3,5_3};
+ *             pred, target NCHW [B,3,H,W] in io_dtype, H and W multiples of 16; d_loss f32 [B].
+ *   backward: d_grad_pred = d(sum_n grad_loss[n] loss[n]) / d pred, NCHW io_dtype; reads the activations the forward call left in
+ *             d_workspace (same workspace, same B/H/W, nothing else run on it in between).  Every VGG conv's data gradient is the
+ *             forward implicit-GEMM kernel on a transposed + flipped packing of the same weight. */
+MVE_API int mve_lpips_create(void** handle, int dtype, int normalize_inputs);
+MVE_API int mve_lpips_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, int* n_forward_ops,
+                           double* flops);
+MVE_API int mve_lpips_forward(void* handle, const void* d_pred, const void* d_target, int io_dtype, int B, int H, int W, float* d_loss,
+                              void* d_workspace, size_t workspace_bytes, void* stream);
+MVE_API int mve_lpips_backward(void* handle, const float* d_grad_loss, int io_dtype, int B, int H, int W, void* d_grad_pred,
+                               void* d_workspace, size_t workspace_bytes, void* stream);
+/* LPIPS building blocks (csrc/lpips.hip), NHWC `dtype` activations:
+ *   scale        : out[2B*H*W][8] = ((normalize ? 2x-1 : x) - shift_c) / scale_c of pred (first B images) and target, channels 3..7 zero
+ *   input_grad   : d x[b][c][y][x] = g[(b,y,x)][c] / scale_c * (normalize ? 2 : 1), NCHW io_dtype
+ *   maxpool2x2   : nn.MaxPool2d(2, 2) and its backward (gradient to the first arg-max of the window, as torch)
+ *   relu_backward: grad = out > 0 ? grad : 0, in place
+ *   lpips_layer  : loss[n] (+)= mean_hw sum_c w_c (u0 - u1)^2 over feat = [pred half | target half]; _backward: d / d feat(pred half) */
+MVE_API int mve_lpips_scale(int dtype, int io_dtype, const void* d_pred, const void* d_target, int B, int H, int W, const float* d_shift3,
+                            const float* d_scale3, int normalize, void* d_out, void* stream);
+MVE_API int mve_lpips_input_grad(int dtype, int io_dtype, const void* d_g8, int B, int H, int W, const float* d_scale3, int normalize,
+                                 void* d_out, void* stream);
+MVE_API int mve_maxpool2x2(int dtype, const void* d_x, int B, int H, int W, int C, void* d_y, void* stream);
+MVE_API int mve_maxpool2x2_backward(int dtype, const void* d_x, const void* d_grad_y, int B, int H, int W, int C, void* d_grad_x,
+                                    void* stream);
+MVE_API int mve_relu_backward(int dtype, void* d_grad, const void* d_out, size_t n, void* stream);
+MVE_API size_t mve_lpips_layer_scratch_bytes(int B, int HW);
+MVE_API int mve_lpips_layer(int dtype, const void* d_feat, const float* d_lin_w, int B, int HW, int C, int accumulate, float* d_loss,
+                            void* d_scratch, void* stream);
+MVE_API int mve_lpips_layer_backward(int dtype, const void* d_feat, const float* d_lin_w, const float* d_grad_loss, int B, int HW, int C,
+                                     void* d_grad_feat, void* stream);
 /* y = x >= 0 ? x : slope[c] * x over NHWC rows (nn.PReLU(num_parameters=C), image_space_ss.py:41-56); n = rows * C elements */
 MVE_API int mve_prelu(int dtype, const void* d_x, const float* d_slope, int C, void* d_y, size_t n, void* stream);
 /* out[b][c][y*r+i][x*r+j] = src[(b,y,x)][c*r*r + i*r + j] + base[b][c][y][x]: nn.PixelShuffle(r) of an NHWC fp32 tensor (row stride ld)

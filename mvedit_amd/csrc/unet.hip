@@ -43,6 +43,14 @@ int mve_axpy(int, const void*, const void*, float, void*, size_t, void*);
 int mve_softmax_rows(int, const float*, size_t, int, int, void*, size_t, void*);
 int mve_prelu(int, const void*, const float*, int, void*, size_t, void*);
 int mve_pixel_shuffle_add(int, const float*, int, const void*, int, int, int, int, int, void*, void*);
+int mve_lpips_scale(int, int, const void*, const void*, int, int, int, const float*, const float*, int, void*, void*);
+int mve_lpips_input_grad(int, int, const void*, int, int, int, const float*, int, void*, void*);
+int mve_maxpool2x2(int, const void*, int, int, int, int, void*, void*);
+int mve_maxpool2x2_backward(int, const void*, const void*, int, int, int, int, void*, void*);
+int mve_relu_backward(int, void*, const void*, size_t, void*);
+size_t mve_lpips_layer_scratch_bytes(int, int);
+int mve_lpips_layer(int, const void*, const float*, int, int, int, int, float*, void*, void*);
+int mve_lpips_layer_backward(int, const void*, const float*, const float*, int, int, int, void*, void*);
 }
 
 namespace {
@@ -109,6 +117,7 @@ constexpr int CN_EMB[4] = {16, 32, 96, 256};      // diffusers ControlNetModel c
 
 struct Config {
     int controlnet = 0, cond_ch = 3;   // ControlNetModel: encoder + mid of the UNet, conditioning embedding, zero convolutions
+    int lpips = 0, lpips_normalize = 1; // LPIPS(net='vgg') forward + backward w.r.t. the prediction (lib/models/losses/lpips_loss.py)
     int sr = 0, sr_scale = 4;          // SRVGGNetCompact (lib/models/decoders/image_space_ss.py): ch[0] = num_feat, layers_per_block = num_conv
     int vae = 0;                       // AutoencoderKL half: 1 = post_quant_conv + Decoder, 2 = Encoder + quant_conv (no time embedding,
                                        // no transformers; in_ch / out_ch are the half's own input / output channels, both <= 8)
@@ -257,13 +266,21 @@ struct Unet {
 
 int esz(int dtype) { return dtype == MVE_F32 ? 4 : 2; }
 
+// torchvision VGG16 `features` indices of the 13 convolutions, their widths, and lpips' five slices (relu1_2 ... relu5_3)
+constexpr int VGG_IDX[13] = {0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28};
+constexpr int VGG_CIN[13] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512};
+constexpr int VGG_COUT[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+constexpr int VGG_SLICE[13] = {1, 1, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5};
+constexpr int VGG_BLK_FIRST[6] = {0, 2, 4, 7, 10, 13};
+std::string vgg_name(int i) { return "net.slice" + std::to_string(VGG_SLICE[i]) + "." + std::to_string(VGG_IDX[i]); }
+
 // enumerate blocks in execution order ------------------------------------------------------------------
 struct ResnetDesc { std::string name; int cin, cout; };
 struct XfDesc { std::string name; int c, heads, layers; };
 
 void enumerate(const Config& c, std::vector<ResnetDesc>& rs, std::vector<XfDesc>& xs) {
     const int n = c.n_levels, L = c.layers_per_block;
-    if (c.sr) return;     // a plain conv stack
+    if (c.sr || c.lpips) return;     // plain conv stacks
     if (c.vae) {      // diffusers Encoder / Decoder (autoencoders/vae.py): resnets only, one attention in the mid block
         const int Cm = c.ch[n - 1];
         if (c.vae == 2) {
@@ -339,6 +356,22 @@ void layout_params(Unet& u) {
     u.fuse_sc = g_fuse_shortcut != 0;
     for (int i = 0; i < c.n_levels; ++i) u.fuse_sc = u.fuse_sc && (c.ch[i] % 64 == 0);
     auto need = [&](const std::string& n) { u.expected.push_back(n); };
+    if (c.lpips) {
+        // every VGG conv twice: forward packing and the transposed / flipped packing that turns the same kernel into its dgrad
+        for (int i = 0; i < 13; ++i) {
+            const std::string n = vgg_name(i), e = "vgg." + std::to_string(i);
+            const size_t ci = i == 0 ? 8 : VGG_CIN[i], co = VGG_COUT[i];
+            sb.add(e + ".w", co * 9 * ci, false); need(n + ".weight");
+            sb.add(e + ".wt", ci * 9 * co, false);
+            sb.add(e + ".b", co, true); need(n + ".bias");
+        }
+        for (int k = 0; k < 5; ++k) { sb.add("lin." + std::to_string(k), VGG_COUT[VGG_BLK_FIRST[k + 1] - 1], true); need("lin" + std::to_string(k) + ".model.1.weight"); }
+        sb.add("shift", 8, true); need("scaling_layer.shift");
+        sb.add("scale", 8, true); need("scaling_layer.scale");
+        sb.add("zeros", 512, true);          // ReLU = PReLU with zero slopes (the slab is zero-filled when it is allocated)
+        u.slab_bytes = sb.top;
+        return;
+    }
     if (c.sr) {
         // body.0: conv in_ch -> F; body.(2k), k = 1..num_conv: conv F -> F; body.(2k+1): PReLU slopes; last: conv F -> out_ch * r * r
         const size_t F = c.ch[0];
@@ -560,7 +593,38 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
     const int Cm_ = c.ch[c.n_levels - 1];
     const int vin = c.vae == 1 ? Cm_ : c.ch[0], vout = c.vae == 1 ? c.ch[0] : Cm_;     // widths after conv_in / before conv_out
     const std::string va = "mid_block.attentions.0";
-    if (c.sr) {
+    if (c.lpips) {
+        int li = -1;
+        for (int i = 0; i < 13; ++i) if (name.compare(0, vgg_name(i).size() + 1, vgg_name(i) + ".") == 0) li = i;
+        if (li >= 0 && ends_with(name, ".weight")) {
+            const long long co = VGG_COUT[li], ci = VGG_CIN[li];
+            const std::string e = "vgg." + std::to_string(li);
+            MVE_CHECK(ndim == 4 && shape[0] == co && shape[1] == ci && shape[2] == 3 && shape[3] == 3, MVE_ERR_ARG, "load_param(%s): expected [%lld,%lld,3,3]", name.c_str(), co, ci);
+            if (li == 0) {
+                MVE_HIP(hipMemsetAsync(dstp(P(e + ".w"), 0), 0, P(e + ".w")->bytes, s));
+                rc = conv(P(e + ".w"), co, ci, co, 8);
+                MVE_HIP(hipMemsetAsync(dstp(P(e + ".wt"), 0), 0, P(e + ".wt")->bytes, s));
+            } else rc = conv(P(e + ".w"), co, ci, co, ci);
+            if (rc == MVE_OK) {
+                // dgrad weight as a conv weight: W'[o' = ci][i' = co][ky][kx] = W[co][ci][2-ky][2-kx]; co is always a multiple of 64, so
+                // the slab-major layout [O'][I'/64][9][64]; source offset of (o', slab, tap, c) = (slab*64 + c)*ci*9 + o'*9 + (8 - tap)
+                const long long rows = li == 0 ? 8 : ci;         // conv1_1: 3 real rows, padded to 8 (the rest stay zero)
+                (void)rows;
+                PackDims dd{{ci, co / 64, 9, 64}, {9, 64 * ci * 9, -1, ci * 9}, {9 * co, 9 * 64, 64, 1}, 64};
+                const size_t esz_src = src_dtype == MVE_F32 ? 4 : 2;
+                rc = pack(src_dtype, c.dtype, (const unsigned char*)src + 8 * esz_src, dstp(P(e + ".wt"), 0), dd, s);
+            }
+        } else if (li >= 0 && ends_with(name, ".bias")) rc = vec(P("vgg." + std::to_string(li) + ".b"), 0, VGG_COUT[li], 1);
+        else if (name == "scaling_layer.shift" || name == "scaling_layer.scale") rc = vec(P(name.substr(14)), 0, 3, 1);
+        else if (name.compare(0, 3, "lin") == 0 && ends_with(name, ".model.1.weight")) {
+            const int k = name[3] - '0';
+            MVE_CHECK(k >= 0 && k < 5, MVE_ERR_ARG, "load_param: no layer %s", name.c_str());
+            rc = vec(P("lin." + std::to_string(k)), 0, VGG_COUT[VGG_BLK_FIRST[k + 1] - 1], 1);
+        } else {
+            mve_set_error("load_param: %s is not a parameter of LPIPS(net='vgg')", name.c_str());
+            return MVE_ERR_ARG;
+        }
+    } else if (c.sr) {
         MVE_CHECK(name.compare(0, 5, "body.") == 0, MVE_ERR_ARG, "load_param: %s is not a parameter of SRVGGNetCompact", name.c_str());
         const int idx = atoi(name.c_str() + 5), last = 2 * (c.layers_per_block + 1);
         const long long F = c.ch[0], nout = (long long)c.out_ch * c.sr_scale * c.sr_scale;
@@ -1009,6 +1073,108 @@ struct Builder {
         return out;
     }
 
+    // LPIPS(net='vgg')(pred, target) and its gradient w.r.t. pred (lpips==0.1.4 as called from lib/models/losses/lpips_loss.py:8-42).
+    // Forward ops = [0, enc_end): both images of every pair go through VGG16 as one batch of 2B; nothing is released, the
+    // activations are the backward's inputs.  Backward ops = [enc_end, end): pred half only; every conv's dgrad is the forward conv
+    // kernel on the transposed / flipped weight packing.
+    int build_lpips(int B_, int H, int W, int io_dtype) {
+        B = B_; dt = c.dtype;
+        const int Bb = B_;
+        pl = Plan();
+        pl.B = Bb; pl.H = H; pl.W = W; pl.n_img = 1; pl.io_dtype = io_dtype;
+        const int e = 2, d = dt, norm = c.lpips_normalize;
+        ld_temb = 0; ld_kv = 0;
+        MVE_CHECK(H % 16 == 0 && W % 16 == 0, MVE_ERR_ARG, "lpips: image size %dx%d must be divisible by 16 (four 2x2 poolings)", H, W);
+        MVE_CHECK((size_t)2 * Bb * H * W * 64 < ((size_t)1 << 31), MVE_ERR_ARG, "lpips: batch %d at %dx%d overflows 32-bit activation indexing", Bb, H, W);
+        Ref pred; pred.kind = Ref::SAMPLE;
+        Ref targ; targ.kind = Ref::CTX;
+        Ref loss; loss.kind = Ref::OUT;
+        Ref shift = wt("shift"), scale = wt("scale"), zeros = wt("zeros");
+        Ref x0 = ws((size_t)2 * Bb * H * W * 8 * e);
+        op(OC_OTHER, 0, "scaling layer (nchw->nhwc)", [=](const Run& r) {
+            return mve_lpips_scale(d, io_dtype, r.p(pred), r.p(targ), Bb, H, W, (const float*)r.p(shift), (const float*)r.p(scale), norm, r.p(x0), r.stream);
+        });
+        struct Act { Ref r; int C, h, w; };
+        std::vector<Act> acts(13);          // post-ReLU output of every conv
+        Ref cur = x0;
+        int cin = 8, h = H, w = W;
+        for (int k = 0; k < 5; ++k) {
+            if (k > 0) {
+                const int C = cin, hh = h, ww = w;
+                Ref pooled = ws((size_t)2 * Bb * (h / 2) * (w / 2) * C * e);
+                Ref in = cur;
+                op(OC_OTHER, 0, "maxpool 2x2", [=](const Run& r) { return mve_maxpool2x2(d, r.p(in), 2 * Bb, hh, ww, C, r.p(pooled), r.stream); });
+                cur = pooled; h /= 2; w /= 2;
+            }
+            rows_img = h * w;
+            for (int i = VGG_BLK_FIRST[k]; i < VGG_BLK_FIRST[k + 1]; ++i) {
+                const int C = VGG_COUT[i];
+                const std::string en = "vgg." + std::to_string(i);
+                Ref y = ws((size_t)2 * Bb * h * w * C * e);
+                conv(cur, cin, 2 * Bb, h, w, 1, 0, wt(en + ".w"), C, y, wt(en + ".b"), Ref(), 0, Ref(), 0, "vgg conv");
+                const size_t nel = (size_t)2 * Bb * h * w * C;
+                op(OC_OTHER, 0, "relu", [=](const Run& r) { return mve_prelu(d, r.p(y), (const float*)r.p(zeros), C, r.p(y), nel, r.stream); });
+                acts[i] = {y, C, h, w};
+                cur = y; cin = C;
+            }
+            const int C = cin, hw = h * w;
+            Ref lin = wt("lin." + std::to_string(k)), tap = cur;
+            Ref scratch = ws(mve_lpips_layer_scratch_bytes(Bb, hw));
+            const int acc = k > 0 ? 1 : 0;
+            op(OC_OTHER, 0, "lpips layer distance", [=](const Run& r) {
+                return mve_lpips_layer(d, r.p(tap), (const float*)r.p(lin), Bb, hw, C, acc, (float*)r.p(loss), r.p(scratch), r.stream);
+            });
+        }
+        pl.enc_end = pl.ops.size();
+        // ---- backward -----------------------------------------------------------------------------------------------------
+        Ref gout; gout.kind = Ref::TIMESTEPS;          // d L / d loss[n], fp32 [B]
+        Ref g;
+        for (int k = 4; k >= 0; --k) {
+            const int last = VGG_BLK_FIRST[k + 1] - 1, C = VGG_COUT[last], hw = h * w;
+            Ref gf = ws((size_t)Bb * hw * C * e);
+            Ref lin = wt("lin." + std::to_string(k)), tap = acts[last].r;
+            op(OC_OTHER, 0, "lpips layer backward", [=](const Run& r) {
+                return mve_lpips_layer_backward(d, r.p(tap), (const float*)r.p(lin), (const float*)r.p(gout), Bb, hw, C, r.p(gf), r.stream);
+            });
+            if (g.kind == Ref::NUL) g = gf;
+            else {
+                const size_t nel = (size_t)Bb * hw * C;
+                Ref gg = g;
+                op(OC_OTHER, 0, "grad += layer grad", [=](const Run& r) { return mve_axpy(d, r.p(gg), r.p(gf), 1.0f, r.p(gg), nel, r.stream); });
+                rel(gf);
+            }
+            rows_img = hw;
+            for (int i = last; i >= VGG_BLK_FIRST[k]; --i) {
+                const int Co = VGG_COUT[i], Ci = i == 0 ? 8 : VGG_CIN[i];
+                const size_t nel = (size_t)Bb * hw * Co;
+                Ref gg = g, a = acts[i].r;
+                op(OC_OTHER, 0, "relu backward", [=](const Run& r) { return mve_relu_backward(d, r.p(gg), r.p(a), nel, r.stream); });
+                Ref gi = ws((size_t)Bb * hw * Ci * e);
+                conv(g, Co, Bb, h, w, 1, 0, wt("vgg." + std::to_string(i) + ".wt"), Ci, gi, Ref(), Ref(), 0, Ref(), 0, "vgg conv dgrad");
+                rel(g);
+                g = gi;
+            }
+            if (k > 0) {
+                const int Cp = VGG_COUT[VGG_BLK_FIRST[k] - 1], hh = 2 * h, ww = 2 * w;
+                Ref gp = ws((size_t)Bb * hh * ww * Cp * e);
+                Ref xin = acts[VGG_BLK_FIRST[k] - 1].r, gg = g;
+                op(OC_OTHER, 0, "maxpool backward", [=](const Run& r) { return mve_maxpool2x2_backward(d, r.p(xin), r.p(gg), Bb, hh, ww, Cp, r.p(gp), r.stream); });
+                rel(g);
+                g = gp; h = hh; w = ww;
+            }
+        }
+        {
+            Ref gg = g;
+            const int HH = H, WW = W;
+            op(OC_OTHER, 0, "input gradient (nhwc->nchw)", [=](const Run& r) {
+                return mve_lpips_input_grad(d, io_dtype, r.p(gg), Bb, HH, WW, (const float*)r.p(scale), norm, r.p(loss), r.stream);
+            });
+        }
+        pl.ws_bytes = ar.peak + 256;
+        if (!u.err.empty()) { mve_set_error("lpips plan: %s", u.err.c_str()); u.err.clear(); return MVE_ERR_STATE; }
+        return MVE_OK;
+    }
+
     // SRVGGNetCompact.forward (lib/models/decoders/image_space_ss.py:63-70): conv + PReLU stack at the input resolution, last conv to
     // out_ch * r * r channels, PixelShuffle(r), plus the nearest-upsampled input.  H x W is the input size.
     int build_sr(int B_, int H, int W, int io_dtype) {
@@ -1450,7 +1616,7 @@ int ensure_plan(Unet& u, int B, int H, int W, int n_img, int has_res, int io_dty
     Builder b(u, *np);
     b.ctx_rows_per_img = ctx_len;
     u.cur = nullptr;
-    const int rc = u.cfg.sr ? b.build_sr(B, H, W, io_dtype) : u.cfg.vae ? b.build_vae(B, H, W, io_dtype) : b.build(B, H, W, n_img, has_res, io_dtype, res_nhwc);
+    const int rc = u.cfg.lpips ? b.build_lpips(B, H, W, io_dtype) : u.cfg.sr ? b.build_sr(B, H, W, io_dtype) : u.cfg.vae ? b.build_vae(B, H, W, io_dtype) : b.build(B, H, W, n_img, has_res, io_dtype, res_nhwc);
     if (rc != MVE_OK) return rc;
     np->ctx_len = ctx_len;
     np->last_use = u.tick;
@@ -1681,6 +1847,73 @@ int mve_srvgg_forward(void* handle, const void* d_in, int io_dtype, int B, int H
     return imgnet_forward(handle, false, d_in, io_dtype, B, H, W, d_out, d_workspace, workspace_bytes, op_ms, stream);
 }
 
+int mve_lpips_create(void** handle, int dtype, int normalize_inputs) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "lpips_create: null handle");
+    MVE_CHECK(dtype == MVE_F16 || dtype == MVE_BF16, MVE_ERR_ARG, "lpips_create: dtype must be f16 or bf16");
+    Unet* u = new Unet();
+    Config& c = u->cfg;
+    c.lpips = 1; c.lpips_normalize = normalize_inputs ? 1 : 0;
+    c.dtype = dtype; c.in_ch = 3; c.out_ch = 3; c.n_levels = 1; c.layers_per_block = 1;
+    c.ctx_dim = 8; c.groups = 1; c.eps = 0.f; c.linear_proj = 0;
+    c.ch[0] = 64; c.attn[0] = 0; c.heads[0] = 1; c.tlayers[0] = 0;
+    layout_params(*u);
+    *handle = u;
+    return MVE_OK;
+}
+
+int mve_lpips_plan(void* handle, int B, int H, int W, int io_dtype, size_t* workspace_bytes, int* n_ops, int* n_forward_ops, double* flops) {
+    MVE_CHECK(handle && B > 0 && H > 0 && W > 0, MVE_ERR_ARG, "lpips_plan: bad arguments");
+    Unet* u = (Unet*)handle;
+    MVE_CHECK(u->cfg.lpips, MVE_ERR_ARG, "lpips_plan: handle is not an LPIPS engine");
+    int rc = ensure_plan(*u, B, H, W, 1, 0, io_dtype, 0, 0);
+    if (rc) return rc;
+    if (workspace_bytes) *workspace_bytes = u->cur->ws_bytes;
+    if (n_ops) *n_ops = (int)u->cur->ops.size();
+    if (n_forward_ops) *n_forward_ops = (int)u->cur->enc_end;
+    if (flops) for (int i = 0; i < OC_COUNT; ++i) flops[i] = u->cur->flops[i];
+    return MVE_OK;
+}
+
+// phase 1: loss[n] = LPIPS(pred[n], target[n]);  phase 2: grad_pred = d (sum_n grad_loss[n] * loss[n]) / d pred.  Phase 2 reads the
+// activations phase 1 left in d_workspace: same workspace, same (B, H, W), no other call on it in between.
+static int lpips_run(void* handle, int phase, const void* d_pred, const void* d_target, const float* d_grad_loss, int io_dtype, int B, int H,
+                     int W, void* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "lpips: null handle");
+    Unet* u = (Unet*)handle;
+    MVE_CHECK(u->cfg.lpips, MVE_ERR_ARG, "lpips: handle is not an LPIPS engine");
+    {
+        char first[256];
+        const int miss = mve_unet_missing_params(handle, first, sizeof(first));
+        MVE_CHECK(miss == 0, MVE_ERR_STATE, "lpips: %d parameters not loaded (first: %s)", miss, first);
+    }
+    MVE_CHECK(d_out && (phase == 2 ? d_grad_loss != nullptr : (d_pred && d_target)), MVE_ERR_ARG, "lpips: null pointer");
+    int rc = ensure_plan(*u, B, H, W, 1, 0, io_dtype, 0, 0);
+    if (rc) return rc;
+    const Plan& pl = *u->cur;
+    MVE_CHECK(d_workspace && workspace_bytes >= pl.ws_bytes, MVE_ERR_NOMEM, "lpips: workspace %zu < required %zu", workspace_bytes, pl.ws_bytes);
+    Run r;
+    r.ws = (unsigned char*)d_workspace; r.wt = u->slab;
+    r.sample = d_pred; r.timesteps = d_grad_loss; r.ctx = d_target; r.out = d_out;
+    r.down_res = nullptr; r.mid_res = nullptr; r.ref_store = nullptr;
+    r.stream = (hipStream_t)stream;
+    const size_t lo = phase == 2 ? pl.enc_end : 0, hi = phase == 1 ? pl.enc_end : pl.ops.size();
+    for (size_t i = lo; i < hi; ++i) {
+        rc = pl.ops[i].fn(r);
+        if (rc) return rc;
+    }
+    return MVE_OK;
+}
+
+int mve_lpips_forward(void* handle, const void* d_pred, const void* d_target, int io_dtype, int B, int H, int W, float* d_loss,
+                      void* d_workspace, size_t workspace_bytes, void* stream) {
+    return lpips_run(handle, 1, d_pred, d_target, nullptr, io_dtype, B, H, W, d_loss, d_workspace, workspace_bytes, stream);
+}
+
+int mve_lpips_backward(void* handle, const float* d_grad_loss, int io_dtype, int B, int H, int W, void* d_grad_pred, void* d_workspace,
+                       size_t workspace_bytes, void* stream) {
+    return lpips_run(handle, 2, nullptr, nullptr, d_grad_loss, io_dtype, B, H, W, d_grad_pred, d_workspace, workspace_bytes, stream);
+}
+
 int mve_unet_tune(int fuse_shortcut) {
     const int old = g_fuse_shortcut;
     if (fuse_shortcut >= 0) g_fuse_shortcut = fuse_shortcut ? 1 : 0;
@@ -1708,8 +1941,10 @@ int mve_unet_load_param(void* handle, const char* name, const void* d_src, int s
             mve_set_error("unet_load_param: hipMalloc(%zu) failed: %s", u->slab_bytes, hipGetErrorString(e));
             return MVE_ERR_HIP;
         }
+        MVE_HIP(hipMemsetAsync(u->slab, 0, u->slab_bytes, (hipStream_t)stream));      // padding rows / optional weights start as zeros
     }
     std::string nm = name;
+    if (u->cfg.lpips && nm.compare(0, 5, "lins.") == 0) nm = "lin" + nm.substr(5);      // nn.ModuleList alias of lin0..lin4
     if (u->cfg.vae) {     // AutoencoderKL state-dict names -> the half's own
         const std::string own = u->cfg.vae == 1 ? "decoder." : "encoder.", pq = u->cfg.vae == 1 ? "post_quant_conv." : "quant_conv.";
         if (nm.compare(0, own.size(), own) == 0) nm = nm.substr(own.size());
@@ -1751,7 +1986,7 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
                      float* op_ms /* optional host array [n_ops]: per-op milliseconds (synchronises) */, void* stream) {
     MVE_CHECK(handle, MVE_ERR_ARG, "unet_forward: null handle");
     Unet* u = (Unet*)handle;
-    MVE_CHECK(!u->cfg.controlnet && !u->cfg.vae && !u->cfg.sr, MVE_ERR_ARG, "unet_forward: handle is a ControlNet / VAE / SRVGG (use their own forward calls)");
+    MVE_CHECK(!u->cfg.controlnet && !u->cfg.vae && !u->cfg.sr && !u->cfg.lpips, MVE_ERR_ARG, "unet_forward: handle is a ControlNet / VAE / SRVGG (use their own forward calls)");
     {
         char first[256];
         const int miss = mve_unet_missing_params(handle, first, sizeof(first));
