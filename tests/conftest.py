@@ -22,9 +22,12 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-# GPU tests written after the round's GPU budget was spent: they have never run on hardware.  Non-strict xfail keeps an unexpected
-# failure from hiding the verified tests behind `-x`; a pass is reported as XPASS.  Remove the mark once a GPU run has confirmed them.
-pending_first_gpu_run = pytest.mark.xfail(strict=False, reason='written after the round-1 GPU budget was exhausted: not yet run on an MI355X')
+# GPU tests written after the round's GPU budget was spent have never run on hardware.  They are skipped unless MVE_RUN_PENDING=1
+# so that an unexpected device fault in unverified code cannot take the verified suite down with it (`pytest -x`, or a fault that
+# kills the process).  First thing next round: MVE_RUN_PENDING=1 python -m pytest tests -m gpu -k "tonemapping or lpips"; then drop the mark.
+pending_first_gpu_run = pytest.mark.skipif(os.environ.get('MVE_RUN_PENDING') != '1',
+                                           reason='written after the round-1 GPU budget was exhausted: not yet run on an MI355X '
+                                                  '(set MVE_RUN_PENDING=1 to run)')
 
 
 @pytest.fixture(scope='session')
