@@ -577,6 +577,22 @@ MVE_API int mve_texture_bilinear_backward(const float* d_grad_out, int Bt, int t
 MVE_API int mve_antialias_backward(const float* d_grad_out, int B, int H, int W, int C, const float* d_rast, const float* d_pos, int V,
                                    const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_color, void* stream);
 
+/* Geometry gradients of dr.rasterize / dr.interpolate (nvdiffrast backward as the reference's mesh optimisation uses it through
+ * MeshRenderer.forward, base_mesh_renderer.py:240-252):
+ *   interpolate_backward_rast: grad_rast[pixel] = (sum_a g_a (a0 - a2), sum_a g_a (a1 - a2), 0, 0)   -- d out / d (u, v)
+ *   rasterize_backward       : grad_pos[b][vertex] += d (u, v, z/w)[pixel] / d clip-space vertex, every pixel's triangle held fixed
+ *                              (continuous barycentrics; float atomics; the caller zero-fills d_grad_pos [B][V][4]). */
+MVE_API int mve_interpolate_backward_rast(const float* d_attr, int Battr, int Vattr, int A, const float* d_rast, int B, int H, int W,
+                                          const int32_t* d_tri, int F, const float* d_grad_out, float* d_grad_rast, void* stream);
+MVE_API int mve_rasterize_backward(const float* d_pos, int B, int V, const int32_t* d_tri, int F, int H, int W, const float* d_rast,
+                                   const float* d_grad_rast, float* d_grad_pos, void* stream);
+/* dr.antialias backward w.r.t. the clip-space vertices (the silhouette gradient): with the pair decisions of the forward held fixed,
+ * out[dst] = c[dst] + |tt - 1/2| (c[src] - c[dst]) and tt is a smooth function of the crossed edge's two vertices.  grad_pos [B][V][4]
+ * is accumulated with float atomics (caller zero-fills or chains it after mve_rasterize_backward). */
+MVE_API int mve_antialias_backward_pos(const float* d_color, const float* d_grad_out, int B, int H, int W, int C, const float* d_rast,
+                                       const float* d_pos, int V, const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_pos,
+                                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,8 +21,37 @@ def edge_dilation(img, mask, radius=3, iters=7):
     return out.to(dtype)
 
 
+class _RasterizeFn(torch.autograd.Function):
+    """Geometry gradient of the rasteriser: d (u, v, z/w) / d clip-space vertices with every pixel's triangle held fixed."""
+
+    @staticmethod
+    def forward(ctx, pos, tri, h, w):
+        rast = _rasterize_raw(pos, tri, (h, w))
+        ctx.save_for_backward(pos.float().contiguous(), tri.to(torch.int32).contiguous(), rast)
+        return rast
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, tri, rast = ctx.saved_tensors
+        B, V, _ = pos.shape
+        _, h, w, _ = rast.shape
+        g_pos = torch.zeros_like(pos)
+        g = g.float().contiguous()
+        with torch.cuda.device(pos.device):
+            _lib.call('mve_rasterize_backward', _lib.ptr(pos), B, V, _lib.ptr(tri), tri.shape[0], h, w, _lib.ptr(rast), _lib.ptr(g), _lib.ptr(g_pos),
+                      _lib.stream_ptr(pos.device))
+        return g_pos, None, None, None
+
+
 def rasterize(pos, tri, resolution):
-    """dr.rasterize(glctx, pos, tri, (h, w)) -> rast [B,h,w,4] = (u, v, z/w, triangle_id+1).  pos [B,V,4] clip space, tri [F,3] int32."""
+    """dr.rasterize(glctx, pos, tri, (h, w)) -> rast [B,h,w,4] = (u, v, z/w, triangle_id+1).  pos [B,V,4] clip space, tri [F,3] int32.
+    Differentiable w.r.t. pos (through u, v, z/w) when pos requires grad."""
+    if torch.is_grad_enabled() and pos.requires_grad:
+        return _RasterizeFn.apply(pos, tri, int(resolution[0]), int(resolution[1]))
+    return _rasterize_raw(pos, tri, resolution)
+
+
+def _rasterize_raw(pos, tri, resolution):
     h, w = resolution
     pos = pos.float().contiguous()
     tri = tri.to(torch.int32).contiguous()
@@ -40,13 +69,13 @@ def rasterize(pos, tri, resolution):
 class _InterpolateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, attr, rast, tri):
-        ctx.save_for_backward(rast, tri)
+        ctx.save_for_backward(rast, tri, attr)
         ctx.attr_shape = tuple(attr.shape)
         return _interpolate_raw(attr, rast, tri)
 
     @staticmethod
     def backward(ctx, g):
-        rast, tri = ctx.saved_tensors
+        rast, tri, attr = ctx.saved_tensors
         Ba, V, A = ctx.attr_shape
         B, h, w, _ = rast.shape
         g_attr = torch.zeros(Ba, V, A, dtype=torch.float32, device=rast.device)
@@ -54,12 +83,20 @@ class _InterpolateFn(torch.autograd.Function):
         with torch.cuda.device(rast.device):
             _lib.call('mve_interpolate_backward', _lib.ptr(g), Ba, V, A, _lib.ptr(rast), B, h, w, _lib.ptr(tri), tri.shape[0], _lib.ptr(g_attr),
                       _lib.stream_ptr(rast.device))
-        return g_attr, None, None
+        g_rast = None
+        if ctx.needs_input_grad[1]:            # d out / d (u, v): the geometry path (rast came from a differentiable rasterize)
+            g_rast = torch.empty_like(rast)
+            a = attr.float().contiguous()
+            with torch.cuda.device(rast.device):
+                _lib.call('mve_interpolate_backward_rast', _lib.ptr(a), Ba, V, A, _lib.ptr(rast), B, h, w, _lib.ptr(tri), tri.shape[0], _lib.ptr(g),
+                          _lib.ptr(g_rast), _lib.stream_ptr(rast.device))
+        return g_attr, g_rast, None
 
 
 def interpolate(attr, rast, tri):
-    """dr.interpolate(attr, rast, tri)[0]: attr [1 or B, V, A] -> [B,h,w,A].  Differentiable w.r.t. attr."""
-    if torch.is_grad_enabled() and attr.requires_grad:
+    """dr.interpolate(attr, rast, tri)[0]: attr [1 or B, V, A] -> [B,h,w,A].  Differentiable w.r.t. attr and, when rast comes from a
+    differentiable `rasterize`, w.r.t. its (u, v)."""
+    if torch.is_grad_enabled() and (attr.requires_grad or rast.requires_grad):
         return _InterpolateFn.apply(attr.float().contiguous(), rast.contiguous(), tri.to(torch.int32).contiguous())
     return _interpolate_raw(attr, rast, tri)
 
@@ -91,6 +128,7 @@ class _AntialiasFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, color, rast, pos, tri, opp):
         ctx.save_for_backward(rast, pos, tri, opp)
+        ctx.color = color.detach() if ctx.needs_input_grad[2] else None        # the silhouette gradient needs the blended colours
         return _antialias_raw(color, rast, pos, tri, opp)
 
     @staticmethod
@@ -102,15 +140,24 @@ class _AntialiasFn(torch.autograd.Function):
         with torch.cuda.device(g.device):
             _lib.call('mve_antialias_backward', _lib.ptr(g), B, h, w, C, _lib.ptr(rast), _lib.ptr(pos), pos.shape[1], _lib.ptr(tri), tri.shape[0],
                       _lib.ptr(opp), _lib.ptr(g_in), _lib.stream_ptr(g.device))
-        return g_in, None, None, None, None
+        g_pos = None
+        if ctx.needs_input_grad[2]:            # d out / d clip-space vertices of the crossed silhouette edges
+            g_pos = torch.zeros_like(pos)
+            with torch.cuda.device(g.device):
+                _lib.call('mve_antialias_backward_pos', _lib.ptr(ctx.color), _lib.ptr(g), B, h, w, C, _lib.ptr(rast), _lib.ptr(pos), pos.shape[1],
+                          _lib.ptr(tri), tri.shape[0], _lib.ptr(opp), _lib.ptr(g_pos), _lib.stream_ptr(g.device))
+        return g_in, None, g_pos, None, None
 
 
 def antialias(color, rast, pos, tri, opp=None):
-    """dr.antialias(color, rast, pos, tri): color [B,h,w,C] -> same shape (rules: oracle/raster_oracle.c).  Differentiable w.r.t. color."""
-    rast, pos = rast.contiguous(), pos.detach().float().contiguous()
+    """dr.antialias(color, rast, pos, tri): color [B,h,w,C] -> same shape (rules: oracle/raster_oracle.c).  Differentiable w.r.t. color
+    and, when pos requires grad, w.r.t. the clip-space vertices of the silhouette edges."""
+    pos_grad = torch.is_grad_enabled() and pos.requires_grad
+    rast = rast.detach().contiguous()
+    pos = pos.float().contiguous() if pos_grad else pos.detach().float().contiguous()
     tri = tri.to(torch.int32).contiguous()
     opp = edge_opposites(tri) if opp is None else opp
-    if torch.is_grad_enabled() and color.requires_grad:
+    if torch.is_grad_enabled() and (color.requires_grad or pos_grad):
         return _AntialiasFn.apply(color.float().contiguous(), rast, pos, tri, opp)
     return _antialias_raw(color, rast, pos, tri, opp)
 
