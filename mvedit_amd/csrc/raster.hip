@@ -793,10 +793,13 @@ int mve_antialias_backward(const float* d_grad_out, int B, int H, int W, int C, 
 
 // =========================================================================================================
 // Geometry gradients (mesh half): d rast / d clip-space vertices with every pixel's triangle held fixed,
-// and d interpolate / d (u, v).  Together they carry image-space gradients back to the DMTet vertices the reference optimises through
-// dr.rasterize / dr.interpolate (base_mesh_renderer.py:240-252).  The chain rule below is stated and checked against autograd in
-// oracle/raster_grad_oracle.py (rasterize_backward); it differentiates the continuous (unsnapped) barycentrics.
+// d interpolate / d (u, v), and the silhouette term of dr.antialias (d |tt - 1/2| / d the crossed edge's vertices).  Together they carry
+// image-space gradients back to the DMTet vertices the reference optimises through dr.rasterize / dr.interpolate / dr.antialias
+// (base_mesh_renderer.py:240-263).  The per-pixel arithmetic lives in raster_grad_core.h, which also compiles for the host: the CPU
+// tests run that very source against autograd and against finite differences of the C oracle (oracle/raster_grad_oracle.py).
 // =========================================================================================================
+#include "raster_grad_core.h"
+
 namespace {
 
 __global__ __launch_bounds__(RB) void k_interpolate_bwd_rast(const float* __restrict__ attr, int Battr, int Vattr, int A, const float* __restrict__ rast,
@@ -804,21 +807,8 @@ __global__ __launch_bounds__(RB) void k_interpolate_bwd_rast(const float* __rest
                                                              const float* __restrict__ g_out, float* __restrict__ g_rast) {
     const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
     if (i >= (size_t)B * npix) return;
-    const f32x4 r = reinterpret_cast<const f32x4*>(rast)[i];
-    const int id = (int)r[3] - 1;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    if (id >= 0 && id < F) {
-        const int b = (int)(i / npix);
-        const float* at = attr + (Battr > 1 ? (size_t)b * Vattr * A : 0);
-        const float* a0 = at + (size_t)tri[3 * id] * A;
-        const float* a1 = at + (size_t)tri[3 * id + 1] * A;
-        const float* a2 = at + (size_t)tri[3 * id + 2] * A;
-        const float* g = g_out + i * A;
-        float gu = 0.f, gv = 0.f;
-        for (int a = 0; a < A; ++a) { gu += g[a] * (a0[a] - a2[a]); gv += g[a] * (a1[a] - a2[a]); }
-        o[0] = gu; o[1] = gv;
-    }
-    reinterpret_cast<f32x4*>(g_rast)[i] = o;
+    const int b = (int)(i / npix);
+    rg_interpolate_bwd_rast(attr + (Battr > 1 ? (size_t)b * Vattr * A : 0), A, rast + 4 * i, tri, F, g_out + i * A, g_rast + 4 * i);
 }
 
 __global__ __launch_bounds__(RB) void k_rasterize_bwd(const float* __restrict__ pos, int B, int V, const int32_t* __restrict__ tri, int F, int H,
@@ -827,65 +817,20 @@ __global__ __launch_bounds__(RB) void k_rasterize_bwd(const float* __restrict__ 
     const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
     const size_t npix = (size_t)H * W;
     if (i >= (size_t)B * npix) return;
-    const int id = (int)rast[4 * i + 3] - 1;
-    if (id < 0 || id >= F) return;
-    const f32x4 g = reinterpret_cast<const f32x4*>(g_rast)[i];
-    const float gu = g[0], gv = g[1], gz = g[2];
-    if (gu == 0.f && gv == 0.f && gz == 0.f) return;
     const int b = (int)(i / npix);
-    const float cx = (float)(i % W) + 0.5f, cy = (float)((i % npix) / W) + 0.5f;
-    int vid[3];
-    float x[3], y[3], z[3], iw[3], sx[3], sy[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        vid[k] = tri[3 * id + k];
-        const f32x4 p = *reinterpret_cast<const f32x4*>(pos + ((size_t)b * V + vid[k]) * 4);
-        x[k] = p[0]; y[k] = p[1]; z[k] = p[2]; iw[k] = 1.0f / p[3];
-        sx[k] = (x[k] * iw[k] * 0.5f + 0.5f) * (float)W;
-        sy[k] = (y[k] * iw[k] * 0.5f + 0.5f) * (float)H;
-    }
-    float E[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int a = (k + 1) % 3, c = (k + 2) % 3;
-        E[k] = (sx[c] - sx[a]) * (cy - sy[a]) - (sy[c] - sy[a]) * (cx - sx[a]);
-    }
-    const float tot = E[0] + E[1] + E[2];
-    if (tot == 0.f) return;
-    float bq[3], q[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { bq[k] = E[k] / tot; q[k] = bq[k] * iw[k]; }
-    const float S = q[0] + q[1] + q[2];
-    const float u = q[0] / S, v = q[1] / S;
-    const float common = gu * u + gv * v;
-    const float gq[3] = {(gu - common) / S, (gv - common) / S, -common / S};
-    float gb[3], g_iw[3], g_zw[3], dotb = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        gb[k] = gq[k] * iw[k] + gz * (z[k] * iw[k]);
-        g_iw[k] = gq[k] * bq[k];
-        g_zw[k] = gz * bq[k];
-        dotb += gb[k] * bq[k];
-    }
-    float gsx[3] = {0.f, 0.f, 0.f}, gsy[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int a = (k + 1) % 3, c = (k + 2) % 3;
-        const float gE = (gb[k] - dotb) / tot;
-        gsx[a] += gE * (sy[c] - cy);
-        gsy[a] += gE * (cx - sx[c]);
-        gsx[c] += gE * (cy - sy[a]);
-        gsy[c] += -gE * (cx - sx[a]);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float* dst = g_pos + ((size_t)b * V + vid[k]) * 4;
-        const float hx = gsx[k] * (0.5f * (float)W), hy = gsy[k] * (0.5f * (float)H);
-        atomicAdd(dst + 0, hx * iw[k]);
-        atomicAdd(dst + 1, hy * iw[k]);
-        atomicAdd(dst + 2, g_zw[k] * iw[k]);
-        atomicAdd(dst + 3, -(hx * x[k] + hy * y[k] + g_zw[k] * z[k] + g_iw[k]) * iw[k] * iw[k]);
-    }
+    rg_rasterize_bwd(pos + (size_t)b * V * 4, tri, F, H, W, rast + 4 * i, g_rast + 4 * i, (int)(i % W), (int)((i % npix) / W), g_pos + (size_t)b * V * 4);
+}
+
+__global__ __launch_bounds__(RB) void k_antialias_bwd_pos(const float* __restrict__ color, const float* __restrict__ g_out, int B, int H, int W,
+                                                          int C, const float* __restrict__ rast, const float* __restrict__ pos, int V,
+                                                          const int32_t* __restrict__ tri, int F, const int32_t* __restrict__ opp,
+                                                          float* __restrict__ g_pos) {
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    const size_t npix = (size_t)H * W;
+    if (i >= (size_t)B * npix) return;
+    const int b = (int)(i / npix), y = (int)((i % npix) / W), x = (int)(i % W);
+    const RGView a{rast + (size_t)b * npix * 4, pos + (size_t)b * V * 4, tri, opp, V, F, H, W};
+    rg_antialias_bwd_pos(a, color + (size_t)b * npix * C, g_out + i * C, C, x, y, g_pos + (size_t)b * V * 4);
 }
 
 }  // namespace
@@ -912,135 +857,9 @@ int mve_rasterize_backward(const float* d_pos, int B, int V, const int32_t* d_tr
     return MVE_OK;
 }
 
-}  // extern "C"
-
-// =========================================================================================================
-// dr.antialias: gradient w.r.t. the clip-space vertices (the silhouette term of the reference's mesh optimisation).  With the
-// discrete choices of aa_pair (front triangle, crossed edge, direction) held fixed, the blend weight |tt - 1/2| is a smooth function
-// of the crossed edge's two vertices.  Chain rule as stated in oracle/raster_grad_oracle.py (antialias_backward_pos), which is checked
-// against finite differences of the C oracle's forward.
-// =========================================================================================================
-namespace {
-
-struct AAEdge { int va, vb; bool horizontal; float s, d, ex, ey, sign; };
-
-// aa_pair (above) with the crossed edge reported; the decision logic is the same operation for operation
-__device__ __forceinline__ bool aa_pair_ex(const AAView& a, int px, int py, int qx, int qy, bool& dst_is_p, float& wgt, AAEdge& ed) {
-    const f32x4 rp = reinterpret_cast<const f32x4*>(a.rast)[(size_t)py * a.W + px];
-    const f32x4 rq = reinterpret_cast<const f32x4*>(a.rast)[(size_t)qy * a.W + qx];
-    const int ip = (int)rp[3] - 1, iq = (int)rq[3] - 1;
-    if (ip == iq) return false;
-    bool use_p;
-    if (ip < 0) use_p = false;
-    else if (iq < 0) use_p = true;
-    else if (rp[2] != rq[2]) use_p = rp[2] < rq[2];
-    else use_p = (py * a.W + px) < (qy * a.W + qx);
-    const int t = use_p ? ip : iq;
-    if (t < 0 || t >= a.F) return false;
-    const int ox = use_p ? px : qx, oy = use_p ? py : qy, nx = use_p ? qx : px, ny = use_p ? qy : py;
-    float sx[3], sy[3];
-    int vi[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        vi[k] = a.tri[3 * t + k];
-        if (vi[k] < 0 || vi[k] >= a.V) return false;
-        const f32x4 v = reinterpret_cast<const f32x4*>(a.pos)[vi[k]];
-        if (v[3] <= 1e-6f) return false;
-        sx[k] = (v[0] / v[3] * 0.5f + 0.5f) * (float)a.W;
-        sy[k] = (v[1] / v[3] * 0.5f + 0.5f) * (float)a.H;
-    }
-    const float cx = (float)ox + 0.5f, cy = (float)oy + 0.5f;
-    const float dx = (float)(nx - ox), dy = (float)(ny - oy);
-    float best = 2.0f;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        const int ia = e, ib = (e + 1) % 3, ic = (e + 2) % 3;
-        const float ex = sx[ib] - sx[ia], ey = sy[ib] - sy[ia];
-        const int o = a.opp[3 * t + e];
-        if (o >= 0) {
-            if (o >= a.V) continue;
-            const f32x4 v = reinterpret_cast<const f32x4*>(a.pos)[o];
-            if (v[3] <= 1e-6f) continue;
-            const float oxs = (v[0] / v[3] * 0.5f + 0.5f) * (float)a.W, oys = (v[1] / v[3] * 0.5f + 0.5f) * (float)a.H;
-            const float sc = ex * (sy[ic] - sy[ia]) - ey * (sx[ic] - sx[ia]);
-            const float so = ex * (oys - sy[ia]) - ey * (oxs - sx[ia]);
-            if (!(sc * so >= 0.0f)) continue;
-        }
-        float s, tt;
-        if (dy == 0.0f) {
-            if (ey == 0.0f) continue;
-            s = (cy - sy[ia]) / ey;
-            tt = ((sx[ia] + s * ex) - cx) * dx;
-        } else {
-            if (ex == 0.0f) continue;
-            s = (cx - sx[ia]) / ex;
-            tt = ((sy[ia] + s * ey) - cy) * dy;
-        }
-        if (s >= 0.0f && s <= 1.0f && tt >= 0.0f && tt <= 1.0f && tt < best) {
-            best = tt;
-            ed.va = vi[ia]; ed.vb = vi[ib]; ed.horizontal = dy == 0.0f; ed.s = s; ed.d = dy == 0.0f ? dx : dy; ed.ex = ex; ed.ey = ey;
-        }
-    }
-    if (best > 1.0f) return false;
-    if (best > 0.5f) { dst_is_p = !use_p; wgt = best - 0.5f; ed.sign = 1.0f; }
-    else if (best < 0.5f) { dst_is_p = use_p; wgt = 0.5f - best; ed.sign = -1.0f; }
-    else return false;
-    return true;
-}
-
-__global__ __launch_bounds__(RB) void k_antialias_bwd_pos(const float* __restrict__ color, const float* __restrict__ g_out, int B, int H, int W,
-                                                          int C, const float* __restrict__ rast, const float* __restrict__ pos, int V,
-                                                          const int32_t* __restrict__ tri, int F, const int32_t* __restrict__ opp,
-                                                          float* __restrict__ g_pos) {
-    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
-    const size_t npix = (size_t)H * W;
-    if (i >= (size_t)B * npix) return;
-    const int b = (int)(i / npix), y = (int)((i % npix) / W), x = (int)(i % W);
-    AAView a{rast + (size_t)b * npix * 4, pos + (size_t)b * V * 4, tri, opp, V, F, H, W};
-    const float* col = color + (size_t)b * npix * C;
-    const float* self = col + ((size_t)y * W + x) * C;
-    const float* g = g_out + i * C;
-    float* gp = g_pos + (size_t)b * V * 4;
-    const int ddx[4] = {-1, 1, 0, 0}, ddy[4] = {0, 0, -1, 1};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int qx = x + ddx[k], qy = y + ddy[k];
-        if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
-        bool dst_is_p;
-        float w;
-        AAEdge ed;
-        if (!aa_pair_ex(a, x, y, qx, qy, dst_is_p, w, ed) || !dst_is_p) continue;     // each blend is visited once, from its receiving pixel
-        const float* nb = col + ((size_t)qy * W + qx) * C;
-        float dot = 0.f;
-        for (int c = 0; c < C; ++c) dot += g[c] * (nb[c] - self[c]);
-        const float g_tt = ed.sign * dot;
-        if (g_tt == 0.f) continue;
-        float gsx[2], gsy[2];
-        if (ed.horizontal) {
-            gsx[0] = (1.0f - ed.s) * ed.d; gsx[1] = ed.s * ed.d;
-            gsy[0] = ed.ex * (ed.s - 1.0f) / ed.ey * ed.d; gsy[1] = -ed.ex * ed.s / ed.ey * ed.d;
-        } else {
-            gsy[0] = (1.0f - ed.s) * ed.d; gsy[1] = ed.s * ed.d;
-            gsx[0] = ed.ey * (ed.s - 1.0f) / ed.ex * ed.d; gsx[1] = -ed.ey * ed.s / ed.ex * ed.d;
-        }
-        const int vid[2] = {ed.va, ed.vb};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f32x4 p = reinterpret_cast<const f32x4*>(a.pos)[vid[j]];
-            const float iw = 1.0f / p[3];
-            const float hx = g_tt * gsx[j] * (0.5f * (float)W), hy = g_tt * gsy[j] * (0.5f * (float)H);
-            atomicAdd(gp + 4 * (size_t)vid[j] + 0, hx * iw);
-            atomicAdd(gp + 4 * (size_t)vid[j] + 1, hy * iw);
-            atomicAdd(gp + 4 * (size_t)vid[j] + 3, -(hx * p[0] + hy * p[1]) * iw * iw);
-        }
-    }
-}
-
-}  // namespace
-
-extern "C" int mve_antialias_backward_pos(const float* d_color, const float* d_grad_out, int B, int H, int W, int C, const float* d_rast,
-                                          const float* d_pos, int V, const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_pos,
-                                          void* stream) {
+int mve_antialias_backward_pos(const float* d_color, const float* d_grad_out, int B, int H, int W, int C, const float* d_rast,
+                               const float* d_pos, int V, const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_pos,
+                               void* stream) {
     const size_t total = (size_t)B * H * W;
     if (total == 0 || C == 0) return MVE_OK;
     MVE_CHECK(d_color && d_grad_out && d_rast && d_pos && d_tri && d_opp && d_grad_pos, MVE_ERR_ARG, "antialias_backward_pos: null pointer");
@@ -1048,3 +867,5 @@ extern "C" int mve_antialias_backward_pos(const float* d_color, const float* d_g
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }
+
+}  // extern "C"

@@ -5,6 +5,8 @@
 // reference's expression op by op.
 #include "common.h"
 
+#include "shading_core.h"
+
 namespace {
 
 constexpr int NT = 256;
@@ -14,39 +16,15 @@ struct Lut {
     const float* x; const float* y; int n;
 };
 
-// torch.bucketize(v, table, right=True).clamp(1, n - 1): number of table entries <= v
-__device__ __forceinline__ int bucket(const float* __restrict__ t, int n, float v) {
-    int i = 0;
-    for (int k = 0; k < n; ++k) i += (t[k] <= v) ? 1 : 0;
-    return i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
-}
-
-// piecewise-linear map from table a to table b (lut: a = lut_x, b = lut_y; inverse_lut: a = lut_y, b = lut_x)
-__device__ __forceinline__ float interp(const float* __restrict__ a, const float* __restrict__ b, int n, float v) {
-    const int i = bucket(a, n, v);
-    const float t = (v - a[i - 1]) / (a[i] - a[i - 1]);
-    return b[i - 1] + (b[i] - b[i - 1]) * t;
-}
-
 __global__ __launch_bounds__(NT) void k_lut(const float* __restrict__ v, size_t n, Lut l, int inverse, int linear, float* __restrict__ out) {
     __shared__ float tx[MAX_STEPS], ty[MAX_STEPS];
     if (threadIdx.x < l.n) { tx[threadIdx.x] = l.x[threadIdx.x]; ty[threadIdx.x] = l.y[threadIdx.x]; }
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
-    float x = v[i];
-    if (!inverse) {
-        if (linear) x = log2f(fmaxf(x, 1e-6f));
-        out[i] = interp(tx, ty, l.n, x);
-    } else {
-        const float r = interp(ty, tx, l.n, x);
-        out[i] = linear ? exp2f(r) : r;
-    }
+    out[i] = sh_lut(tx, ty, l.n, v[i], inverse, linear);
 }
 
-// image = lut(inverse_lut(rgb / max(alpha, 1e-6)) + log2(max(shading, 1e-6))) * alpha + bg * (1 - alpha)      (tone-mapped), or
-// image = rgb * shading + bg * (1 - alpha)                                                                    (no table),
-// shading = max(light . n_cv, 0) * (1 - ambient) + ambient,  n_cv = (2 n0 - 1, 1 - 2 n1, 1 - 2 n2)
 __global__ __launch_bounds__(NT) void k_shade_views(const float* __restrict__ rgba, const float* __restrict__ normal_fg,
                                                     const float* __restrict__ lights, unsigned n_views, unsigned pix, float ambient,
                                                     float bg, Lut l, float* __restrict__ image) {
@@ -55,22 +33,7 @@ __global__ __launch_bounds__(NT) void k_shade_views(const float* __restrict__ rg
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= (size_t)n_views * pix) return;
-    const unsigned v = (unsigned)(i / pix);
-    const f32x4 c = *reinterpret_cast<const f32x4*>(rgba + i * 4);
-    const float n0 = normal_fg[i * 3] * 2.0f - 1.0f, n1 = -normal_fg[i * 3 + 1] * 2.0f + 1.0f, n2 = -normal_fg[i * 3 + 2] * 2.0f + 1.0f;
-    const float dot = (lights[v * 3] * n0 + lights[v * 3 + 1] * n1) + lights[v * 3 + 2] * n2;
-    const float shading = fmaxf(dot, 0.0f) * (1.0f - ambient) + ambient;
-    const float a = c[3], back = bg * (1.0f - a);
-    float o[3];
-    if (l.n > 0) {
-        const float ls = log2f(fmaxf(shading, 1e-6f)), den = fmaxf(a, 1e-6f);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] = interp(tx, ty, l.n, interp(ty, tx, l.n, c[k] / den) + ls) * a + back;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] = c[k] * shading + back;
-    }
-    image[i * 3] = o[0]; image[i * 3 + 1] = o[1]; image[i * 3 + 2] = o[2];
+    sh_shade_pixel(rgba + i * 4, normal_fg + i * 3, lights + 3 * (i / pix), ambient, bg, tx, ty, l.n, image + i * 3);
 }
 
 }  // namespace

@@ -1,0 +1,50 @@
+// Per-element arithmetic of the tone-mapping table and the render-step shading (shading.hip), written so that the same source also
+// compiles for the host (oracle/devcore_host.cpp): the CPU tests compare that build with outputs of the reference's Tonemapping class.
+// No fma contraction in either build.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define MVE_SH_FN __device__ __forceinline__
+#else
+#define MVE_SH_FN static inline
+#endif
+
+// torch.bucketize(v, table, right=True).clamp(1, n - 1): number of table entries <= v
+MVE_SH_FN int sh_bucket(const float* t, int n, float v) {
+    int i = 0;
+    for (int k = 0; k < n; ++k) i += (t[k] <= v) ? 1 : 0;
+    return i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
+}
+
+// piecewise-linear map from table a to table b (lut: a = lut_x, b = lut_y; inverse_lut: a = lut_y, b = lut_x)
+MVE_SH_FN float sh_interp(const float* a, const float* b, int n, float v) {
+    const int i = sh_bucket(a, n, v);
+    const float t = (v - a[i - 1]) / (a[i] - a[i - 1]);
+    return b[i - 1] + (b[i] - b[i - 1]) * t;
+}
+
+// Tonemapping.lut (inverse = 0; linear: input_mode='linear') / Tonemapping.inverse_lut (inverse = 1; linear: output_mode='linear')
+MVE_SH_FN float sh_lut(const float* tx, const float* ty, int n, float x, int inverse, int linear) {
+    if (!inverse) {
+        if (linear) x = log2f(fmaxf(x, 1e-6f));
+        return sh_interp(tx, ty, n, x);
+    }
+    const float r = sh_interp(ty, tx, n, x);
+    return linear ? exp2f(r) : r;
+}
+
+// one pixel of lib/pipelines/mvedit_3d_pipeline.py:1372-1384 (n = 0: `self.tonemapping is None`)
+MVE_SH_FN void sh_shade_pixel(const float* rgba, const float* normal_fg, const float* light, float ambient, float bg, const float* tx,
+                              const float* ty, int n, float* out) {
+    const float n0 = normal_fg[0] * 2.0f - 1.0f, n1 = -normal_fg[1] * 2.0f + 1.0f, n2 = -normal_fg[2] * 2.0f + 1.0f;
+    const float dot = (light[0] * n0 + light[1] * n1) + light[2] * n2;
+    const float shading = fmaxf(dot, 0.0f) * (1.0f - ambient) + ambient;
+    const float a = rgba[3], back = bg * (1.0f - a);
+    if (n > 0) {
+        const float ls = log2f(fmaxf(shading, 1e-6f)), den = fmaxf(a, 1e-6f);
+        for (int k = 0; k < 3; ++k) out[k] = sh_interp(tx, ty, n, sh_interp(ty, tx, n, rgba[k] / den) + ls) * a + back;
+    } else {
+        for (int k = 0; k < 3; ++k) out[k] = rgba[k] * shading + back;
+    }
+}

@@ -20,3 +20,18 @@ def build(force=False):
     if stale:
         subprocess.run(['make', '-C', HERE, '-B', 'liboracle.so'], check=True, capture_output=True)
     return LIB
+
+
+DEVCORE = os.path.join(HERE, 'libdevcore.so')
+
+
+def build_devcore(force=False):
+    """Host build (g++) of the product's host/device core headers behind plain loops (devcore_host.cpp): lets the CPU tests run the
+    per-pixel arithmetic of kernels whose first GPU run is pending."""
+    src = os.path.join(HERE, 'devcore_host.cpp')
+    core = os.path.join(os.path.dirname(HERE), 'mvedit_amd', 'csrc')
+    deps = [src, os.path.join(core, 'raster_grad_core.h'), os.path.join(core, 'shading_core.h')]
+    if force or not os.path.exists(DEVCORE) or any(os.path.getmtime(d) > os.path.getmtime(DEVCORE) for d in deps):
+        subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-Wall', '-shared', '-o', DEVCORE, src, '-lm'],
+                       check=True, capture_output=True)
+    return DEVCORE

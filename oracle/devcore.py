@@ -1,0 +1,64 @@
+"""ORACLE -- test infrastructure only: numpy front-end of libdevcore.so, the HOST build of the product's host/device core headers
+(mvedit_amd/csrc/raster_grad_core.h, shading_core.h; harness: oracle/devcore_host.cpp).  Same arithmetic as the HIP kernels
+mve_rasterize_backward / mve_interpolate_backward_rast / mve_antialias_backward_pos / mve_tonemap_lut / mve_shade_views, sequential."""
+import ctypes
+
+import numpy as np
+
+from . import build_devcore
+
+_lib = ctypes.CDLL(build_devcore())
+_p, _i, _f, _u, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint, ctypes.c_size_t
+_lib.dc_interpolate_backward_rast.argtypes = [_p, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p]
+_lib.dc_rasterize_backward.argtypes = [_p, _i, _i, _p, _i, _i, _i, _p, _p, _p]
+_lib.dc_antialias_backward_pos.argtypes = [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]
+_lib.dc_tonemap_lut.argtypes = [_p, _z, _p, _p, _i, _i, _i, _p]
+_lib.dc_shade_views.argtypes = [_p, _p, _p, _u, _u, _f, _f, _p, _p, _i, _p]
+for f in (_lib.dc_interpolate_backward_rast, _lib.dc_rasterize_backward, _lib.dc_antialias_backward_pos, _lib.dc_tonemap_lut, _lib.dc_shade_views):
+    f.restype = None
+
+_c = lambda a, dt=np.float32: np.ascontiguousarray(a, dt)
+_ptr = lambda a: a.ctypes.data_as(_p) if a is not None else None
+
+
+def interpolate_backward_rast(attr, rast, tri, grad_out):
+    attr, rast, tri, grad_out = _c(attr), _c(rast), _c(tri, np.int32), _c(grad_out)
+    B, H, W, _ = rast.shape
+    out = np.zeros_like(rast)
+    _lib.dc_interpolate_backward_rast(_ptr(attr), attr.shape[0], attr.shape[1], attr.shape[2], _ptr(rast), B, H, W, _ptr(tri), tri.shape[0],
+                                      _ptr(grad_out), _ptr(out))
+    return out
+
+
+def rasterize_backward(pos, tri, rast, grad_rast):
+    pos, rast, tri, grad_rast = _c(pos), _c(rast), _c(tri, np.int32), _c(grad_rast)
+    B, H, W, _ = rast.shape
+    out = np.zeros_like(pos)
+    _lib.dc_rasterize_backward(_ptr(pos), B, pos.shape[1], _ptr(tri), tri.shape[0], H, W, _ptr(rast), _ptr(grad_rast), _ptr(out))
+    return out
+
+
+def antialias_backward_pos(color, rast, pos, tri, opp, grad_out):
+    color, rast, pos, tri, opp, grad_out = _c(color), _c(rast), _c(pos), _c(tri, np.int32), _c(opp, np.int32), _c(grad_out)
+    B, H, W, C = color.shape
+    out = np.zeros_like(pos)
+    _lib.dc_antialias_backward_pos(_ptr(color), _ptr(grad_out), B, H, W, C, _ptr(rast), _ptr(pos), pos.shape[1], _ptr(tri), tri.shape[0], _ptr(opp),
+                                   _ptr(out))
+    return out
+
+
+def tonemap_lut(x, lut_x, lut_y, inverse=False, linear=False):
+    x, lut_x, lut_y = _c(x), _c(lut_x), _c(lut_y)
+    out = np.empty_like(x)
+    _lib.dc_tonemap_lut(_ptr(x), x.size, _ptr(lut_x), _ptr(lut_y), lut_x.size, int(inverse), int(linear), _ptr(out))
+    return out
+
+
+def shade_views(rgba, normal_fg, cam_lights, ambient, bg, lut_x=None, lut_y=None):
+    rgba, normal_fg, cam_lights = _c(rgba), _c(normal_fg), _c(cam_lights)
+    lx, ly = (_c(lut_x), _c(lut_y)) if lut_x is not None else (None, None)
+    b = cam_lights.shape[0]
+    n = rgba.size // 4
+    out = np.empty(rgba.shape[:-1] + (3,), np.float32)
+    _lib.dc_shade_views(_ptr(rgba), _ptr(normal_fg), _ptr(cam_lights), b, n // b, ambient, bg, _ptr(lx), _ptr(ly), lx.size if lx is not None else 0, _ptr(out))
+    return out

@@ -87,6 +87,29 @@ def test_antialias_position_gradient_vs_finite_differences():
     assert bad <= len(idx) // 20            # a perturbation may flip a discrete choice now and then
 
 
+def test_device_source_on_host_equals_closed_forms():
+    """The per-pixel bodies of the three HIP kernels (mvedit_amd/csrc/raster_grad_core.h) compiled for the HOST (oracle/devcore_host.cpp,
+    fp32, sequential) against the float64 closed forms above: the device arithmetic itself is checked here; what is left for the
+    first GPU run is the launch geometry and the atomics."""
+    from oracle import devcore as D
+    P, tri, H, W = _scene()
+    Pn, trin = P.numpy(), tri.numpy()
+    rast = np.asarray(RO.rasterize(Pn, trin, (H, W)))
+    rng = np.random.default_rng(3)
+    g_rast = rng.standard_normal(rast.shape).astype(np.float32)
+    want = R.rasterize_backward(P.double(), tri, torch.from_numpy(rast).double(), torch.from_numpy(g_rast).double()).numpy()
+    got = D.rasterize_backward(Pn, trin, rast, g_rast)
+    assert np.abs(got - want).max() < 5e-5 * np.abs(want).max()
+    attr = rng.standard_normal((1, Pn.shape[1], 5)).astype(np.float32)
+    go = rng.standard_normal((2, H, W, 5)).astype(np.float32)
+    want = R.interpolate_backward_rast(torch.from_numpy(attr).double(), tri, torch.from_numpy(rast).double(), torch.from_numpy(go).double()).numpy()
+    assert np.abs(D.interpolate_backward_rast(attr, rast, trin, go) - want).max() < 1e-5
+    Pn, trin, rast, opp, color, G = _aa_case()
+    want = R.antialias_backward_pos(color, rast, Pn, trin, opp, G)
+    got = D.antialias_backward_pos(color, rast, Pn, trin, opp, G)
+    assert (np.abs(got) > 0).sum() >= 20 and np.abs(got - want).max() < 1e-5 * np.abs(want).max()
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pending_first_gpu_run

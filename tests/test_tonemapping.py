@@ -38,6 +38,20 @@ def test_lut_round_trip_property():
     assert (T.inverse_lut(lx, ly, T.lut(lx, ly, x)) - x).abs().max() < 2e-5
 
 
+def test_device_source_on_host_matches_reference_output():
+    """mvedit_amd/csrc/shading_core.h -- the arithmetic of mve_tonemap_lut / mve_shade_views -- compiled for the HOST
+    (oracle/devcore_host.cpp) against outputs of the reference's Tonemapping class: bit-exact in 'log' mode and on the shaded batch;
+    last-place differences of log2f / exp2f in the 'linear' modes."""
+    from oracle import devcore as D
+    lx, ly = G['lut_x'], G['lut_y']
+    assert np.array_equal(D.tonemap_lut(G['x_log'], lx, ly), G['lut_log'])
+    assert np.array_equal(D.tonemap_lut(G['y'], lx, ly, inverse=True), G['inv_log'])
+    np.testing.assert_allclose(D.tonemap_lut(G['x_lin'], lx, ly, linear=True), G['lut_lin'], rtol=1e-6, atol=2e-7)
+    np.testing.assert_allclose(D.tonemap_lut(G['y'], lx, ly, inverse=True, linear=True), G['inv_lin'], rtol=1e-6)
+    np.testing.assert_allclose(D.shade_views(G['rgba'], G['normal_fg'], G['cam_lights'], 0.1, 1.0, lx, ly), G['shaded_tm'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(D.shade_views(G['rgba'], G['normal_fg'], G['cam_lights'], 0.1, 1.0), G['shaded_plain'], rtol=1e-6, atol=1e-7)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pending_first_gpu_run
