@@ -172,3 +172,81 @@ def test_dgrad_weight_packing_formula():
     g = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
     y.backward(g)
     assert torch.allclose(F.conv2d(g, torch.from_numpy(Wp), padding=1), x.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_layer_gradient_closed_form():
+    """The per-pixel closed form the layer-backward kernel evaluates (csrc/lpips.hip, k_lpips_layer<MODE 1>):
+        g_c = coef (2 w_c d_c / n0 - (sum_k 2 w_k d_k f0_k) f0_c / (n0^2 |f0|)),  d = f0 / n0 - f1 / n1,  n = |f| + 1e-10,  coef = dL/dloss / HW
+    against autograd over lpips' normalize_tensor / lin / spatial-average wiring, float64."""
+    g = torch.Generator().manual_seed(7)
+    B, C, H, W = 2, 64, 5, 6
+    f0 = torch.relu(torch.randn(B, C, H, W, generator=g, dtype=torch.float64)).requires_grad_(True)
+    f1 = torch.relu(torch.randn(B, C, H, W, generator=g, dtype=torch.float64))
+    w = torch.rand(C, generator=g, dtype=torch.float64)
+    coef = torch.tensor([0.7, 1.3], dtype=torch.float64)
+    u0 = f0 / (torch.sqrt((f0 ** 2).sum(1, keepdim=True)) + 1e-10)
+    u1 = f1 / (torch.sqrt((f1 ** 2).sum(1, keepdim=True)) + 1e-10)
+    val = (((u0 - u1) ** 2) * w.view(1, C, 1, 1)).sum(1).mean(dim=(1, 2))
+    (val * coef).sum().backward()
+    x, y = f0.detach(), f1
+    r0 = torch.sqrt((x ** 2).sum(1, keepdim=True))
+    i0, i1 = 1 / (r0 + 1e-10), 1 / (torch.sqrt((y ** 2).sum(1, keepdim=True)) + 1e-10)
+    d = x * i0 - y * i1
+    wv = w.view(1, C, 1, 1)
+    dot = (2 * wv * d * x).sum(1, keepdim=True)
+    k2 = dot * i0 * i0 / r0
+    closed = (coef.view(B, 1, 1, 1) / (H * W)) * (2 * wv * d * i0 - k2 * x)
+    assert (closed - f0.grad).abs().max() < 1e-12
+
+
+def test_backward_schedule_equals_autograd():
+    """The executor's backward op order (csrc/unet.hip, build_lpips: per block from the deepest -- layer gradient (closed form), add to
+    the running gradient, then per conv in reverse: ReLU mask on the saved output, dgrad = conv with the transposed / flipped weight,
+    and a first-arg-max pool backward between blocks) replayed with torch ops in fp32 on the CPU, against autograd over the oracle."""
+    sd = L.random_params(3)
+    g = torch.Generator().manual_seed(9)
+    pred, target = torch.rand(2, 3, 32, 32, generator=g), torch.rand(2, 3, 32, 32, generator=g)
+    coef = torch.tensor([1.0, 0.5])
+    p = pred.clone().requires_grad_(True)
+    (L.lpips(sd, p, target) * coef).sum().backward()
+    B = 2
+    x = torch.cat([pred, target]) * 2 - 1
+    h = (x - sd['scaling_layer.shift']) / sd['scaling_layer.scale']
+    acts, pools = [], {}
+    for i in range(13):
+        if i in (2, 4, 7, 10):
+            h = F.max_pool2d(h, 2, 2)
+        n = f'net.slice{L.VGG_SLICE[i]}.{L.VGG_IDX[i]}'
+        h = F.relu(F.conv2d(h, sd[f'{n}.weight'], sd[f'{n}.bias'], padding=1))
+        acts.append(h)
+    first = (0, 2, 4, 7, 10, 13)
+
+    def layer_grad(f, w, k):
+        x0, y = f[:B], f[B:]
+        r0 = torch.sqrt((x0 ** 2).sum(1, keepdim=True))
+        i0, i1 = 1 / (r0 + 1e-10), 1 / (torch.sqrt((y ** 2).sum(1, keepdim=True)) + 1e-10)
+        d = x0 * i0 - y * i1
+        wv = w.view(1, -1, 1, 1)
+        k2 = (2 * wv * d * x0).sum(1, keepdim=True) * i0 * i0 / r0
+        return (coef.view(B, 1, 1, 1) / (f.shape[2] * f.shape[3])) * (2 * wv * d * i0 - k2 * x0)
+
+    def pool_bwd(xin, gy):                                   # first arg-max in row-major window order
+        Bn, C, H, W = xin.shape
+        win = xin.reshape(Bn, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(Bn, C, H // 2, W // 2, 4)
+        arg = win.argmax(-1)                                 # torch.argmax returns the first maximal index
+        gx = torch.zeros_like(win).scatter_(-1, arg[..., None], gy[..., None])
+        return gx.reshape(Bn, C, H // 2, W // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(Bn, C, H, W)
+
+    gcur = None
+    for k in range(4, -1, -1):
+        last = first[k + 1] - 1
+        gf = layer_grad(acts[last], sd[f'lin{k}.model.1.weight'].flatten(), k)
+        gcur = gf if gcur is None else gcur + gf
+        for i in range(last, first[k] - 1, -1):
+            gcur = gcur * (acts[i][:B] > 0)
+            wt = sd[f'net.slice{L.VGG_SLICE[i]}.{L.VGG_IDX[i]}.weight']
+            gcur = F.conv2d(gcur, wt.flip(2, 3).transpose(0, 1), padding=1)
+        if k > 0:
+            gcur = pool_bwd(acts[first[k] - 1][:B], gcur)
+    grad = gcur / sd['scaling_layer.scale'] * 2
+    assert ((grad - p.grad).norm() / p.grad.norm()) < 1e-5
