@@ -1,5 +1,5 @@
 """Full-size check + timing of the native SD VAE (run on the GPU box): 512 x 512 decode / encode of a batch of views, per-class
-time split, chunk invariance, finiteness.  python tools/vae_check.py [views]"""
+time split, chunk invariance, finiteness.  python tools/vae_check.py [views] [--detail]"""
 import sys
 import time
 
@@ -9,7 +9,7 @@ sys.path.insert(0, '.')
 from mvedit_amd import synthetic as SY
 from mvedit_amd.vae import AutoencoderKLEngine, SD_VAE_CONFIG
 
-V = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+V = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 dev = torch.device('cuda')
 cfg = dict(SD_VAE_CONFIG)
 t0 = time.time()
@@ -48,3 +48,7 @@ for name, half, inp in (('decode', eng.decoder, z), ('encode', eng.encoder, x)):
         a[0] += m; a[1] += f; a[2] += 1
     for (c, lab), (m, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
         print(f'   {c:9s} {lab:34s} x{n:3d} {m:8.2f} ms  {f / max(m, 1e-9) / 1e9:7.0f} TF/s')
+    if '--detail' in sys.argv:          # every op in execution order: which conv shapes run below the class average
+        for c, lab, f, m in prof[0]:
+            if m > 0.05:
+                print(f'      {c:9s} {lab:34s} {m:7.3f} ms  {f / 1e9:9.1f} GFLOP  {f / max(m, 1e-9) / 1e9:7.0f} TF/s')
