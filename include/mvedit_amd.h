@@ -222,6 +222,11 @@ MVE_API int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* 
 MVE_API int mve_attention(int dtype, const void* d_Q, int ldq, const void* d_K, int ldk, const void* d_V, int ldv,
                           const void* d_K2, int ldk2, const void* d_V2, int ldv2, void* d_O, int ldo,
                           int B, int Lq, int Lk, int Lk2, int heads, int head_dim, float scale, void* stream);
+/* Experiment knob (no reference counterpart): 0 = the measured kernel configuration; 1 = for head_dim 40 with a single KV segment, 16
+ * query rows per wave, 64-key fills and 3-4 waves per SIMD (the d = 40 case is VALU / exp bound at 2 waves per SIMD).  Results of the
+ * two variants agree to rounding, not bitwise (the online-softmax rescale points differ).  Negative: query only.  Returns the previous
+ * value.  tools/ab_attention.py measures both on one box. */
+MVE_API int mve_attention_tune(int variant);
 
 /* GroupNorm over NHWC input (optionally the channel-concat of two tensors) with optional fused SiLU:
  *   out[B*HW][C1+C2] = act( (x - mean_g) * rstd_g * gamma + beta ), torch.nn.GroupNorm semantics.

@@ -33,8 +33,7 @@
 
 namespace {
 
-constexpr int QB = 128;      // query rows per block
-constexpr int NT = 256;
+constexpr int NT = 256;      // 4 waves; a wave owns QF fragments of 16 query rows (QF = 2: 128 query rows per block)
 
 struct AttnParams {
     const void* Q; const void* K; const void* V; const void* K2; const void* V2; void* O;
@@ -75,13 +74,16 @@ template <int KB2> __device__ __forceinline__ int v_swz2(int row, int chunk) {
     else return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <class Tag, int D, bool SEG2>
-__global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnParams p) {
+// QF, KB2X, OCC: experiment knobs (mve_attention_tune).  The defaults (2, 0, 0) are the measured configuration; QF = 1 halves the
+// per-wave state (16 query rows), KB2X overrides the keys per LDS fill, OCC the blocks per CU the register allocator targets.
+template <class Tag, int D, bool SEG2, int QF = 2, int KB2X = 0, int OCC = 0>
+__global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attention2(const AttnParams p) {
+    constexpr int QB = 64 * QF;      // query rows per block
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KS = DP / 32;
     constexpr int DC = D / 8;
     constexpr int DVF = (D + 15) / 16;
-    constexpr int KB2 = D > 64 ? 64 : 128;       // keys per LDS fill (LDS budget: 2 blocks/CU for d = 80)
+    constexpr int KB2 = KB2X ? KB2X : (D > 64 ? 64 : 128);       // keys per LDS fill (LDS budget: 2 blocks/CU for d = 80)
     constexpr int NH = KB2 / 64;                 // 64-key halves per fill
     constexpr int CPR = DP / 8;                  // 16-byte chunks per K row
     constexpr int KROW = DP * 2;                 // bytes per K row
@@ -142,10 +144,10 @@ __global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnP
         }
     }
 
-    V8 qf[2][KS];
-    const int q_base = qt * QB + wid * 32;
+    V8 qf[QF][KS];
+    const int q_base = qt * QB + wid * (16 * QF);
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < QF; ++f) {
         int q = q_base + f * 16 + l16;
         q = q < p.Lq ? q : p.Lq - 1;
         const T* row = Qp + ((size_t)b * p.Lq + q) * p.ldq + h * D;
@@ -229,25 +231,31 @@ __global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnP
         }
     };
 
-    f32x4 oacc[DVF][2];
+    f32x4 oacc[DVF][QF];
 #pragma unroll
-    for (int i = 0; i < DVF; ++i) { oacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    for (int i = 0; i < DVF; ++i)
+#pragma unroll
+        for (int f = 0; f < QF; ++f) oacc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) { m_run[f] = -INFINITY; l_run[f] = 0.f; }
 
     // one 64-key half: S^T = K Q^T, online softmax, O^T += V^T P^T.  MASKED is compiled separately so that the common
     // path carries no select instructions (the compiler if-converts a runtime test into 48 v_cndmask per half).
     auto do_half = [&](const unsigned char* Ks, const unsigned char* Vs, int hf, int key0, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        f32x4 s[4][2];
+        f32x4 s[4][QF];
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf) { s[kf][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kf][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) s[kf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
                 const V8 ka = *reinterpret_cast<const V8*>(Ks + koff[ks] + (hf * 64 + kf * 16) * KROW);
-                s[kf][0] = Tag::mfma16(ka, qf[0][ks], s[kf][0]);
-                s[kf][1] = Tag::mfma16(ka, qf[1][ks], s[kf][1]);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s[kf][f] = Tag::mfma16(ka, qf[f][ks], s[kf][f]);
             }
         }
         if constexpr (MASKED) {
@@ -255,11 +263,14 @@ __global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnP
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (key0 + kf * 16 + g * 4 + r >= Ltot) { s[kf][0][r] = -INFINITY; s[kf][1][r] = -INFINITY; }
-        }
-        V8 pf[2][2];
+                    if (key0 + kf * 16 + g * 4 + r >= Ltot) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+                        for (int f = 0; f < QF; ++f) s[kf][f][r] = -INFINITY;
+                    }
+        }
+        V8 pf[QF][2];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
             float mx = -INFINITY;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
@@ -309,8 +320,8 @@ __global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnP
 #pragma unroll
             for (int i = 0; i < DVF; ++i) {
                 const V8 va = *reinterpret_cast<const V8*>(Vs + voff[hf * 2 + kk] + i * 16 * VROW);
-                oacc[i][0] = Tag::mfma16(va, pf[0][kk], oacc[i][0]);
-                oacc[i][1] = Tag::mfma16(va, pf[1][kk], oacc[i][1]);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) oacc[i][f] = Tag::mfma16(va, pf[f][kk], oacc[i][f]);
             }
         }
     };
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnP
 
     typedef T T4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < QF; ++f) {
         float l;
         if constexpr (ONES) {
             l = __shfl(oacc[DVF - 1][f][L_R], L_G * 16 + l16, 64);    // row D of O^T is sum_j P for query l16
@@ -369,8 +380,22 @@ __global__ __launch_bounds__(NT, (D > 80 ? 1 : 2)) void k_attention2(const AttnP
     }
 }
 
+// 0: the measured configuration.  1 (d = 40 only, single KV segment): 16 query rows per wave, 64-key fills, 3 blocks per CU --
+// an experiment for the VALU-bound d = 40 case (mve_attention_tune; results are NOT bit-identical across variants: the online-softmax
+// rescale points move with the fill size).
+int g_attn_variant = 0;
+
 template <class Tag, int D>
 int launch(const AttnParams& p, hipStream_t s) {
+    if constexpr (D == 40) {
+        if (g_attn_variant == 1 && p.Lk2 == 0) {
+            const unsigned grid1 = (unsigned)(((p.Lq + 63) / 64) * p.heads * p.B);
+            k_attention2<Tag, D, false, 1, 64, 3><<<grid1, NT, 0, s>>>(p);
+            MVE_LAUNCH_CHECK();
+            return MVE_OK;
+        }
+    }
+    constexpr int QB = 128;
     const unsigned grid = (unsigned)(((p.Lq + QB - 1) / QB) * p.heads * p.B);
     if (p.Lk2 > 0) k_attention2<Tag, D, true><<<grid, NT, 0, s>>>(p);
     else k_attention2<Tag, D, false><<<grid, NT, 0, s>>>(p);
@@ -392,6 +417,12 @@ int dispatch_d(const AttnParams& p, int d, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int mve_attention_tune(int variant) {
+    const int old = g_attn_variant;
+    if (variant >= 0) g_attn_variant = variant;
+    return old;
+}
 
 extern "C" int mve_attention(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                              const void* K2, int ldk2, const void* V2, int ldv2, void* O, int ldo, int B, int Lq,

@@ -439,3 +439,31 @@ def test_gemm_256_wide_tile_matches_small_kernel(lib):
         check('gemm 256-wide', outs[0], a.float() @ w.float().t() + bias, dtype)
     finally:
         tune(old)
+
+
+@pytest.mark.gpu
+def test_attention_experimental_variant_matches_default(lib):
+    """mve_attention_tune(1): 16 query rows per wave / 64-key fills for head dim 40 (an A/B candidate, tools/ab_attention.py).  Same
+    function, different rescale points: agreement to rounding with the default and with the reference softmax."""
+    from conftest import pending_first_gpu_run  # noqa: F401  (the variant has not run on hardware yet: opt in with MVE_RUN_PENDING=1)
+    import os
+    if os.environ.get('MVE_RUN_PENDING') != '1':
+        pytest.skip('attention variant 1 not yet run on an MI355X (set MVE_RUN_PENDING=1)')
+    from mvedit_amd import ops, _lib
+    dtype = torch.float16
+    B, L, heads, d = 2, 333, 8, 40
+    qkv = rnd((B * L, 3 * heads * d), dtype, 1)
+    q, k, v = (qkv[:, i * heads * d:(i + 1) * heads * d].cuda() for i in range(3))
+    tune = _lib.raw('mve_attention_tune')
+    old = tune(-1)
+    try:
+        tune(0)
+        o0 = ops.attention(q, k, v, B, L, L, heads, d)
+        tune(1)
+        o1 = ops.attention(q, k, v, B, L, L, heads, d)
+    finally:
+        tune(old)
+    qf, kf, vf = (t.float().cpu().reshape(B, L, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(B * L, heads * d)
+    check('attention variant 1', o1, ref, dtype)
+    assert (o1.float() - o0.float()).abs().max() < 2e-3

@@ -1,0 +1,36 @@
+"""Same-box A/B of the attention kernel variants (mve_attention_tune) on the UNet's self-attention shapes; prints time, TFLOP/s and the
+difference between the variants' outputs.  python tools/ab_attention.py"""
+import sys
+
+import torch
+
+sys.path.insert(0, '.')
+from mvedit_amd import _lib, ops
+
+
+def timed(fn, it=10):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(it):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / it
+
+
+tune = _lib.raw('mve_attention_tune')
+for B, L, heads, d in ((64, 4096, 8, 40), (8, 4096, 8, 40), (64, 1024, 8, 80), (32, 8192, 8, 40)):
+    C = heads * d
+    qkv = torch.randn(B * L, 3 * C, device='cuda', dtype=torch.float16)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    outs = []
+    for variant in (0, 1):
+        tune(variant)
+        ms = timed(lambda: ops.attention(q, k, v, B, L, L, heads, d))
+        outs.append(ops.attention(q, k, v, B, L, L, heads, d))
+        fl = 4.0 * B * heads * L * L * d
+        print(f'B={B:3d} L={L:5d} d={d:3d} variant {variant}: {ms:8.3f} ms  {fl / ms / 1e9:7.0f} TFLOP/s')
+    tune(0)
+    print('      max |v1 - v0| =', (outs[1].float() - outs[0].float()).abs().max().item())

@@ -1,9 +1,15 @@
 #!/bin/bash
-# First GPU run of the tests written after round 1's GPU budget was spent (tone mapping / shading, mesh geometry gradients, LPIPS).  Each file runs in its own
-# process so that a device fault in one cannot hide the others.  ~30 s of box time.  Logs land in gpurun_out/.
+# First GPU run of the tests written after round 1's GPU budget was spent (tone mapping / shading, mesh geometry gradients, LPIPS, the
+# experimental attention variant).  Each group runs in its own process so that a device fault in one cannot hide the others.
+# ~40 s of box time.  Logs land in gpurun_out/.
 mkdir -p gpurun_out
 export MVE_RUN_PENDING=1
-for f in tests/test_tonemapping.py tests/test_mesh_grad.py tests/test_lpips.py; do
-    echo "== $f"
-    timeout 120 python -m pytest "$f" -q -m gpu -p no:cacheprovider -s 2>&1 | tail -25 | tee "gpurun_out/pending_$(basename "$f" .py).log" | grep -E "passed|failed|^E  |rel|engine|^FAILED" | head -20
-done
+run() {   # run <log name> <pytest args...>
+    local name=$1; shift
+    echo "== $name"
+    timeout 120 python -m pytest "$@" -q -m gpu -p no:cacheprovider -s 2>&1 | tail -25 | tee "gpurun_out/pending_${name}.log" | grep -E "passed|failed|^E  |rel|engine|^FAILED" | head -20
+}
+run tonemapping tests/test_tonemapping.py
+run mesh_grad tests/test_mesh_grad.py
+run lpips tests/test_lpips.py
+run attention_variant tests/test_unet_ops.py -k experimental_variant
