@@ -23,3 +23,38 @@ def test_version_and_error_plumbing(lib):
                                   ctypes.c_void_p(16), 8, 1, 4, 4, 0, 8, 48, ctypes.c_float(1.0), None)
     assert rc == -1 and 'head dim' in lib.last_error()
     assert lib.raw('mve_march_scratch_bytes')(1000) >= 4 * 4
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.build()/smoke() and bench.py's cpu_baseline leg may touch it.
+    The package and the tools never do; bench.py does so in exactly one function."""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for fn in ast.walk(tree):
+            if isinstance(fn, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in fn.names] if isinstance(fn, ast.Import) else [fn.module or '']
+                if any(n == 'oracle' or n.startswith('oracle.') for n in names):
+                    hits.append(fn.lineno)
+        return hits
+
+    for d, _, files in os.walk(os.path.join(root, 'mvedit_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                assert not oracle_imports(os.path.join(d, f)), f'{f} imports the oracle'
+    for f in os.listdir(os.path.join(root, 'tools')):
+        if f.endswith('.py'):
+            assert not oracle_imports(os.path.join(root, 'tools', f)), f'tools/{f} imports the oracle'
+    tree = ast.parse(open(os.path.join(root, 'bench.py')).read())
+    owners = {fn.name for fn in ast.walk(tree) if isinstance(fn, ast.FunctionDef)
+              for node in ast.walk(fn) if isinstance(node, ast.ImportFrom) and (node.module or '').startswith('oracle')}
+    assert owners == {'cpu_baseline'}, owners
+    # no C/HIP source of the product #includes anything from oracle/ (comments may cite oracle files)
+    import re
+    for f in os.listdir(os.path.join(root, 'mvedit_amd', 'csrc')):
+        for inc in re.findall(r'#include\s+[<"]([^>"]+)[>"]', open(os.path.join(root, 'mvedit_amd', 'csrc', f)).read()):
+            assert 'oracle' not in inc, (f, inc)
