@@ -248,6 +248,8 @@ def main():
     sd = U.make_state_dict(cfg, seed=1234, dtype=dtype)
     eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype, dev)
     del sd
+    if os.environ.get('MVE_BENCH_GRAPH') == '1':          # experiment: hipGraph replay of the forward (off by default)
+        eng.enable_graph(True)
     g = torch.Generator().manual_seed(0)
     latents_all = torch.randn(V, 4, LATENT, LATENT, generator=g)
     ctx_uncond = torch.randn(1, CTX_LEN, cfg['cross_attention_dim'], generator=g)

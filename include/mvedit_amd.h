@@ -411,6 +411,12 @@ MVE_API int mve_pixel_shuffle_add(int io_dtype, const float* d_src, int ld, cons
 /* Tuning knob for engines created AFTER the call: 1 (default) folds every ResnetBlock2D conv_shortcut into conv2's K loop
  * (mve_conv3x3_shortcut), 0 keeps the separate 1x1 GEMMs; negative only queries.  Returns the previous setting. */
 MVE_API int mve_unet_tune(int fuse_shortcut);
+/* Opt-in hipGraph replay of mve_unet_forward (no reference counterpart; the reference launches every kernel eagerly): a forward whose
+ * plan and every pointer argument (sample, timesteps, context, output, workspace, residuals, stream) equal those of an earlier call is
+ * captured into a graph on its second sighting and replayed afterwards -- for launch-bound small-batch forwards (8 images per rank at
+ * 8 GPUs).  Calls with op_ms (profiling) always run eagerly.  enable < 0 only queries; disabling frees the cached graphs.  Returns
+ * the previous setting.  Off by default. */
+MVE_API int mve_unet_graph(void* handle, int enable);
 
 /* Attention-processor options of the reference, applied to every later plan/forward of this engine:
  *   ip_tokens > 0 : IPAttnProcessor2_0 (lib/models/architecture/ip_adapter/attention_processor.py:301-396) -- the last ip_tokens rows of

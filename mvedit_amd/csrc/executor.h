@@ -182,6 +182,7 @@ struct Plan {
     AttnOpts ao;
     size_t ref_store_bytes = 0;
     unsigned long long last_use = 0;
+    unsigned long long uid = 0;       // unique per built plan (graph cache key: plan objects are recycled by the LRU)
     std::vector<Op> ops;
     size_t enc_end = 0;        // ops[0, enc_end) = unet_enc
     size_t ws_bytes = 0;
@@ -247,6 +248,19 @@ struct Unet {
     bool fuse_sc = false;                       // conv_shortcut folded into conv2's K loop (all widths multiples of 64)
     std::map<std::string, int> sc_cin;          // resnet prefix -> input width, for resnets with a shortcut
     std::string err;
+    // optional hipGraph replay of mve_unet_forward (mve_unet_graph): a call whose plan AND every pointer argument equal an earlier
+    // call's is captured on its second sighting and replayed from then on (launch-bound small-batch forwards, e.g. 8 images per rank)
+    struct GraphEntry {
+        unsigned long long plan_uid = 0;
+        int phase = 0, seen = 0;
+        std::vector<const void*> ptrs;          // sample, timesteps, ctx, out, workspace, mid residual, ref store, stream, down residuals...
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        unsigned long long last_use = 0;
+    };
+    bool graph_mode = false;
+    std::vector<GraphEntry> graphs;
+    unsigned long long plan_counter = 0;
 };
 
 int esz(int dtype) { return dtype == MVE_F32 ? 4 : 2; }

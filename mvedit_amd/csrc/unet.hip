@@ -46,6 +46,7 @@ int ensure_plan(Unet& u, int B, int H, int W, int n_img, int has_res, int io_dty
     if (rc != MVE_OK) return rc;
     np->ctx_len = ctx_len;
     np->last_use = u.tick;
+    np->uid = ++u.plan_counter;
     if (u.plans.size() >= 8) {
         size_t lru = 0;
         for (size_t i = 1; i < u.plans.size(); ++i)
@@ -349,6 +350,7 @@ int mve_unet_tune(int fuse_shortcut) {
 int mve_unet_destroy(void* handle) {
     if (!handle) return MVE_OK;
     Unet* u = (Unet*)handle;
+    for (auto& g : u->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
     if (u->slab) (void)hipFree(u->slab);
     delete u;
     return MVE_OK;
@@ -434,6 +436,42 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
               "unet_forward: reference store %zu < required %zu bytes", u->ref_store_bytes, pl.ref_store_bytes);
     r.stream = (hipStream_t)stream;
     const size_t lo = phase == 2 ? pl.enc_end : 0, hi = phase == 1 ? pl.enc_end : pl.ops.size();
+    if (u->graph_mode && !op_ms) {
+        // hipGraph replay (opt-in): identical plan + pointers as an earlier call -> capture on the second sighting, replay afterwards
+        std::vector<const void*> key = {d_sample, d_timesteps, d_ctx, d_out, d_workspace, d_mid_residual, u->ref_store, stream};
+        if (has_res) for (int i = 0; i < u->cfg.n_levels * (u->cfg.layers_per_block + 1); ++i) key.push_back(down_residuals[i]);
+        Unet::GraphEntry* ge = nullptr;
+        for (auto& g : u->graphs)
+            if (g.plan_uid == pl.uid && g.phase == phase && g.ptrs == key) { ge = &g; break; }
+        if (ge && ge->exec) {
+            ge->last_use = u->tick;
+            MVE_HIP(hipGraphLaunch(ge->exec, r.stream));
+            return MVE_OK;
+        }
+        if (ge) {           // second sighting: capture, instantiate, launch
+            MVE_HIP(hipStreamBeginCapture(r.stream, hipStreamCaptureModeRelaxed));
+            for (size_t i = lo; i < hi && rc == MVE_OK; ++i) rc = pl.ops[i].fn(r);
+            hipGraph_t graph = nullptr;
+            const hipError_t ce = hipStreamEndCapture(r.stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            MVE_HIP(ce);
+            MVE_HIP(hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0));
+            ge->graph = graph;
+            ge->last_use = u->tick;
+            MVE_HIP(hipGraphLaunch(ge->exec, r.stream));
+            return MVE_OK;
+        }
+        if (u->graphs.size() >= 8) {          // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < u->graphs.size(); ++i) if (u->graphs[i].last_use < u->graphs[lru].last_use) lru = i;
+            if (u->graphs[lru].exec) (void)hipGraphExecDestroy(u->graphs[lru].exec);
+            if (u->graphs[lru].graph) (void)hipGraphDestroy(u->graphs[lru].graph);
+            u->graphs.erase(u->graphs.begin() + lru);
+        }
+        Unet::GraphEntry ne;
+        ne.plan_uid = pl.uid; ne.phase = phase; ne.seen = 1; ne.ptrs = key; ne.last_use = u->tick;
+        u->graphs.push_back(ne);          // first sighting: run eagerly below (also performs any one-time kernel attribute set-up)
+    }
     std::vector<hipEvent_t> ev;
     if (op_ms) {
         ev.resize(hi - lo + 1);
@@ -451,6 +489,20 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return MVE_OK;
+}
+
+int mve_unet_graph(void* handle, int enable) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "unet_graph: null handle");
+    Unet* u = (Unet*)handle;
+    const int old = u->graph_mode ? 1 : 0;
+    if (enable >= 0) {
+        u->graph_mode = enable != 0;
+        if (!u->graph_mode) {
+            for (auto& g : u->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+            u->graphs.clear();
+        }
+    }
+    return old;
 }
 
 int mve_unet_set_attention(void* handle, int ip_tokens, float ip_scale, int ref_mode, int ref_H, int ref_W, int ref_skip,

@@ -73,6 +73,10 @@ class UNet2DConditionEngine:
                 pass
             self._h = None
 
+    def enable_graph(self, flag=True):
+        """Opt-in hipGraph replay of forwards whose plan and tensors (addresses) repeat -- for launch-bound small batches (mve_unet_graph)."""
+        return bool(_lib.raw('mve_unet_graph')(self._h, int(bool(flag))))
+
     # ------------------------------------------------------------------ weights
     @classmethod
     def from_state_dict(cls, state_dict, config=None, dtype=torch.float16, device='cuda'):
