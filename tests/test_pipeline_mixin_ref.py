@@ -29,3 +29,29 @@ def test_get_noise_pred_equals_reference_output(name, fuse):
     with torch.no_grad():
         out = Pipe(fuse).get_noise_pred(**kw)
     np.testing.assert_allclose(out.numpy(), G[name], rtol=1e-5, atol=1e-6)
+
+
+class Pipe2(Adapter3DMixin):
+    def __init__(self, fuse, n_nets):
+        self.unet, self.fuse_chunks = object(), fuse
+        self.controlnet = stubs.StubMulti([stubs.StubNet(k) for k in range(n_nets)])
+        self.negative_prompt_embeds = torch.linspace(-1, 1, 7 * 16).view(1, 7, 16)
+
+
+@pytest.mark.parametrize('fuse', [False, True])
+@pytest.mark.parametrize('name', ['plain', 'paired', 'reference_attention_no_depth'])
+def test_two_pass_equals_reference_output(monkeypatch, name, fuse):
+    """get_noise_pred_p1 / _p2 (lib/pipelines/adapter3d_mixin.py:137-317): which ControlNets run in which pass, the cached encoder state,
+    the residual sums of pass 2, reference attention through cond_noisy_latent_batches, ctrl_text_embedding=False, adapter_scale --
+    against the reference's own two methods executed over the same stand-ins (unet_enc / unet_dec / MultiControlNetModel replaced alike
+    on both sides)."""
+    import mvedit_amd.pipelines.adapter3d_mixin as M
+    monkeypatch.setattr(M, 'unet_enc', stubs.stub_unet_enc)
+    monkeypatch.setattr(M, 'unet_dec', stubs.stub_unet_dec)
+    kw = stubs.cases_2pass()[name]
+    pipe = Pipe2(fuse, 2 + len(kw['p1'].get('extra_control_batches') or []))
+    with torch.no_grad():
+        noise1, dec_args, dec_kwargs = pipe.get_noise_pred_p1(**kw['p1'])
+        noise2 = pipe.get_noise_pred_p2(dec_args=dec_args, dec_kwargs=dec_kwargs, **kw['p2'])
+    np.testing.assert_allclose(noise1.numpy(), G[f'2pass_{name}_p1'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(noise2.numpy(), G[f'2pass_{name}_p2'], rtol=1e-5, atol=1e-6)
