@@ -113,6 +113,35 @@ def main():
     out['train_weights'] = res['weights'].numpy()
     out['train_weights_sum'], out['train_depth'], out['train_image'] = (res[k][0].numpy() for k in ('weights_sum', 'depth', 'image'))
     out['train_rays'], out['train_ts'] = res['rays'][0].numpy(), res['ts'][0].numpy()
+    # BaseNeRF.render (lib/models/autoencoders/base_nerf.py:489-556) with cfg = dict(return_rgba, compute_normal), calling the forward
+    # above as its decoder and the reference's own geometry helpers (lib/core/utils/geometry_utils.py)
+    gns = dict(torch=torch, F=F, np=np)
+    for name in ('get_ray_directions', 'get_rays', 'depth_to_normal'):
+        _fn(os.path.join(REF, 'lib/core/utils/geometry_utils.py'), name, gns)
+    rns = dict(torch=torch, get_ray_directions=gns['get_ray_directions'], get_rays=gns['get_rays'], depth_to_normal=gns['depth_to_normal'])
+    render = _fn(os.path.join(REF, 'lib/models/autoencoders/base_nerf.py'), 'render', rns, cls='BaseNeRF')
+
+    class Decoder(Renderer):
+        def train(self, mode=True):
+            self.training = mode
+
+        def __call__(self, *a, **k):
+            return forward(self, *a, **k)
+
+    class NeRF:
+        bg_color, grid_size = 1.0, G
+    S, b = 16, 2
+    f = S / (2 * np.tan(np.radians(20)))
+    intr = torch.tensor([[f, 1.05 * f, S / 2 + 0.3, S / 2 - 0.2], [0.9 * f, f, S / 2, S / 2]], dtype=torch.float32)
+    poses = torch.eye(4)[None, :3].repeat(b, 1, 1)
+    poses[0, :, 3] = torch.tensor([0.1, -0.05, -2.2])
+    c, sn = np.cos(0.6), np.sin(0.6)
+    poses[1, :, :3] = torch.tensor([[c, 0, sn], [0, 1, 0], [-sn, 0, c]], dtype=torch.float32)
+    poses[1, :, 3] = torch.tensor([-2.2 * sn, 0.0, -2.2 * c])
+    rgba, depth, normal, normal_fg = render(NeRF(), Decoder(), [None], t(bits)[None], S, S, intr[None], poses[None],
+                                            cfg=dict(return_rgba=True, compute_normal=True, dt_gamma_scale=0.5))
+    out.update(render_intrinsics=intr.numpy(), render_poses=poses.numpy(), render_rgba=rgba[0].numpy(), render_depth=depth[0].numpy(),
+               render_normal=normal[0].numpy(), render_normal_fg=normal_fg[0].numpy())
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, os.path.getsize(OUT), {k: (v.shape, float(np.abs(v).mean())) for k, v in out.items()})
 

@@ -39,3 +39,24 @@ def test_train_branch_restatement_equals_reference_output():
     assert r['weights'].shape[0] > 500 and r['weights'].shape[0] == G['train_weights'].shape[0]
     for k in ('weights', 'weights_sum', 'depth', 'image', 'rays', 'ts'):
         assert np.array_equal(r[k], G[f'train_{k}']), k
+
+
+def test_nerf_render_restatement_equals_reference_output():
+    """oracle/nerf_oracle.py: nerf_render (rays from intrinsics / poses, dt_gamma from the focal lengths, 1/r -> 1/z depth, normals from
+    the foreground depth, background blend) against the reference's `BaseNeRF.render` executed over its own geometry helpers and the
+    forward above."""
+    params, bits, grid, _, _ = _scene()
+    rgba, depth, normal, normal_fg = N.nerf_render(params, bits, grid, 16, 16, G['render_intrinsics'], G['render_poses'], dt_gamma_scale=0.5,
+                                                   max_steps=256)
+    assert (rgba[..., 3] > 0.5).sum() > 30
+    np.testing.assert_allclose(rgba, G['render_rgba'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(depth, G['render_depth'], rtol=1e-5, atol=1e-6)
+    # normal_fg divides the depth by max(alpha, 1e-6): where alpha ~ 0 it amplifies last-place differences of the depth a million times and
+    # is multiplied by alpha again in `normal`; compare it on the foreground only
+    fg = (G['render_rgba'][..., 3] > 1e-3)
+    for yy in (-1, 0, 1):          # ... whose 4-neighbourhood (the finite-difference stencil of depth_to_normal) is foreground as well
+        for xx in (-1, 0, 1):
+            fg &= np.roll(G['render_rgba'][..., 3] > 1e-3, (yy, xx), axis=(1, 2))
+    assert fg.sum() > 30
+    np.testing.assert_allclose(normal_fg[fg], G['render_normal_fg'][fg], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(normal, G['render_normal'], rtol=1e-4, atol=2e-5)
