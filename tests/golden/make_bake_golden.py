@@ -59,6 +59,8 @@ def dr_module():
         return rast, torch.zeros_like(rast)
 
     def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+        if attr.dim() == 2:                 # [V, A]: shared by all views
+            attr = attr[None]
         out = torch.from_numpy(np.asarray(RO.interpolate(attr.detach().numpy(), rast.numpy(), tri.numpy())))
         return out, torch.zeros(*out.shape[:-1], 2 * out.shape[-1])
 
