@@ -33,6 +33,11 @@ def _fn(path, name, ns, cls=None):
     return ns[name]
 
 
+def density_fn(x):
+    """analytic stand-in for the decoder's density (same on both sides of the comparison)"""
+    return 40.0 * torch.exp(-8.0 * (x * x).sum(-1)) * (1.0 + 0.3 * torch.sin(9.0 * x[..., 0]))
+
+
 def scene(S=20, G=32, seed=3):
     params = N.make_nerf_params(seed=seed, table_scale=0.5)           # a table large enough for visible structure
     grid = sphere_density_grid(G, radius=0.6)
@@ -142,6 +147,31 @@ def main():
                                             cfg=dict(return_rgba=True, compute_normal=True, dt_gamma_scale=0.5))
     out.update(render_intrinsics=intr.numpy(), render_poses=poses.numpy(), render_rgba=rgba[0].numpy(), render_depth=depth[0].numpy(),
                render_normal=normal[0].numpy(), render_normal_fg=normal_fg[0].numpy())
+    # update_extra_state (:105-177): full refresh (iter_density < 16) of the density grid + bitfield, one scene.
+    # Random draws come from torch's CPU generator after manual_seed, in the method's own order; tests/test_nerf_ref.py replays them.
+    def packbits(grid, thresh, bitfield=None):
+        res = t(ORM.packbits(grid.numpy(), float(thresh)))
+        if bitfield is not None:
+            bitfield.view(-1)[:] = res
+            return bitfield
+        return res
+    uns = dict(torch=torch, get_module_device=lambda m: torch.device('cpu'), custom_meshgrid=lambda *a: torch.meshgrid(*a, indexing='ij'),
+               morton3D=lambda c: t(ORM.morton3D(c.numpy())), morton3D_invert=lambda i: t(ORM.morton3D_invert(i.int().numpy())), packbits=packbits)
+    update = _fn(os.path.join(REF, 'lib/models/decoders/base_volume_renderer.py'), 'update_extra_state', uns, cls='VolumeRenderer')
+
+    class GridRenderer(Renderer):
+        def point_density_decode(self, xyzs, code):
+            x = xyzs.reshape(-1, 3)
+            return density_fn(x), [x.shape[0]]
+    H = 16
+    # (only the full refresh: the pipelines always pass iter_density = 0 -- mvedit_3d_pipeline.py:496-510 never advances it -- and the
+    # partial branch of the method raises a shape error for one scene: its [2, N] index meets a [1, 2N] value at :163)
+    for tag, it, seed in (('full', 0, 11),):
+        grid0 = torch.zeros(1, H ** 3)
+        bitfield = torch.zeros(1, H ** 3 // 8, dtype=torch.uint8)
+        torch.manual_seed(seed)
+        update(GridRenderer(), [None], grid0, bitfield, it, density_thresh=0.01, decay=0.9, S=128)
+        out[f'grid_{tag}_after'], out[f'grid_{tag}_bits'] = grid0.numpy(), bitfield.numpy()
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, os.path.getsize(OUT), {k: (v.shape, float(np.abs(v).mean())) for k, v in out.items()})
 

@@ -60,3 +60,27 @@ def test_nerf_render_restatement_equals_reference_output():
     assert fg.sum() > 30
     np.testing.assert_allclose(normal_fg[fg], G['render_normal_fg'][fg], rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(normal, G['render_normal'], rtol=1e-4, atol=2e-5)
+
+
+def test_density_grid_refresh_equals_reference_output():
+    """oracle/nerf_oracle.py: density_grid_points / density_grid_update (+ the C oracle's packbits) against the reference's
+    `update_extra_state` executed on the CPU, full refresh -- the only branch the pipelines reach: they always pass iter_density = 0
+    (mvedit_3d_pipeline.py:496-510), and the partial branch raises a shape error for one scene (:163).  The reference's jitter is
+    replayed from torch's CPU generator (torch.rand_like over the ij-meshgrid order)."""
+    import importlib.util
+    import torch
+    from oracle import raymarching as ORM
+    spec = importlib.util.spec_from_file_location('make_vr_golden', os.path.join(HERE, 'golden', 'make_volume_renderer_golden.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    H, n_cells = 16, 16 ** 3
+    dens = lambda x: mod.density_fn(torch.from_numpy(x)).numpy()
+    # full refresh: every cell once, jitter = torch.rand_like(xyzs) over the ij-meshgrid order
+    torch.manual_seed(11)
+    g = np.arange(H)
+    coords = np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(-1, 3)
+    noise = torch.rand(n_cells, 3).numpy()
+    xyzs, idx = N.density_grid_points(coords, noise, H, 1.0)
+    grid, mean = N.density_grid_update(np.zeros(n_cells, np.float32), dens(xyzs), idx, 0.9)
+    assert np.array_equal(grid, G['grid_full_after'][0]) and (grid > 0.01).sum() > 100
+    assert np.array_equal(ORM.packbits(grid, min(float(mean), 0.01)), G['grid_full_bits'][0])
