@@ -84,3 +84,29 @@ def test_density_grid_refresh_equals_reference_output():
     grid, mean = N.density_grid_update(np.zeros(n_cells, np.float32), dens(xyzs), idx, 0.9)
     assert np.array_equal(grid, G['grid_full_after'][0]) and (grid > 0.01).sum() > 100
     assert np.array_equal(ORM.packbits(grid, min(float(mean), 0.01)), G['grid_full_bits'][0])
+
+
+def test_point_decode_composition_equals_reference_output():
+    """oracle/nerf_oracle.py: point_decode against the reference's `iNGPDecoder.point_decode` EXECUTED around the oracle's own hash-grid
+    encoder (tests/golden/decoder_ref.npz, tests/golden/make_decoder_golden.py): coordinate normalisation, MLP, density blob, truncated-exp
+    density, saturated sigmoid.  Also the clamped gradient of the reference's `_trunc_exp` and the constructor's level-scale expression."""
+    import importlib.util
+    import torch
+    D = np.load(os.path.join(HERE, 'golden', 'decoder_ref.npz'))
+    spec = importlib.util.spec_from_file_location('make_decoder_golden', os.path.join(HERE, 'golden', 'make_decoder_golden.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    params = N.make_nerf_params(seed=7, table_scale=0.5)
+    params['b1'], params['b2'] = D['b1'], D['b2']
+    sig, rgb = N.point_decode(mod.points().numpy(), params, 1.0)
+    np.testing.assert_allclose(sig, D['sigmas'], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(rgb, D['rgbs'], rtol=1e-5, atol=1e-6)
+    assert sig.std() > 0.05 and rgb.std() > 0.01 and (sig[:200] > sig[200:].mean()).mean() > 0.5     # non-degenerate; the blob raises the centre
+    # the level scale every hash-grid level derives from
+    pls = np.exp2(np.log2(320 * 1.0 / 16) / 11)
+    assert pls == float(D['per_level_scale'])
+    meta, _ = N.grid_meta(12, 16, 320, 1.0)
+    assert abs(float(meta[11][0]) - (16 * pls ** 11 - 1)) < 1e-3 and meta[0][1] == 16
+    # d sigma / d pre-activation as the training kernels use it: g * clamp(exp(x), 1e-6, 1e6)
+    pre = D['trunc_exp_pre']
+    np.testing.assert_allclose(np.clip(np.exp(pre.astype(np.float64)), 1e-6, 1e6), D['trunc_exp_grad'], rtol=1e-6)
