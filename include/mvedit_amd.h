@@ -224,7 +224,8 @@ MVE_API int mve_attention(int dtype, const void* d_Q, int ldq, const void* d_K, 
                           int B, int Lq, int Lk, int Lk2, int heads, int head_dim, float scale, void* stream);
 /* Experiment knob (no reference counterpart): 0 = the measured kernel configuration; 1 = for head_dim 40 with a single KV segment, 16
  * query rows per wave, 64-key fills and 3-4 waves per SIMD (the d = 40 case is VALU / exp bound at 2 waves per SIMD).  Results of the
- * two variants agree to rounding, not bitwise (the online-softmax rescale points differ).  Negative: query only.  Returns the previous
+ * two variants agree to rounding, not bitwise (the online-softmax rescale points differ); 2 = for head_dim 80 / 160 a K-tile chunk
+ * permutation whose fragment reads are free of LDS bank conflicts (same arithmetic: bit-identical results).  Negative: query only.  Returns the previous
  * value.  tools/ab_attention.py measures both on one box. */
 MVE_API int mve_attention_tune(int variant);
 

@@ -42,10 +42,18 @@ struct AttnParams {
     float scale_log2e;   // softmax scale * log2(e)
 };
 
-template <int DP> __device__ __forceinline__ int k_swz(int row, int chunk) {
+// chunk permutation of K row `row` (a bijection inside every group of 4 chunks, applied identically by the LDS-DMA source side and the
+// fragment reads).  DP = 64: 128-byte rows, conflict-free.  Other DP (192- / 320-byte rows): the original term (row >> 2) & 3 leaves the
+// ds_read_b128 lane groups {0-3,12-15,20-27}, ... 2-way conflicted; KSW2 uses ((row >> 3) & 1) << 1, which an exhaustive search over the
+// per-4-row tables shows to be conflict-free for both strides (an experiment behind mve_attention_tune(2) until it has run on hardware).
+template <int DP, bool KSW2> __device__ __forceinline__ int k_perm(int row, int pc) {
+    if constexpr (DP == 64) return pc ^ ((row >> 1) & 7);
+    else if constexpr (KSW2) return pc ^ (((row >> 3) & 1) << 1);
+    else return pc ^ ((row >> 2) & 3);
+}
+template <int DP, bool KSW2> __device__ __forceinline__ int k_swz(int row, int chunk) {
     // K tile: [64 keys][DP] 16-bit, DP*2 bytes per row
-    if constexpr (DP == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-    else return row * (DP * 2) + ((chunk ^ ((row >> 2) & 3)) << 4);
+    return row * (DP * 2) + (k_perm<DP, KSW2>(row, chunk) << 4);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -76,7 +84,7 @@ template <int KB2> __device__ __forceinline__ int v_swz2(int row, int chunk) {
 
 // QF, KB2X, OCC: experiment knobs (mve_attention_tune).  The defaults (2, 0, 0) are the measured configuration; QF = 1 halves the
 // per-wave state (16 query rows), KB2X overrides the keys per LDS fill, OCC the blocks per CU the register allocator targets.
-template <class Tag, int D, bool SEG2, int QF = 2, int KB2X = 0, int OCC = 0>
+template <class Tag, int D, bool SEG2, int QF = 2, int KB2X = 0, int OCC = 0, bool KSW2 = false>
 __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attention2(const AttnParams p) {
     constexpr int QB = 64 * QF;      // query rows per block
     constexpr int DP = (D + 31) / 32 * 32;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
     for (int i = 0; i < K_INSTR; ++i) {
         const int pos = (wid * K_INSTR + i) * 64 + lane;
         const int row = pos / CPR, pc = pos - row * CPR;
-        const int c = (DP == 64) ? (pc ^ ((row >> 1) & 7)) : (pc ^ ((row >> 2) & 3));
+        const int c = k_perm<DP, KSW2>(row, pc);
         kd_row[i] = row;
         kd_col[i] = c < DC ? c * 8 : -1;
     }
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
     // fragment row offsets are multiples of 16.
     int koff[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) koff[ks] = k_swz<DP>(l16, ks * 4 + g);
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = k_swz<DP, KSW2>(l16, ks * 4 + g);
     // V^T fragment (A operand) of dv fragment i, key step (hf, kk):  voff[hf*2+kk] + i*16*VROW
     int voff[NH * 2];
 #pragma unroll
@@ -380,7 +388,8 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
     }
 }
 
-// 0: the measured configuration.  1 (d = 40 only, single KV segment): 16 query rows per wave, 64-key fills, 3 blocks per CU --
+// 0: the measured configuration.  2 (d = 80 / 160, single KV segment): conflict-free K swizzle, same arithmetic (bit-identical results).
+// 1 (d = 40 only, single KV segment): 16 query rows per wave, 64-key fills, 3 blocks per CU --
 // an experiment for the VALU-bound d = 40 case (mve_attention_tune; results are NOT bit-identical across variants: the online-softmax
 // rescale points move with the fill size).
 int g_attn_variant = 0;
@@ -397,6 +406,13 @@ int launch(const AttnParams& p, hipStream_t s) {
     }
     constexpr int QB = 128;
     const unsigned grid = (unsigned)(((p.Lq + QB - 1) / QB) * p.heads * p.B);
+    if constexpr (D == 80 || D == 160) {
+        if (g_attn_variant == 2 && p.Lk2 == 0) {          // conflict-free K swizzle (see k_perm)
+            k_attention2<Tag, D, false, 2, 0, 0, true><<<grid, NT, 0, s>>>(p);
+            MVE_LAUNCH_CHECK();
+            return MVE_OK;
+        }
+    }
     if (p.Lk2 > 0) k_attention2<Tag, D, true><<<grid, NT, 0, s>>>(p);
     else k_attention2<Tag, D, false><<<grid, NT, 0, s>>>(p);
     MVE_LAUNCH_CHECK();

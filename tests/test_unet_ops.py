@@ -467,3 +467,26 @@ def test_attention_experimental_variant_matches_default(lib):
     ref = F.scaled_dot_product_attention(qf, kf, vf).transpose(1, 2).reshape(B * L, heads * d)
     check('attention variant 1', o1, ref, dtype)
     assert (o1.float() - o0.float()).abs().max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_attention_conflict_free_k_swizzle_is_bit_identical(lib):
+    """mve_attention_tune(2): the K tile of head dims 80 / 160 stored under a chunk permutation whose fragment reads have no LDS bank
+    conflicts (derived analytically from the ds_read_b128 lane groups; tools/lds_conflicts.py).  Pure data-layout change: bitwise equal."""
+    import os
+    if os.environ.get('MVE_RUN_PENDING') != '1':
+        pytest.skip('attention variant 2 not yet run on an MI355X (set MVE_RUN_PENDING=1)')
+    from mvedit_amd import ops, _lib
+    tune = _lib.raw('mve_attention_tune')
+    old = tune(-1)
+    try:
+        for heads, d, L in ((8, 80, 300), (8, 160, 150)):
+            qkv = rnd((2 * L, 3 * heads * d), torch.float16, d)
+            q, k, v = (qkv[:, i * heads * d:(i + 1) * heads * d].cuda() for i in range(3))
+            tune(0)
+            o0 = ops.attention(q, k, v, 2, L, L, heads, d)
+            tune(2)
+            o2 = ops.attention(q, k, v, 2, L, L, heads, d)
+            assert torch.equal(o0, o2), (heads, d)
+    finally:
+        tune(old)
