@@ -225,8 +225,9 @@ MVE_API int mve_attention(int dtype, const void* d_Q, int ldq, const void* d_K, 
 /* Experiment knob (no reference counterpart): 0 = the measured kernel configuration; 1 = for head_dim 40 with a single KV segment, 16
  * query rows per wave, 64-key fills and 3-4 waves per SIMD (the d = 40 case is VALU / exp bound at 2 waves per SIMD).  Results of the
  * two variants agree to rounding, not bitwise (the online-softmax rescale points differ); 2 = for head_dim 80 / 160 a K-tile chunk
- * permutation whose fragment reads are free of LDS bank conflicts (same arithmetic: bit-identical results).  Negative: query only.  Returns the previous
- * value.  tools/ab_attention.py measures both on one box. */
+ * permutation whose fragment reads are free of LDS bank conflicts (same arithmetic: bit-identical results); 4 = a V^T-tile swizzle
+ * that also spreads the transposing stores over the LDS banks (single KV segment, any head_dim; bit-identical results); 6 = 2 + 4.
+ * Negative: query only.  Returns the previous value.  tools/ab_attention.py measures them on one box. */
 MVE_API int mve_attention_tune(int variant);
 
 /* GroupNorm over NHWC input (optionally the channel-concat of two tensors) with optional fused SiLU:

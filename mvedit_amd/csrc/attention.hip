@@ -77,14 +77,18 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 __device__ __attribute__((aligned(16))) unsigned int g_attn_zero_page[4] = {0u, 0u, 0u, 0u};
 
-template <int KB2> __device__ __forceinline__ int v_swz2(int row, int chunk) {
-    if constexpr (KB2 == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);   // 256-byte rows: every row starts on bank 0
-    else return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+// V^T tile: [dv rows][KB2 keys] 16-bit.  The fragment reads (ds_read_b128) are conflict-free with the base term alone, but the transposing
+// ds_write_b32 stores of store_v are not: the 32 lanes of a store group hold 5-8 different dv chunks c = row >> 3 whose base terms
+// coincide, so they pile onto the same banks (tools/lds_conflicts.py: 5- to 10-way).  VSW2 adds a term in c that keeps the reads
+// conflict-free and cuts the stores to 2- to 4-way (an experiment behind mve_attention_tune(4) until it has run on hardware).
+template <int KB2, bool VSW2> __device__ __forceinline__ int v_swz2(int row, int chunk) {
+    if constexpr (KB2 == 128) return row * 256 + ((chunk ^ (row & 15) ^ (VSW2 ? (row >> 3) & 7 : 0)) << 4);   // 256-byte rows
+    else return row * 128 + ((chunk ^ ((row >> 1) & 7) ^ (VSW2 ? (row >> 4) & 7 : 0)) << 4);
 }
 
 // QF, KB2X, OCC: experiment knobs (mve_attention_tune).  The defaults (2, 0, 0) are the measured configuration; QF = 1 halves the
 // per-wave state (16 query rows), KB2X overrides the keys per LDS fill, OCC the blocks per CU the register allocator targets.
-template <class Tag, int D, bool SEG2, int QF = 2, int KB2X = 0, int OCC = 0, bool KSW2 = false>
+template <class Tag, int D, bool SEG2, int QF = 2, int KB2X = 0, int OCC = 0, bool KSW2 = false, bool VSW2 = false>
 __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attention2(const AttnParams p) {
     constexpr int QB = 64 * QF;      // query rows per block
     constexpr int DP = (D + 31) / 32 * 32;
@@ -196,10 +200,21 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
     int koff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) koff[ks] = k_swz<DP, KSW2>(l16, ks * 4 + g);
-    // V^T fragment (A operand) of dv fragment i, key step (hf, kk):  voff[hf*2+kk] + i*16*VROW
-    int voff[NH * 2];
+    // V^T fragment (A operand) of dv fragment i, key step (hf, kk):  voff[hf*2+kk] + i*16*VROW.  With VSW2 the swizzle term depends on
+    // the fragment too: row = 16 i + l16 changes it by the constant XOR VX(i), kept as per-(i, step) lane constants when that is cheap
+    // in registers (VTAB) and applied at the read otherwise.
+    constexpr bool VTAB = VSW2 && DVF * NH * 2 <= 12;
+    int voff[VTAB ? 1 : NH * 2], voff2[VTAB ? DVF : 1][NH * 2];
+    if constexpr (VTAB) {
 #pragma unroll
-    for (int s2 = 0; s2 < NH * 2; ++s2) voff[s2] = v_swz2<KB2>(l16, s2 * 4 + g);
+        for (int i = 0; i < DVF; ++i)
+#pragma unroll
+            for (int s2 = 0; s2 < NH * 2; ++s2) voff2[i][s2] = v_swz2<KB2, true>(i * 16 + l16, s2 * 4 + g);
+    } else {
+#pragma unroll
+        for (int s2 = 0; s2 < NH * 2; ++s2) voff[s2] = v_swz2<KB2, VSW2>(l16, s2 * 4 + g);
+    }
+    auto vx = [](int i) { return !VSW2 ? 0 : (KB2 == 128 ? ((2 * i) & 7) << 4 : (i & 7) << 4); };
 
     auto dma_k = [&](int t, int buf) {
         const int j0 = t * KB2;
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
                 const unsigned short* bb = reinterpret_cast<const unsigned short*>(&vreg[i][1]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    *reinterpret_cast<unsigned*>(Vs + v_swz2<KB2>(vt_col[i] + e, chunk) + within) = (unsigned)a[e] | ((unsigned)bb[e] << 16);
+                    *reinterpret_cast<unsigned*>(Vs + v_swz2<KB2, VSW2>(vt_col[i] + e, chunk) + within) = (unsigned)a[e] | ((unsigned)bb[e] << 16);
             }
         }
     };
@@ -327,7 +342,14 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < DVF; ++i) {
-                const V8 va = *reinterpret_cast<const V8*>(Vs + voff[hf * 2 + kk] + i * 16 * VROW);
+                V8 va;
+                if constexpr (VTAB) va = *reinterpret_cast<const V8*>(Vs + voff2[i][hf * 2 + kk]);
+                else {
+                    int a = voff[hf * 2 + kk];
+                    // volatile: left to itself the compiler keeps all DVF * NH * 2 XORed offsets live across the tile loop and spills (d = 160)
+                    if constexpr (VSW2) { if (vx(i)) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a) : "s"(vx(i))); }
+                    va = *reinterpret_cast<const V8*>(Vs + a + i * 16 * VROW);
+                }
 #pragma unroll
                 for (int f = 0; f < QF; ++f) oacc[i][f] = Tag::mfma16(va, pf[f][kk], oacc[i][f]);
             }
@@ -389,6 +411,7 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
 }
 
 // 0: the measured configuration.  2 (d = 80 / 160, single KV segment): conflict-free K swizzle, same arithmetic (bit-identical results).
+// 4 (single KV segment): V^T store swizzle VSW2, same arithmetic (bit-identical results); 6 = 2 + 4.
 // 1 (d = 40 only, single KV segment): 16 query rows per wave, 64-key fills, 3 blocks per CU --
 // an experiment for the VALU-bound d = 40 case (mve_attention_tune; results are NOT bit-identical across variants: the online-softmax
 // rescale points move with the fill size).
@@ -407,11 +430,17 @@ int launch(const AttnParams& p, hipStream_t s) {
     constexpr int QB = 128;
     const unsigned grid = (unsigned)(((p.Lq + QB - 1) / QB) * p.heads * p.B);
     if constexpr (D == 80 || D == 160) {
-        if (g_attn_variant == 2 && p.Lk2 == 0) {          // conflict-free K swizzle (see k_perm)
-            k_attention2<Tag, D, false, 2, 0, 0, true><<<grid, NT, 0, s>>>(p);
+        if ((g_attn_variant == 2 || g_attn_variant == 6) && p.Lk2 == 0) {          // conflict-free K swizzle (see k_perm)
+            if (g_attn_variant == 6) k_attention2<Tag, D, false, 2, 0, 0, true, true><<<grid, NT, 0, s>>>(p);
+            else k_attention2<Tag, D, false, 2, 0, 0, true><<<grid, NT, 0, s>>>(p);
             MVE_LAUNCH_CHECK();
             return MVE_OK;
         }
+    }
+    if ((g_attn_variant == 4 || g_attn_variant == 6) && p.Lk2 == 0) {              // V^T store swizzle (see v_swz2)
+        k_attention2<Tag, D, false, 2, 0, 0, false, true><<<grid, NT, 0, s>>>(p);
+        MVE_LAUNCH_CHECK();
+        return MVE_OK;
     }
     if (p.Lk2 > 0) k_attention2<Tag, D, true><<<grid, NT, 0, s>>>(p);
     else k_attention2<Tag, D, false><<<grid, NT, 0, s>>>(p);

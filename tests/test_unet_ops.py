@@ -490,3 +490,28 @@ def test_attention_conflict_free_k_swizzle_is_bit_identical(lib):
             assert torch.equal(o0, o2), (heads, d)
     finally:
         tune(old)
+
+
+@pytest.mark.gpu
+def test_attention_vt_store_swizzle_is_bit_identical(lib):
+    """mve_attention_tune(4) / (6): the V^T tile under a swizzle that also spreads the transposing ds_write_b32 stores over the banks
+    (tools/lds_conflicts.py: 5- to 10-way -> 2- to 4-way, reads still conflict-free).  Pure data-layout change: bitwise equal."""
+    import os
+    if os.environ.get('MVE_RUN_PENDING') != '1':
+        pytest.skip('attention variants 4 / 6 not yet run on an MI355X (set MVE_RUN_PENDING=1)')
+    from mvedit_amd import ops, _lib
+    tune = _lib.raw('mve_attention_tune')
+    old = tune(-1)
+    try:
+        for dtype in (torch.float16, torch.bfloat16):
+            for heads, d, L in ((8, 40, 333), (5, 64, 257), (8, 80, 300), (8, 160, 150)):
+                qkv = rnd((2 * L, 3 * heads * d), dtype, d)
+                q, k, v = (qkv[:, i * heads * d:(i + 1) * heads * d].cuda() for i in range(3))
+                tune(0)
+                o0 = ops.attention(q, k, v, 2, L, L, heads, d)
+                for variant in ((4,) if d in (40, 64) else (4, 6)):
+                    tune(variant)
+                    o1 = ops.attention(q, k, v, 2, L, L, heads, d)
+                    assert torch.equal(o0, o1), (dtype, heads, d, variant)
+    finally:
+        tune(old)

@@ -21,16 +21,17 @@ def timed(fn, it=10):
 
 
 tune = _lib.raw('mve_attention_tune')
-for B, L, heads, d in ((64, 4096, 8, 40), (8, 4096, 8, 40), (64, 1024, 8, 80), (32, 8192, 8, 40)):
+for B, L, heads, d in ((64, 4096, 8, 40), (8, 4096, 8, 40), (64, 1024, 8, 80), (64, 256, 8, 160), (16, 4096, 5, 64), (32, 8192, 8, 40)):
     C = heads * d
     qkv = torch.randn(B * L, 3 * C, device='cuda', dtype=torch.float16)
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     outs = []
-    for variant in ((0, 1) if d == 40 else (0, 2)):
+    variants = {40: (0, 1, 4), 64: (0, 4)}.get(d, (0, 2, 4, 6))
+    for variant in variants:
         tune(variant)
         ms = timed(lambda: ops.attention(q, k, v, B, L, L, heads, d))
         outs.append(ops.attention(q, k, v, B, L, L, heads, d))
         fl = 4.0 * B * heads * L * L * d
         print(f'B={B:3d} L={L:5d} d={d:3d} variant {variant}: {ms:8.3f} ms  {fl / ms / 1e9:7.0f} TFLOP/s')
     tune(0)
-    print('      max |variant - default| =', (outs[1].float() - outs[0].float()).abs().max().item())
+    print('      max |variant - default| =', [(v, (o.float() - outs[0].float()).abs().max().item()) for v, o in zip(variants[1:], outs[1:])])

@@ -12,4 +12,4 @@ run() {   # run <log name> <pytest args...>
 run tonemapping tests/test_tonemapping.py
 run mesh_grad tests/test_mesh_grad.py
 run lpips tests/test_lpips.py
-run attention_variant tests/test_unet_ops.py -k "experimental_variant or conflict_free"
+run attention_variant tests/test_unet_ops.py -k "experimental_variant or conflict_free or vt_store_swizzle"
