@@ -281,6 +281,40 @@ MVE_API int mve_shade_views(const float* d_rgba, const float* d_normal_fg, const
                             uint32_t pix_per_view, float ambient_light, float bg_color, const float* d_lut_x, const float* d_lut_y,
                             int steps, float* d_image, void* stream);
 
+/* Image-space loss of one NeRF optimisation iteration and its gradients: lib/pipelines/mvedit_3d_pipeline.py:542-603 (`nerf_optim`,
+ * from `out_rgbs = outputs['image']...` to `loss = loss + entropy_loss`) with depth_to_normal (lib/core/utils/geometry_utils.py:119-148),
+ * TVLoss(power=1.5) (lib/models/losses/tv_loss.py), L1LossMod (lib/models/losses/pixelwise_loss.py) and Tonemapping.lut / inverse_lut.
+ * N = P * ps * ps rays, patch-major ([P, ps, ps] flattened); everything f32, device pointers.
+ *   shaded            `not is_init or init_shaded` (:558);  lut_steps = 0 with NULL tables: `self.tonemapping is None`
+ *   pixel_loss_weight loss_weight of nerf.pixel_loss (1.2, lib/pipelines/utils.py:231); is_init selects the alpha factor 5 / 1 (:580)
+ *   patch_w [P]       cam_weights[target_cam_ids] / cam_weights_mean (`target_w`, constant over a patch, :531-532)
+ *   patch_lights [P,3] cam_lights[target_cam_ids] (:533-534)
+ *   target_n / target_depth  NULL when `use_normal` / `use_depth` is false
+ *   weights [M], ts [M,2]    per-sample outputs of composite_rays_train (entropy term, :596-603); M may be 0 */
+typedef struct MveReconLossDesc {
+    int32_t P, ps, shaded, is_init, lut_steps;
+    float ambient_light, bg_color, normal_bg[3];
+    float pixel_loss_weight, normal_reg_weight, depth_weight, entropy_weight, bg_width;
+    const float *d_lut_x, *d_lut_y;
+    const float *d_image, *d_weights_sum, *d_depth;     /* outputs['image'] [N,3], ['weights_sum'] [N], ['depth'] [N] */
+    const float *d_weights, *d_ts;
+    uint32_t M;
+    const float *d_target_dir, *d_target_rgbs, *d_target_m, *d_target_n, *d_target_depth;   /* [N,3] [N,3] [N] [N,3] [N] */
+    const float *d_patch_w, *d_patch_lights;
+} MveReconLossDesc;
+MVE_API size_t mve_recon_loss_workspace_bytes(int P, int ps, uint32_t M);
+/* losses[6] = total (`loss` at :603), pixel_rgb_loss, alphas_loss, normal_reg_loss, depth_loss, entropy_loss; out_rgbs [N,3] and
+ * out_normals [N,3] are the tensors the patch (LPIPS) losses of :611-627 consume.  The workspace keeps the normals for the backward. */
+MVE_API int mve_recon_loss_forward(const MveReconLossDesc* desc, void* d_ws, size_t ws_bytes, float* d_losses, float* d_out_rgbs,
+                                   float* d_out_normals, void* stream);
+/* Gradients of g_loss * loss + <g_out_rgbs, out_rgbs> + <g_out_normals, out_normals> (either may be NULL) w.r.t. image [N,3],
+ * weights_sum [N], depth [N] and weights [M]: what loss.backward() hands to composite_rays_train's backward.  d_g_loss: one f32 on the
+ * device (autograd's incoming gradient, read by the kernels so that the host never waits for it), NULL = 1.  Must follow a forward on
+ * the same descriptor and workspace.  Pure gathers: no atomics, bitwise reproducible. */
+MVE_API int mve_recon_loss_backward(const MveReconLossDesc* desc, void* d_ws, size_t ws_bytes, const float* d_g_out_rgbs,
+                                    const float* d_g_out_normals, const float* d_g_loss, float* d_g_image, float* d_g_weights_sum, float* d_g_depth,
+                                    float* d_g_weights, void* stream);
+
 /* =========================================================================
  * 3. UNet2DCondition executor (native runtime behind the reference's UNet seam).
  *    Replaces `self.unet(sample, t, encoder_hidden_states=..., cross_attention_kwargs=...,

@@ -33,6 +33,7 @@ EXTRA_FLAGS = {
     'raster.hip': ['-ffp-contract=off'],
     'dmtet.hip': ['-ffp-contract=off'],
     'shading.hip': ['-ffp-contract=off'],
+    'recon_loss.hip': ['-ffp-contract=off'],
 }
 
 

@@ -17,6 +17,10 @@ _lib.dc_shade_views.argtypes = [_p, _p, _p, _u, _u, _f, _f, _p, _p, _i, _p]
 for f in (_lib.dc_interpolate_backward_rast, _lib.dc_rasterize_backward, _lib.dc_antialias_backward_pos, _lib.dc_tonemap_lut, _lib.dc_shade_views):
     f.restype = None
 
+_d = ctypes.c_double
+_lib.dc_recon_loss.argtypes = [_i] * 5 + [_f, _f, _p] + [_f] * 5 + [_p] * 7 + [_i] + [_p] * 9 + [_f] + [_p] * 8
+_lib.dc_recon_loss.restype = None
+
 _c = lambda a, dt=np.float32: np.ascontiguousarray(a, dt)
 _ptr = lambda a: a.ctypes.data_as(_p) if a is not None else None
 
@@ -61,4 +65,29 @@ def shade_views(rgba, normal_fg, cam_lights, ambient, bg, lut_x=None, lut_y=None
     n = rgba.size // 4
     out = np.empty(rgba.shape[:-1] + (3,), np.float32)
     _lib.dc_shade_views(_ptr(rgba), _ptr(normal_fg), _ptr(cam_lights), b, n // b, ambient, bg, _ptr(lx), _ptr(ly), lx.size if lx is not None else 0, _ptr(out))
+    return out
+
+
+def recon_loss(image, weights_sum, depth, weights, ts, target_rgbs, target_m_blur, target_dir, patch_w, patch_lights, *, target_n=None,
+               target_depth=None, lut_x=None, lut_y=None, shaded=True, is_init=False, ambient_light=0.2, bg_color=1.0, normal_bg=(0.5, 0.5, 1.0),
+               pixel_loss_weight=1.2, normal_reg_weight=0.0, depth_weight=0.0, entropy_weight=0.0, bg_width=0.015, g_rgb_ext=None,
+               g_nrm_ext=None, gl=1.0):
+    """Host run of recon_loss_core.h in the order recon_loss.hip launches it.  Shapes as oracle/recon_loss_oracle.nerf_optim_loss;
+    ts [M, 2].  Returns dict(losses[6] = total, rgb, alpha, tv, depth, entropy; out_rgbs, out_normals, g_image, g_weights_sum, g_depth, g_weights)."""
+    P, ps = target_rgbs.shape[:2]
+    N = P * ps * ps
+    f = lambda a: None if a is None else _c(a)
+    image, alpha, depth, weights, ts = _c(image), _c(weights_sum), _c(depth), _c(weights), _c(ts)
+    arrs = [f(target_dir), f(target_rgbs), f(target_m_blur), f(target_n), f(target_depth), f(patch_w), f(patch_lights), f(g_rgb_ext), f(g_nrm_ext)]
+    lx, ly = f(lut_x), f(lut_y)
+    nbg = _c(normal_bg)
+    ws = np.zeros(20 * N, np.float32)
+    losses = np.zeros(6, np.float64)
+    out = dict(out_rgbs=np.zeros((P, ps, ps, 3), np.float32), out_normals=np.zeros((P, ps, ps, 3), np.float32), g_image=np.zeros((N, 3), np.float32),
+               g_weights_sum=np.zeros(N, np.float32), g_depth=np.zeros(N, np.float32), g_weights=np.zeros(weights.size, np.float32))
+    _lib.dc_recon_loss(P, ps, int(shaded), int(is_init), 0 if lx is None else lx.size, ambient_light, bg_color, _ptr(nbg), pixel_loss_weight,
+                       normal_reg_weight, depth_weight, entropy_weight, bg_width, _ptr(lx), _ptr(ly), _ptr(image), _ptr(alpha), _ptr(depth),
+                       _ptr(weights), _ptr(ts), weights.size, *[_ptr(a) for a in arrs], gl, _ptr(ws), losses.ctypes.data_as(_p),
+                       *[_ptr(out[k]) for k in ('out_rgbs', 'out_normals', 'g_image', 'g_weights_sum', 'g_depth', 'g_weights')])
+    out['losses'] = losses
     return out

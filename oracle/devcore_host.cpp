@@ -7,6 +7,7 @@
 
 #include "../mvedit_amd/csrc/raster_grad_core.h"
 #include "../mvedit_amd/csrc/shading_core.h"
+#include "../mvedit_amd/csrc/recon_loss_core.h"
 
 extern "C" {
 
@@ -46,6 +47,39 @@ void dc_shade_views(const float* rgba, const float* normal_fg, const float* ligh
                     const float* lut_x, const float* lut_y, int steps, float* image) {
     for (size_t i = 0; i < (size_t)n_views * pix; ++i)
         sh_shade_pixel(rgba + i * 4, normal_fg + i * 3, lights + 3 * (i / pix), ambient, bg, lut_x, lut_y, lut_x ? steps : 0, image + i * 3);
+}
+
+// The whole image-space loss of one NeRF optimisation iteration, forward and backward, as recon_loss.hip sequences it: xyz pass, pixel
+// pass, TV pass, entropy pass; then pixel backward, depth backward, entropy backward.  losses[6] = total, rgb, alpha, tv, depth, entropy
+// (summed in double here; the device reduces per block in float).  ws: 3N (xyz) + 3N (nfg) + N (wfg) + N (g_alpha_part) + 12N (gdir) floats.
+void dc_recon_loss(int P, int ps, int shaded, int is_init, int lut_n, float ambient, float bg, const float* normal_bg, float pixel_loss_weight,
+                   float normal_reg_weight, float depth_weight, float entropy_weight, float bg_width, const float* lut_x, const float* lut_y,
+                   const float* image, const float* alpha, const float* depth, const float* weights, const float* ts, int M, const float* dir,
+                   const float* tgt_rgb, const float* tgt_m, const float* tgt_n, const float* tgt_depth, const float* patch_w,
+                   const float* patch_light, const float* g_rgb_ext, const float* g_nrm_ext, float gl, float* ws, double* losses,
+                   float* out_rgbs, float* out_normals, float* g_image, float* g_alpha, float* g_depth, float* g_weights) {
+    const RlParams q = rl_make_params(P, ps, shaded, is_init, lut_n, ambient, bg, normal_bg, pixel_loss_weight, normal_reg_weight, depth_weight,
+                                      entropy_weight, bg_width);
+    const int N = P * ps * ps;
+    float *xyz = ws, *nfg = ws + 3 * (size_t)N, *wfg = ws + 6 * (size_t)N, *gap = ws + 7 * (size_t)N, *gdir = ws + 8 * (size_t)N;
+    double sums[5] = {0, 0, 0, 0, 0};
+    for (int p = 0; p < N; ++p) rl_st(xyz, p, rl_xyz(depth, alpha, dir, p));
+    for (int p = 0; p < N; ++p) {
+        float part[4];
+        rl_pixel_fwd(q, lut_x, lut_y, xyz, image, alpha, depth, dir, tgt_rgb, tgt_m, tgt_depth, patch_w, patch_light, p, nfg, wfg, out_rgbs,
+                     out_normals, part);
+        sums[0] += part[0]; sums[1] += part[1]; sums[3] += part[2]; sums[4] += part[3];
+    }
+    if (q.c_tv != 0.f)
+        for (int p = 0; p < N; ++p)
+            sums[2] += q.c_tv * rl_tv_term(nfg, wfg, tgt_n, ps, p / (ps * ps), (p / ps) % ps, p % ps, nullptr, nullptr, nullptr, nullptr);
+    for (int i = 0; i < M; ++i) sums[4] += rl_entropy_sample(q, weights[i], ts[2 * i + 1], gl, g_weights + i);
+    losses[0] = sums[0] + sums[1] + sums[2] + sums[3] + sums[4];
+    for (int k = 0; k < 5; ++k) losses[1 + k] = sums[k];
+    for (int p = 0; p < N; ++p)
+        rl_pixel_bwd(q, lut_x, lut_y, xyz, nfg, wfg, image, alpha, tgt_rgb, tgt_m, tgt_n, patch_w, patch_light, g_rgb_ext, g_nrm_ext, gl, p, g_image,
+                     gap, gdir);
+    for (int p = 0; p < N; ++p) rl_depth_bwd(q, gdir, gap, alpha, depth, dir, tgt_depth, patch_w, gl, p, g_alpha, g_depth);
 }
 
 }  // extern "C"

@@ -80,3 +80,27 @@ def test_render_and_mesh_argument_checks(L):
     _bad(lib, 'mve_antialias_backward_pos', p, p, 1, 4, 4, 3, p, p, 8, p, 4, None, p, None, match='null')
     _bad(lib, 'mve_lpips_layer', 1, p, p, 2, 16, 60, 0, p, p, None, match='bad arguments')
     assert lib.call('mve_maxpool2x2', 1, p, 0, 8, 8, 64, p, None) == 0          # empty batch: a no-op, not an error
+
+
+def test_recon_loss_descriptor_checks(L):
+    lib, p, _ = L
+    from mvedit_amd.recon_loss import _Desc
+    raw = lib.raw('mve_recon_loss_workspace_bytes')
+    assert raw(0, 128, 0) == 0 and raw(8, 128, 1000) == 4 * (20 * 8 * 128 * 128 + 5 * (2 * 512 + 4))
+
+    def desc(**kw):
+        d = _Desc(P=2, ps=8, shaded=1, is_init=0, lut_steps=0, ambient_light=0.2, bg_color=1.0, pixel_loss_weight=1.2, bg_width=0.015, M=0)
+        for f in ('d_image', 'd_weights_sum', 'd_depth', 'd_target_dir', 'd_target_rgbs', 'd_target_m', 'd_patch_w', 'd_patch_lights'):
+            setattr(d, f, p.value)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    fwd = lambda d, ws=1 << 20: ('mve_recon_loss_forward', ctypes.byref(d), p, ws, p, p, p, None)
+    _bad(lib, *fwd(desc(ps=1)), match='patch geometry')
+    _bad(lib, *fwd(desc(d_depth=None)), match='null pointer')
+    _bad(lib, *fwd(desc(M=5)), match='no weights')
+    _bad(lib, *fwd(desc(lut_steps=16)), match='tone-mapping table')
+    _bad(lib, *fwd(desc(bg_width=0.0)), match='bg_width')
+    _bad(lib, *fwd(desc(), ws=64), match='workspace')
+    _bad(lib, 'mve_recon_loss_backward', ctypes.byref(desc()), p, 64, None, None, None, p, p, p, p, None, match='workspace')
+    _bad(lib, 'mve_recon_loss_backward', ctypes.byref(desc()), p, 1 << 20, None, None, None, None, p, p, p, None, match='null output')
