@@ -315,6 +315,21 @@ MVE_API int mve_recon_loss_backward(const MveReconLossDesc* desc, void* d_ws, si
                                     const float* d_g_out_normals, const float* d_g_loss, float* d_g_image, float* d_g_weights_sum, float* d_g_depth,
                                     float* d_g_weights, void* stream);
 
+/* Mesh regularisers of the mesh-optimisation loop and their gradients: laplacian_smooth_loss(verts, faces) and
+ * normal_consistency(face_normals, faces) of lib/models/decoders/mesh_renderer/base_mesh_renderer.py:55-101 (with
+ * compute_edge_to_face_mapping :20-52 and laplacian_uniform :71-91), called per iteration at lib/pipelines/mvedit_3d_pipeline.py:775-776.
+ * verts [V,3] f32, faces [F,3] i32 (indices in [0, V)), face_normals [F,3] f32.  losses[0] = mean_i |(D - A) v|_i over the V vertices
+ * (A: distinct neighbours); losses[1] = mean over the unique edges of |1 - clamp(n_t0 . n_t1, -1, 1)| with t0 / t1 the faces listing
+ * the edge as (min, max) / (max, min), face 0 where a side is missing (the reference's default).  The workspace carries the per-vertex
+ * edge buckets from the forward to the backward. */
+MVE_API size_t mve_mesh_reg_workspace_bytes(int V, int F);
+MVE_API int mve_mesh_reg_forward(const float* d_verts, int V, const int32_t* d_faces, int F, const float* d_face_normals, void* d_ws,
+                                 size_t ws_bytes, float* d_losses, void* stream);
+/* g_losses: two f32 on the device (autograd's incoming gradients of the two losses), NULL = (1, 1).  g_verts [V,3] receives the Laplacian
+ * term's gradient (normal_consistency does not depend on verts directly), g_face_normals [F,3] the consistency term's. */
+MVE_API int mve_mesh_reg_backward(const float* d_verts, int V, const int32_t* d_faces, int F, const float* d_face_normals, void* d_ws,
+                                  size_t ws_bytes, const float* d_g_losses, float* d_g_verts, float* d_g_face_normals, void* stream);
+
 /* =========================================================================
  * 3. UNet2DCondition executor (native runtime behind the reference's UNet seam).
  *    Replaces `self.unet(sample, t, encoder_hidden_states=..., cross_attention_kwargs=...,

@@ -34,6 +34,7 @@ EXTRA_FLAGS = {
     'dmtet.hip': ['-ffp-contract=off'],
     'shading.hip': ['-ffp-contract=off'],
     'recon_loss.hip': ['-ffp-contract=off'],
+    'mesh_reg.hip': ['-ffp-contract=off'],
 }
 
 

@@ -514,3 +514,54 @@ class DMTet:
             _lib.call('mve_dmtet_write', _lib.ptr(pos), _lib.ptr(sdf), _lib.ptr(tets), nv, nt, _lib.ptr(verts), _lib.ptr(faces),
                       _lib.ptr(edges), _lib.ptr(ws), nbytes, sp)
         return verts, faces, edges
+
+
+class _MeshRegFn(torch.autograd.Function):
+    """(laplacian_smooth_loss, normal_consistency) in one pass over the mesh: mve_mesh_reg_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, verts, face_normals, faces):
+        assert verts.is_cuda and faces.is_cuda and verts.dim() == 2 and verts.shape[1] == 3 and faces.dim() == 2 and faces.shape[1] == 3
+        dev = verts.device
+        v = verts.detach().to(torch.float32).contiguous()
+        fn = face_normals.detach().to(device=dev, dtype=torch.float32).contiguous()
+        f = faces.to(torch.int32).contiguous()
+        V, F = v.shape[0], f.shape[0]
+        assert fn.shape == (F, 3)
+        ws = torch.empty(_lib.raw('mve_mesh_reg_workspace_bytes')(V, F), dtype=torch.uint8, device=dev)     # carried to backward
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call('mve_mesh_reg_forward', _lib.ptr(v), V, _lib.ptr(f), F, _lib.ptr(fn), _lib.ptr(ws), ws.numel(), _lib.ptr(losses),
+                      _lib.stream_ptr(dev))
+        ctx.keep, ctx.dtypes = (v, f, fn, ws), (verts.dtype, face_normals.dtype)
+        return losses[0].clone(), losses[1].clone()
+
+    @staticmethod
+    def backward(ctx, g_lap, g_nc):
+        v, f, fn, ws = ctx.keep
+        dev = v.device
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
+        gl = torch.stack([zero if g_lap is None else g_lap.detach().float().reshape(()), zero if g_nc is None else g_nc.detach().float().reshape(())])
+        g_v, g_fn = torch.empty_like(v), torch.empty_like(fn)
+        with torch.cuda.device(dev):
+            _lib.call('mve_mesh_reg_backward', _lib.ptr(v), v.shape[0], _lib.ptr(f), f.shape[0], _lib.ptr(fn), _lib.ptr(ws), ws.numel(), _lib.ptr(gl),
+                      _lib.ptr(g_v), _lib.ptr(g_fn), _lib.stream_ptr(dev))
+        return g_v.to(ctx.dtypes[0]), g_fn.to(ctx.dtypes[1]), None
+
+
+def mesh_regularizers(verts, faces, face_normals):
+    """-> (laplacian_smooth_loss(verts, faces), normal_consistency(face_normals, faces)) of
+    lib/models/decoders/mesh_renderer/base_mesh_renderer.py:55-101 in one native pass (the pair the mesh-optimisation loop adds at
+    mvedit_3d_pipeline.py:775-776), differentiable w.r.t. verts and face_normals."""
+    return _MeshRegFn.apply(verts, face_normals, faces)
+
+
+def laplacian_smooth_loss(verts, faces):
+    """base_mesh_renderer.py:94-101"""
+    return _MeshRegFn.apply(verts, torch.zeros(faces.shape[0], 3, dtype=torch.float32, device=verts.device), faces)[0]
+
+
+def normal_consistency(face_normals, t_pos_idx, num_verts=None):
+    """base_mesh_renderer.py:55-68; num_verts saves the device read of t_pos_idx.max() when the caller knows it"""
+    V = int(t_pos_idx.max()) + 1 if num_verts is None else int(num_verts)
+    return _MeshRegFn.apply(torch.zeros(V, 3, dtype=torch.float32, device=face_normals.device), face_normals, t_pos_idx)[1]

@@ -21,6 +21,9 @@ _d = ctypes.c_double
 _lib.dc_recon_loss.argtypes = [_i] * 5 + [_f, _f, _p] + [_f] * 5 + [_p] * 7 + [_i] + [_p] * 9 + [_f] + [_p] * 8
 _lib.dc_recon_loss.restype = None
 
+_lib.dc_mesh_reg.argtypes = [_p, _i, _p, _i, _p, _f, _f, _p, _p, _p, _p]
+_lib.dc_mesh_reg.restype = None
+
 _c = lambda a, dt=np.float32: np.ascontiguousarray(a, dt)
 _ptr = lambda a: a.ctypes.data_as(_p) if a is not None else None
 
@@ -91,3 +94,14 @@ def recon_loss(image, weights_sum, depth, weights, ts, target_rgbs, target_m_blu
                        *[_ptr(out[k]) for k in ('out_rgbs', 'out_normals', 'g_image', 'g_weights_sum', 'g_depth', 'g_weights')])
     out['losses'] = losses
     return out
+
+
+def mesh_reg(verts, faces, face_normals, gl_lap=1.0, gl_nc=1.0):
+    """Host run of mesh_reg_core.h in the order mesh_reg.hip launches it -> dict(losses[2] = laplacian_smooth_loss, normal_consistency;
+    n_edges; g_verts [V, 3]; g_face_normals [F, 3])."""
+    verts, faces, face_normals = _c(verts), _c(faces, np.int32), _c(face_normals)
+    losses, ne = np.zeros(2, np.float64), ctypes.c_int(0)
+    g_v, g_fn = np.zeros_like(verts), np.zeros_like(face_normals)
+    _lib.dc_mesh_reg(_ptr(verts), verts.shape[0], _ptr(faces), faces.shape[0], _ptr(face_normals), gl_lap, gl_nc, losses.ctypes.data_as(_p),
+                     ctypes.cast(ctypes.byref(ne), _p), _ptr(g_v), _ptr(g_fn))
+    return dict(losses=losses, n_edges=ne.value, g_verts=g_v, g_face_normals=g_fn)

@@ -8,6 +8,8 @@
 #include "../mvedit_amd/csrc/raster_grad_core.h"
 #include "../mvedit_amd/csrc/shading_core.h"
 #include "../mvedit_amd/csrc/recon_loss_core.h"
+#include "../mvedit_amd/csrc/mesh_reg_core.h"
+#include <vector>
 
 extern "C" {
 
@@ -80,6 +82,39 @@ void dc_recon_loss(int P, int ps, int shaded, int is_init, int lut_n, float ambi
         rl_pixel_bwd(q, lut_x, lut_y, xyz, nfg, wfg, image, alpha, tgt_rgb, tgt_m, tgt_n, patch_w, patch_light, g_rgb_ext, g_nrm_ext, gl, p, g_image,
                      gap, gdir);
     for (int p = 0; p < N; ++p) rl_depth_bwd(q, gdir, gap, alpha, depth, dir, tgt_depth, patch_w, gl, p, g_alpha, g_depth);
+}
+
+// Both mesh regularisers, forward and backward, as mesh_reg.hip sequences them: count -> scan -> scatter the half-edges into per-vertex
+// buckets -> per-vertex sort + forward -> reduce; then the two per-vertex backward passes.  losses[2] = laplacian_smooth_loss,
+// normal_consistency; n_edges_out = E.  g_fn must come zero-initialised.
+void dc_mesh_reg(const float* verts, int V, const int32_t* faces, int F, const float* face_normals, float gl_lap, float gl_nc, double* losses,
+                 int* n_edges_out, float* g_verts, float* g_fn) {
+    std::vector<int> cnt(V, 0), base(V + 1, 0), fill(V, 0);
+    for (int t = 0; t < F; ++t)
+        for (int k = 0; k < 3; ++k) cnt[faces[3 * t + k]] += 2;
+    for (int i = 0; i < V; ++i) base[i + 1] = base[i] + cnt[i];
+    std::vector<uint64_t> bucket((size_t)6 * F);
+    for (int t = 0; t < F; ++t)
+        for (int k = 0; k < 3; ++k) {
+            const int a = faces[3 * t + k], b = faces[3 * t + (k + 1) % 3], side = a > b ? 1 : 0;
+            bucket[base[a] + fill[a]++] = mr_pack(b, t, side);
+            bucket[base[b] + fill[b]++] = mr_pack(a, t, side);
+        }
+    std::vector<float> u((size_t)3 * V);
+    double lap = 0, nc = 0;
+    long long E = 0;
+    for (int i = 0; i < V; ++i) {
+        mr_sort(bucket.data() + base[i], cnt[i]);
+        float ncs; int ne;
+        lap += mr_vertex_fwd(i, bucket.data() + base[i], cnt[i], verts, face_normals, u.data() + 3 * i, &ncs, &ne);
+        nc += ncs; E += ne;
+    }
+    losses[0] = lap / V; losses[1] = E ? nc / (double)E : 0.0;
+    *n_edges_out = (int)E;
+    for (int i = 0; i < V; ++i) {
+        mr_vertex_bwd_lap(i, bucket.data() + base[i], cnt[i], u.data(), gl_lap / (float)V, g_verts);
+        if (E) mr_vertex_bwd_nc(i, bucket.data() + base[i], cnt[i], face_normals, gl_nc / (float)E, g_fn);
+    }
 }
 
 }  // extern "C"

@@ -104,3 +104,13 @@ def test_recon_loss_descriptor_checks(L):
     _bad(lib, *fwd(desc(), ws=64), match='workspace')
     _bad(lib, 'mve_recon_loss_backward', ctypes.byref(desc()), p, 64, None, None, None, p, p, p, p, None, match='workspace')
     _bad(lib, 'mve_recon_loss_backward', ctypes.byref(desc()), p, 1 << 20, None, None, None, None, p, p, p, None, match='null output')
+
+
+def test_mesh_reg_argument_checks(L):
+    lib, p, _ = L
+    raw = lib.raw('mve_mesh_reg_workspace_bytes')
+    assert raw(0, 10) == 0 and raw(1000, 2000) >= 6 * 2000 * 8 + 3 * 1000 * 4 * 2
+    _bad(lib, 'mve_mesh_reg_forward', p, 100, p, 200, p, p, 64, p, None, match='workspace')
+    _bad(lib, 'mve_mesh_reg_forward', p, 0, p, 200, p, p, 1 << 20, p, None, match='mesh size')
+    _bad(lib, 'mve_mesh_reg_forward', p, 100, None, 200, p, p, 1 << 20, p, None, match='null pointer')
+    _bad(lib, 'mve_mesh_reg_backward', p, 100, p, 200, p, p, 1 << 20, None, None, p, None, match='null output')

@@ -14,3 +14,4 @@ run mesh_grad tests/test_mesh_grad.py
 run lpips tests/test_lpips.py
 run attention_variant tests/test_unet_ops.py -k "experimental_variant or conflict_free or vt_store_swizzle"
 run recon_loss tests/test_recon_loss.py
+run mesh_reg tests/test_mesh_reg.py
