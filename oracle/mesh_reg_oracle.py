@@ -17,8 +17,8 @@ def edge_to_face(faces):
     side = (he[:, 0] > he[:, 1]).long()
     key = torch.minimum(he[:, 0], he[:, 1]) * (int(f.max()) + 1) + torch.maximum(he[:, 0], he[:, 1])
     uniq, inv = torch.unique(key, return_inverse=True)
-    tris = torch.arange(f.shape[0]).repeat_interleave(3)
-    tpe = torch.zeros(uniq.shape[0], 2, dtype=torch.int64)
+    tris = torch.arange(f.shape[0], device=f.device).repeat_interleave(3)
+    tpe = torch.zeros(uniq.shape[0], 2, dtype=torch.int64, device=f.device)
     for s in (0, 1):
         m = side == s
         tpe[inv[m], s] = tris[m]
@@ -38,7 +38,7 @@ def laplacian_smooth_loss(verts, faces):
     V = verts.shape[0]
     ii, jj = f[:, [1, 2, 0]].flatten(), f[:, [2, 0, 1]].flatten()
     adj = torch.stack([torch.cat([ii, jj]), torch.cat([jj, ii])], dim=0).unique(dim=1)
-    A = torch.zeros(V, V, dtype=verts.dtype)
+    A = torch.zeros(V, V, dtype=verts.dtype, device=verts.device)
     A[adj[0], adj[1]] = 1.0
     L = torch.diag(A.sum(1)) - A
     return (L @ verts).norm(dim=1).mean()

@@ -63,7 +63,7 @@ def nerf_optim_loss(image, weights_sum, depth, weights, bin_width, target_rgbs, 
     `shaded` = `not is_init or init_shaded` (:558).  Returns a dict with `loss`, its parts, `out_rgbs`, `out_normals`."""
     P, ps = target_rgbs.shape[:2]
     dt = image.dtype
-    nbg = torch.as_tensor(normal_bg, dtype=dt)
+    nbg = torch.as_tensor(normal_bg, dtype=dt, device=image.device)
     out_alphas = weights_sum.reshape(P, ps, ps, 1)
     out_depth = depth.reshape(P, ps, ps) * torch.linalg.norm(target_dir, dim=-1)
     out_depth_fg = out_depth / out_alphas[..., 0].clamp(min=1e-6)

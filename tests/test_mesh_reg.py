@@ -112,3 +112,39 @@ def test_hip_large_mesh_vs_oracle(lib):
     assert abs(float(lap) - float(lap64)) < 1e-5 * float(lap64) and abs(float(nc) - float(nc64)) < 1e-5 * float(nc64) + 1e-9
     # u = deg v_i - sum v_j cancels from O(1) coordinates down to O(edge^2): fp32 leaves ~1e-4 of relative error in u / |u|
     assert rel(g_v.cpu().numpy(), gv64.numpy()) < 1e-3 and rel(g_fn.cpu().numpy(), gf64.numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_hip_timing_against_the_torch_functions_on_the_same_gpu(lib):
+    """not a parity test: prints what the two regularisers cost per iteration natively and as the reference's torch formulation
+    (two torch.unique calls + index_add / gathers, on the GPU)"""
+    import sys
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from make_mesh_reg_golden import octa_sphere
+    from mvedit_amd.mesh_ops import mesh_regularizers
+    v_np, f_np = octa_sphere(7)                                                   # 65538 vertices, 131072 faces
+    v = torch.from_numpy(v_np).float().cuda()
+    f = torch.from_numpy(f_np).cuda()
+    fn = torch.nn.functional.normalize(torch.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=-1), dim=-1)
+
+    def native():
+        vv, ff = v.clone().requires_grad_(True), fn.clone().requires_grad_(True)
+        lap, nc = mesh_regularizers(vv, f, ff)
+        (lap + nc).backward()
+
+    def torch_ops():
+        vv, ff = v.clone().requires_grad_(True), fn.clone().requires_grad_(True)
+        ii, jj = f[:, [1, 2, 0]].flatten(), f[:, [2, 0, 1]].flatten()
+        adj = torch.stack([torch.cat([ii, jj]), torch.cat([jj, ii])], dim=0).unique(dim=1)
+        lap = torch.zeros_like(vv).index_add(0, adj[0], vv[adj[0]] - vv[adj[1]]).norm(dim=1).mean()
+        (lap + M.normal_consistency(ff, f)).backward()
+    for name, fn_ in (('native', native), ('torch functions', torch_ops)):
+        fn_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn_()
+        torch.cuda.synchronize()
+        print(f'mesh regularisers fwd+bwd, 131 k faces, {name}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms')

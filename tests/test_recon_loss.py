@@ -224,3 +224,43 @@ def test_hip_full_size_iteration(lib):
     ok = well_conditioned(alpha, P, ps)
     for k, got, gd, gs in zip(LEAVES, grads, g64, g32):
         close_enough(got, gd.numpy(), gs.numpy(), 'g_' + k, None if k == 'weights' else ok)
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_hip_timing_against_the_torch_statements_on_the_same_gpu(lib):
+    """not a parity test: prints what one iteration's image-space loss costs natively and as the reference's torch statements (the
+    restatement, on the GPU) -- the number DESIGN.md section 4.8 quotes comes from here"""
+    import time
+    P, ps = 8, 128
+    g = torch.Generator().manual_seed(3)
+    N, M = P * ps * ps, 8 * P * ps * ps
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, ps), torch.linspace(-1, 1, ps), indexing='ij')
+    dirs = torch.stack([xx * 0.27, yy * 0.27, torch.ones_like(xx)], -1)[None].expand(P, -1, -1, -1).contiguous()
+    alpha = (0.05 + torch.rand(N, generator=g) * 1.1).clamp(0, 1)
+    args = [torch.rand(N, 3, generator=g) * alpha[:, None], alpha, (0.25 + 0.02 * torch.rand(N, generator=g)) * alpha, torch.rand(M, generator=g) * 0.2,
+            torch.stack([torch.rand(M, generator=g) * 3 + 1, torch.rand(M, generator=g) * 0.03 + 1e-3], -1), torch.rand(P, ps, ps, 3, generator=g),
+            torch.rand(P, ps, ps, 1, generator=g), dirs, torch.rand(P, generator=g) + 0.5, torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)]
+    kw = dict(target_n=torch.rand(P, ps, ps, 3, generator=g), target_depth=None, shaded=True, is_init=False, ambient_light=0.2, normal_reg_weight=2.0,
+              entropy_weight=1.0, bg_width=0.015)
+    from mvedit_amd.recon_loss import nerf_optim_loss
+    from mvedit_amd.tonemapping import Tonemapping
+    tm = Tonemapping(device='cuda')
+    cu = [a.cuda() for a in args]
+    kwc = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+
+    def native():
+        leaves = [a.clone().requires_grad_(True) for a in cu[:4]]
+        nerf_optim_loss(*leaves, *cu[4:], tonemapping=tm, **kwc)['loss'].backward()
+
+    def torch_ops():
+        leaves = [a.clone().requires_grad_(True) for a in cu[:4]]
+        R.nerf_optim_loss(*leaves, cu[4][:, 1], *cu[5:], lut_x=tm.lut_x, lut_y=tm.lut_y, **kwc)['loss'].backward()
+    for name, fn in (('native', native), ('torch statements', torch_ops)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        print(f'recon loss fwd+bwd, 8 x 128^2 rays, {name}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms')
