@@ -315,6 +315,28 @@ MVE_API int mve_recon_loss_backward(const MveReconLossDesc* desc, void* d_ws, si
                                     const float* d_g_out_normals, const float* d_g_loss, float* d_g_image, float* d_g_weights_sum, float* d_g_depth,
                                     float* d_g_weights, void* stream);
 
+/* The same for one MESH optimisation iteration: lib/pipelines/mvedit_3d_pipeline.py:745-782 (`mesh_optim`, from `out_alphas =
+ * render_out['rgba']...` to the regularised sum; the two mesh regularisers of that sum are mve_mesh_reg_*).  N = n * size * size pixels,
+ * view-major; rgba [N,4], normal [N,3], depth [N] = render_out['rgba' / 'normal' / 'depth'] (depth only feeds the detached cosine
+ * weighting of :751-758), target_m_erode [N] the 5x5-eroded mask (:723-724), view_w [n] = cam_weights / cam_weights_mean. */
+typedef struct MveMeshLossDesc {
+    int32_t n, size, mesh_is_simplified;
+    float normal_bg[3];
+    float pixel_loss_weight, normal_reg_weight;
+    const float *d_rgba, *d_normal, *d_depth;
+    const float *d_target_dir, *d_target_rgbs, *d_target_m_erode, *d_target_m_blur, *d_target_n;   /* [N,3] [N,3] [N] [N] [N,3] or NULL */
+    const float *d_view_w;
+} MveMeshLossDesc;
+MVE_API size_t mve_mesh_loss_workspace_bytes(int n, int size);
+/* losses[4] = pixel_rgb_loss + alphas_loss + normal_reg_loss, and the three parts (alpha / normal terms 0 when mesh_is_simplified);
+ * out_rgbs [N,3] / out_normals [N,3]: the tensors the patch losses of :784-818 cut their patches from. */
+MVE_API int mve_mesh_loss_forward(const MveMeshLossDesc* desc, void* d_ws, size_t ws_bytes, float* d_losses, float* d_out_rgbs,
+                                  float* d_out_normals, void* stream);
+/* Gradients of g_loss * loss + <g_out_rgbs, out_rgbs> + <g_out_normals, out_normals> w.r.t. rgba [N,4] and normal [N,3] (d_g_loss: one
+ * f32 on the device, NULL = 1; the ext gradients may be NULL).  One launch, pure gather. */
+MVE_API int mve_mesh_loss_backward(const MveMeshLossDesc* desc, void* d_ws, size_t ws_bytes, const float* d_g_out_rgbs,
+                                   const float* d_g_out_normals, const float* d_g_loss, float* d_g_rgba, float* d_g_normal, void* stream);
+
 /* Mesh regularisers of the mesh-optimisation loop and their gradients: laplacian_smooth_loss(verts, faces) and
  * normal_consistency(face_normals, faces) of lib/models/decoders/mesh_renderer/base_mesh_renderer.py:55-101 (with
  * compute_edge_to_face_mapping :20-52 and laplacian_uniform :71-91), called per iteration at lib/pipelines/mvedit_3d_pipeline.py:775-776.

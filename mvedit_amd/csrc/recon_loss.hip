@@ -7,6 +7,7 @@
 #include "common.h"
 
 #include "recon_loss_core.h"
+#include "mesh_loss_core.h"
 
 namespace {
 
@@ -148,6 +149,86 @@ RlParams params_of(const MveReconLossDesc* d) {
                           d->pixel_loss_weight, d->normal_reg_weight, d->depth_weight, d->entropy_weight, d->bg_width);
 }
 
+// ---- mesh_optim (mvedit_3d_pipeline.py:745-782): the same structure over whole rendered views ----------------------------------------
+struct MWs {
+    float *xyz, *craw, *cosp, *alpha, *nfg, *part;     // part[3][2 nbp]: rgb, alpha, tv
+    unsigned nbp;
+};
+
+size_t mws_floats(size_t N) { return 9 * N + (size_t)3 * 2 * mve_cdiv(N, NT); }
+
+MWs mcarve(void* ws, size_t N) {
+    MWs w;
+    float* f = static_cast<float*>(ws);
+    w.xyz = f; w.craw = f + 3 * N; w.cosp = f + 4 * N; w.alpha = f + 5 * N; w.nfg = f + 6 * N; w.part = f + 9 * N;
+    w.nbp = (unsigned)mve_cdiv(N, NT);
+    return w;
+}
+
+__global__ __launch_bounds__(NT) void k_ml_xyz(int N, const float* __restrict__ depth, const float* __restrict__ dir, float* __restrict__ xyz) {
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p < N) rl_st(xyz, p, ml_xyz(depth, dir, p));
+}
+
+__global__ __launch_bounds__(NT) void k_ml_cos(int N, int S, const float* __restrict__ xyz, const float* __restrict__ dir, float* __restrict__ craw) {
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p < N) craw[p] = ml_cos_raw(xyz, dir, S, p);
+}
+
+__global__ __launch_bounds__(NT) void k_ml_pixel(MlParams q, MveMeshLossDesc d, MWs w, float* __restrict__ out_rgbs, float* __restrict__ out_normals) {
+    __shared__ float sh[NT];
+    const int N = q.n * q.S * q.S, p = blockIdx.x * NT + threadIdx.x;
+    float part[2] = {0.f, 0.f};
+    if (p < N)
+        ml_pixel_fwd(q, w.craw, d.d_rgba, d.d_normal, d.d_target_rgbs, d.d_target_m_erode, d.d_target_m_blur, d.d_view_w, p, w.cosp, w.alpha, w.nfg,
+                     out_rgbs, out_normals, part);
+    const float s0 = block_sum(part[0], sh), s1 = block_sum(part[1], sh);
+    if (threadIdx.x == 0) { w.part[blockIdx.x] = s0; w.part[2 * w.nbp + blockIdx.x] = s1; w.part[4 * w.nbp + blockIdx.x] = 0.f; }
+}
+
+__global__ __launch_bounds__(NT) void k_ml_tv(MlParams q, const float* __restrict__ tgt_n, MWs w) {
+    __shared__ float sh[NT];
+    const int N = q.n * q.S * q.S, p = blockIdx.x * NT + threadIdx.x;
+    float v = 0.f;
+    if (p < N && q.c_tv != 0.f)
+        v = q.c_tv * rl_tv_term(w.nfg, w.alpha, tgt_n, q.S, p / (q.S * q.S), (p / q.S) % q.S, p % q.S, nullptr, nullptr, nullptr, nullptr);
+    const float s = block_sum(v, sh);
+    if (threadIdx.x == 0) { w.part[w.nbp + blockIdx.x] = 0.f; w.part[3 * w.nbp + blockIdx.x] = 0.f; w.part[5 * w.nbp + blockIdx.x] = s; }
+}
+
+// losses[0] = total, [1..3] = rgb, alpha, tv
+__global__ __launch_bounds__(NT) void k_ml_reduce(MWs w, float* __restrict__ losses) {
+    __shared__ float sh[NT];
+    float total = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        float v = 0.f;
+        for (unsigned c = threadIdx.x; c < 2 * w.nbp; c += NT) v += w.part[k * 2 * w.nbp + c];
+        const float s = block_sum(v, sh);
+        total += s;
+        if (threadIdx.x == 0) losses[1 + k] = s;
+    }
+    if (threadIdx.x == 0) losses[0] = total;
+}
+
+__global__ __launch_bounds__(NT) void k_ml_pixel_bwd(MlParams q, MveMeshLossDesc d, MWs w, const float* __restrict__ g_rgb_ext,
+                                                     const float* __restrict__ g_nrm_ext, const float* __restrict__ d_gl, float* __restrict__ g_rgba,
+                                                     float* __restrict__ g_normal) {
+    const int N = q.n * q.S * q.S, p = blockIdx.x * NT + threadIdx.x;
+    const float gl = d_gl ? *d_gl : 1.0f;
+    if (p < N)
+        ml_pixel_bwd(q, w.cosp, w.alpha, w.nfg, d.d_rgba, d.d_normal, d.d_target_rgbs, d.d_target_m_erode, d.d_target_m_blur, d.d_target_n,
+                     d.d_view_w, g_rgb_ext, g_nrm_ext, gl, p, g_rgba, g_normal);
+}
+
+int check_mdesc(const MveMeshLossDesc* d, const char* who) {
+    MVE_CHECK(d, MVE_ERR_ARG, "%s: null descriptor", who);
+    MVE_CHECK(d->n > 0 && d->size >= 2 && (long long)d->n * d->size * d->size < (1ll << 27), MVE_ERR_ARG, "%s: bad view geometry n=%d size=%d", who,
+              d->n, d->size);
+    MVE_CHECK(d->d_rgba && d->d_normal && d->d_depth && d->d_target_dir && d->d_target_rgbs && d->d_target_m_erode && d->d_target_m_blur &&
+              d->d_view_w, MVE_ERR_ARG, "%s: null pointer", who);
+    return MVE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -202,6 +283,48 @@ int mve_recon_loss_backward(const MveReconLossDesc* d, void* d_ws, size_t ws_byt
         k_rl_entropy<<<w.nbs, NT, 0, s>>>(q, d->d_weights, d->d_ts, d->M, d_g_loss, w, d_g_weights);
         MVE_LAUNCH_CHECK();
     }
+    return MVE_OK;
+}
+
+size_t mve_mesh_loss_workspace_bytes(int n, int size) {
+    if (n <= 0 || size <= 0) return 0;
+    return mws_floats((size_t)n * size * size) * sizeof(float);
+}
+
+int mve_mesh_loss_forward(const MveMeshLossDesc* d, void* d_ws, size_t ws_bytes, float* d_losses, float* d_out_rgbs, float* d_out_normals,
+                          void* stream) {
+    if (int rc = check_mdesc(d, "mesh_loss_forward")) return rc;
+    MVE_CHECK(d_ws && d_losses && d_out_rgbs && d_out_normals, MVE_ERR_ARG, "mesh_loss_forward: null output");
+    const size_t N = (size_t)d->n * d->size * d->size;
+    MVE_CHECK(ws_bytes >= mws_floats(N) * sizeof(float), MVE_ERR_ARG, "mesh_loss_forward: workspace %zu < %zu bytes", ws_bytes,
+              mws_floats(N) * sizeof(float));
+    const MlParams q = ml_make_params(d->n, d->size, d->mesh_is_simplified ? 1 : 0, d->normal_bg, d->pixel_loss_weight, d->normal_reg_weight);
+    const MWs w = mcarve(d_ws, N);
+    hipStream_t s = (hipStream_t)stream;
+    k_ml_xyz<<<w.nbp, NT, 0, s>>>((int)N, d->d_depth, d->d_target_dir, w.xyz);
+    MVE_LAUNCH_CHECK();
+    k_ml_cos<<<w.nbp, NT, 0, s>>>((int)N, d->size, w.xyz, d->d_target_dir, w.craw);
+    MVE_LAUNCH_CHECK();
+    k_ml_pixel<<<w.nbp, NT, 0, s>>>(q, *d, w, d_out_rgbs, d_out_normals);
+    MVE_LAUNCH_CHECK();
+    k_ml_tv<<<w.nbp, NT, 0, s>>>(q, d->d_target_n, w);
+    MVE_LAUNCH_CHECK();
+    k_ml_reduce<<<1, NT, 0, s>>>(w, d_losses);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_mesh_loss_backward(const MveMeshLossDesc* d, void* d_ws, size_t ws_bytes, const float* d_g_out_rgbs, const float* d_g_out_normals,
+                           const float* d_g_loss, float* d_g_rgba, float* d_g_normal, void* stream) {
+    if (int rc = check_mdesc(d, "mesh_loss_backward")) return rc;
+    MVE_CHECK(d_ws && d_g_rgba && d_g_normal, MVE_ERR_ARG, "mesh_loss_backward: null output");
+    const size_t N = (size_t)d->n * d->size * d->size;
+    MVE_CHECK(ws_bytes >= mws_floats(N) * sizeof(float), MVE_ERR_ARG, "mesh_loss_backward: workspace %zu < %zu bytes", ws_bytes,
+              mws_floats(N) * sizeof(float));
+    const MlParams q = ml_make_params(d->n, d->size, d->mesh_is_simplified ? 1 : 0, d->normal_bg, d->pixel_loss_weight, d->normal_reg_weight);
+    const MWs w = mcarve(d_ws, N);
+    k_ml_pixel_bwd<<<w.nbp, NT, 0, (hipStream_t)stream>>>(q, *d, w, d_g_out_rgbs, d_g_out_normals, d_g_loss, d_g_rgba, d_g_normal);
+    MVE_LAUNCH_CHECK();
     return MVE_OK;
 }
 

@@ -103,3 +103,66 @@ def nerf_optim_loss(image, weights_sum, depth, weights, ts, target_rgbs, target_
     res = dict(zip(PARTS, parts.unbind(0)))
     res.update(loss=loss, out_rgbs=out_rgbs, out_normals=out_normals)
     return res
+
+
+class _MeshDesc(ctypes.Structure):
+    """MveMeshLossDesc (include/mvedit_amd.h)"""
+    _fields_ = ([(n, ctypes.c_int32) for n in ('n', 'size', 'mesh_is_simplified')] + [('normal_bg', ctypes.c_float * 3)]
+                + [(n, ctypes.c_float) for n in ('pixel_loss_weight', 'normal_reg_weight')]
+                + [(n, ctypes.c_void_p) for n in ('d_rgba', 'd_normal', 'd_depth', 'd_target_dir', 'd_target_rgbs', 'd_target_m_erode', 'd_target_m_blur',
+                                                  'd_target_n', 'd_view_w')])
+
+
+class _MeshLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgba, normal, consts, hyper):
+        dev = rgba.device
+        assert rgba.is_cuda, 'native path: CUDA tensors only'
+        n, S = consts['target_rgbs'].shape[:2]
+        N = n * S * S
+        keep = dict(rgba=_f32(rgba, dev).reshape(N, 4), normal=_f32(normal, dev).reshape(N, 3), **{k: _f32(v, dev) for k, v in consts.items()})
+        assert keep['depth'].numel() == N and keep['target_dir'].numel() == 3 * N and keep['view_w'].numel() == n
+        d = _MeshDesc(n=n, size=S, mesh_is_simplified=int(hyper['simplified']), normal_bg=(ctypes.c_float * 3)(*hyper['normal_bg']),
+                      pixel_loss_weight=hyper['pixel_loss_weight'], normal_reg_weight=hyper['normal_reg_weight'])
+        for field, key in (('d_rgba', 'rgba'), ('d_normal', 'normal'), ('d_depth', 'depth'), ('d_target_dir', 'target_dir'),
+                           ('d_target_rgbs', 'target_rgbs'), ('d_target_m_erode', 'target_m_erode'), ('d_target_m_blur', 'target_m_blur'),
+                           ('d_target_n', 'target_n'), ('d_view_w', 'view_w')):
+            setattr(d, field, None if keep[key] is None else keep[key].data_ptr())
+        ws = torch.empty(_lib.raw('mve_mesh_loss_workspace_bytes')(n, S), dtype=torch.uint8, device=dev)
+        losses = torch.empty(4, dtype=torch.float32, device=dev)
+        out_rgbs = torch.empty(n, S, S, 3, dtype=torch.float32, device=dev)
+        out_normals = torch.empty(n, S, S, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call('mve_mesh_loss_forward', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.ptr(losses), _lib.ptr(out_rgbs), _lib.ptr(out_normals),
+                      _lib.stream_ptr(dev))
+        ctx.desc, ctx.keep, ctx.ws, ctx.N = d, keep, ws, N
+        ctx.in_shapes, ctx.in_dtypes = (rgba.shape, normal.shape), (rgba.dtype, normal.dtype)
+        ctx.mark_non_differentiable(losses)
+        return losses[0].clone(), out_rgbs, out_normals, losses
+
+    @staticmethod
+    def backward(ctx, g_loss, g_rgbs, g_normals, _unused):
+        dev = ctx.ws.device
+        gl, g_rgbs, g_normals = _f32(g_loss, dev), _f32(g_rgbs, dev), _f32(g_normals, dev)
+        g_rgba = torch.empty(ctx.N, 4, dtype=torch.float32, device=dev)
+        g_normal = torch.empty(ctx.N, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call('mve_mesh_loss_backward', ctypes.byref(ctx.desc), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.ptr(g_rgbs), _lib.ptr(g_normals),
+                      _lib.ptr(gl), _lib.ptr(g_rgba), _lib.ptr(g_normal), _lib.stream_ptr(dev))
+        return g_rgba.reshape(ctx.in_shapes[0]).to(ctx.in_dtypes[0]), g_normal.reshape(ctx.in_shapes[1]).to(ctx.in_dtypes[1]), None, None
+
+
+def mesh_optim_loss(rgba, normal, depth, target_rgbs, target_m_erode, target_m_blur, target_dir, view_w, *, target_n=None,
+                    mesh_is_simplified=False, normal_bg=(0.5, 0.5, 1.0), pixel_loss_weight=1.2, normal_reg_weight=0.0):
+    """Image-space part of one mesh optimisation iteration (lib/pipelines/mvedit_3d_pipeline.py:745-782): rgba [n, S, S, 4], normal
+    [n, S, S, 3], depth [n, S, S] = `render_out['rgba' / 'normal' / 'depth'].squeeze(0)`; targets [n, S, S, C]; view_w [n] = cam_weights /
+    cam_weights_mean.  -> dict(loss (= pixel_rgb_loss + alphas_loss + normal_reg_loss), the parts (detached), out_rgbs, out_normals);
+    differentiable w.r.t. rgba and normal.  The mesh regularisers of the same sum are `mesh_ops.mesh_regularizers`."""
+    consts = dict(depth=depth, target_rgbs=target_rgbs, target_m_erode=target_m_erode, target_m_blur=target_m_blur, target_dir=target_dir,
+                  target_n=target_n, view_w=view_w)
+    hyper = dict(simplified=bool(mesh_is_simplified), normal_bg=tuple(float(v) for v in normal_bg), pixel_loss_weight=float(pixel_loss_weight),
+                 normal_reg_weight=float(normal_reg_weight))
+    loss, out_rgbs, out_normals, parts = _MeshLossFn.apply(rgba, normal, consts, hyper)
+    res = dict(zip(('loss', 'pixel_rgb_loss', 'alphas_loss', 'normal_reg_loss'), parts.unbind(0)))
+    res.update(loss=loss, out_rgbs=out_rgbs, out_normals=out_normals)
+    return res

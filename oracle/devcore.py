@@ -21,6 +21,8 @@ _d = ctypes.c_double
 _lib.dc_recon_loss.argtypes = [_i] * 5 + [_f, _f, _p] + [_f] * 5 + [_p] * 7 + [_i] + [_p] * 9 + [_f] + [_p] * 8
 _lib.dc_recon_loss.restype = None
 
+_lib.dc_mesh_loss.argtypes = [_i, _i, _i, _p, _f, _f] + [_p] * 11 + [_f] + [_p] * 6
+_lib.dc_mesh_loss.restype = None
 _lib.dc_mesh_reg.argtypes = [_p, _i, _p, _i, _p, _f, _f, _p, _p, _p, _p]
 _lib.dc_mesh_reg.restype = None
 
@@ -105,3 +107,23 @@ def mesh_reg(verts, faces, face_normals, gl_lap=1.0, gl_nc=1.0):
     _lib.dc_mesh_reg(_ptr(verts), verts.shape[0], _ptr(faces), faces.shape[0], _ptr(face_normals), gl_lap, gl_nc, losses.ctypes.data_as(_p),
                      ctypes.cast(ctypes.byref(ne), _p), _ptr(g_v), _ptr(g_fn))
     return dict(losses=losses, n_edges=ne.value, g_verts=g_v, g_face_normals=g_fn)
+
+
+def mesh_loss(rgba, normal, depth, target_rgbs, target_m_erode, target_m_blur, target_dir, view_w, *, target_n=None, simplified=False,
+              normal_bg=(0.5, 0.5, 1.0), pixel_loss_weight=1.2, normal_reg_weight=0.0, g_rgb_ext=None, g_nrm_ext=None, gl=1.0):
+    """Host run of mesh_loss_core.h in recon_loss.hip's launch order; shapes as oracle/recon_loss_oracle.mesh_optim_loss.
+    Returns dict(losses[4] = total, rgb, alpha, tv; out_rgbs, out_normals, g_rgba, g_normal)."""
+    n, S = rgba.shape[:2]
+    N = n * S * S
+    f = lambda a: None if a is None else _c(a)
+    arrs = [f(rgba), f(normal), f(depth), f(target_dir), f(target_rgbs), f(target_m_erode), f(target_m_blur), f(target_n), f(view_w), f(g_rgb_ext),
+            f(g_nrm_ext)]
+    nbg = _c(normal_bg)
+    ws = np.zeros(9 * N, np.float32)
+    losses = np.zeros(4, np.float64)
+    out = dict(out_rgbs=np.zeros((n, S, S, 3), np.float32), out_normals=np.zeros((n, S, S, 3), np.float32), g_rgba=np.zeros((n, S, S, 4), np.float32),
+               g_normal=np.zeros((n, S, S, 3), np.float32))
+    _lib.dc_mesh_loss(n, S, int(simplified), _ptr(nbg), pixel_loss_weight, normal_reg_weight, *[_ptr(a) for a in arrs], gl, _ptr(ws),
+                      losses.ctypes.data_as(_p), *[_ptr(out[k]) for k in ('out_rgbs', 'out_normals', 'g_rgba', 'g_normal')])
+    out['losses'] = losses
+    return out

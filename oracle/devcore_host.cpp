@@ -9,6 +9,7 @@
 #include "../mvedit_amd/csrc/shading_core.h"
 #include "../mvedit_amd/csrc/recon_loss_core.h"
 #include "../mvedit_amd/csrc/mesh_reg_core.h"
+#include "../mvedit_amd/csrc/mesh_loss_core.h"
 #include <vector>
 
 extern "C" {
@@ -115,6 +116,32 @@ void dc_mesh_reg(const float* verts, int V, const int32_t* faces, int F, const f
         mr_vertex_bwd_lap(i, bucket.data() + base[i], cnt[i], u.data(), gl_lap / (float)V, g_verts);
         if (E) mr_vertex_bwd_nc(i, bucket.data() + base[i], cnt[i], face_normals, gl_nc / (float)E, g_fn);
     }
+}
+
+// Image-space loss of one mesh optimisation iteration, forward and backward, in recon_loss.hip's launch order: xyz, raw cosine, pixel
+// pass, TV pass; one backward pass.  losses[4] = total, rgb, alpha, tv.  ws: 3N (xyz) + N (cos_raw) + N (cos) + N (alpha) + 3N (nfg) floats.
+void dc_mesh_loss(int n, int S, int simplified, const float* normal_bg, float pixel_loss_weight, float normal_reg_weight, const float* rgba,
+                  const float* normal, const float* depth, const float* dir, const float* tgt_rgb, const float* m_erode, const float* m_blur,
+                  const float* tgt_n, const float* view_w, const float* g_rgb_ext, const float* g_nrm_ext, float gl, float* ws, double* losses,
+                  float* out_rgbs, float* out_normals, float* g_rgba, float* g_normal) {
+    const MlParams q = ml_make_params(n, S, simplified, normal_bg, pixel_loss_weight, normal_reg_weight);
+    const int N = n * S * S;
+    float *xyz = ws, *craw = ws + 3 * (size_t)N, *cosp = ws + 4 * (size_t)N, *alpha = ws + 5 * (size_t)N, *nfg = ws + 6 * (size_t)N;
+    double sums[3] = {0, 0, 0};
+    for (int p = 0; p < N; ++p) rl_st(xyz, p, ml_xyz(depth, dir, p));
+    for (int p = 0; p < N; ++p) craw[p] = ml_cos_raw(xyz, dir, S, p);
+    for (int p = 0; p < N; ++p) {
+        float part[2];
+        ml_pixel_fwd(q, craw, rgba, normal, tgt_rgb, m_erode, m_blur, view_w, p, cosp, alpha, nfg, out_rgbs, out_normals, part);
+        sums[0] += part[0]; sums[1] += part[1];
+    }
+    if (q.c_tv != 0.f)
+        for (int p = 0; p < N; ++p)
+            sums[2] += q.c_tv * rl_tv_term(nfg, alpha, tgt_n, S, p / (S * S), (p / S) % S, p % S, nullptr, nullptr, nullptr, nullptr);
+    losses[0] = sums[0] + sums[1] + sums[2];
+    for (int k = 0; k < 3; ++k) losses[1 + k] = sums[k];
+    for (int p = 0; p < N; ++p)
+        ml_pixel_bwd(q, cosp, alpha, nfg, rgba, normal, tgt_rgb, m_erode, m_blur, tgt_n, view_w, g_rgb_ext, g_nrm_ext, gl, p, g_rgba, g_normal);
 }
 
 }  // extern "C"

@@ -97,3 +97,38 @@ def nerf_optim_loss(image, weights_sum, depth, weights, bin_width, target_rgbs, 
                             + torch.sum(bg_w * (torch.log(bg_w.clamp(min=1e-6)) - math.log(bg_width)))) * (entropy_weight / (P * ps * ps))
     res['loss'] = loss + res['entropy_loss']
     return res
+
+
+def mesh_optim_loss(rgba, normal, depth, target_rgbs, target_m_erode, target_m_blur, target_dir, view_w, *, target_n=None, simplified=False,
+                    normal_bg=(0.5, 0.5, 1.0), pixel_loss_weight=1.2, normal_reg_weight=0.0):
+    """Image-space part of one MESH optimisation iteration, lib/pipelines/mvedit_3d_pipeline.py:745-782 (`mesh_optim`): rgba [n, S, S, 4],
+    normal [n, S, S, 3], depth [n, S, S] as `render_out` holds them; view_w [n] = cam_weights / cam_weights_mean; simplified =
+    `mesh_is_simplified`.  PINNED by tests/golden/mesh_loss_ref.npz (the reference's own statements executed, float64)."""
+    dt = rgba.dtype
+    nbg = torch.as_tensor(normal_bg, dtype=dt, device=rgba.device)
+    w = view_w[:, None, None, None]
+    out_alphas = rgba[..., 3:]
+    out_rgbs = rgba[..., :3] / out_alphas.clamp(min=1e-3)
+    out_rgbs = out_rgbs * target_m_erode + target_rgbs * (1 - target_m_erode)
+    n_cv = depth_to_normal_opencv(depth.detach(), target_dir) * 2 - 1
+    cos = (n_cv * F.normalize(target_dir, dim=-1)).sum(-1, keepdim=True).neg().clamp(min=0)
+    cos = -F.max_pool2d(-cos.permute(0, 3, 1, 2), 5, stride=1, padding=2).permute(0, 2, 3, 1)
+    out_normals = normal * cos + normal.detach() * (1 - cos)
+    nfg = (out_normals - nbg * (1 - out_alphas)) / out_alphas.clamp(min=1e-3)
+    res = dict(out_rgbs=out_rgbs, out_normals=out_normals, out_normals_cos=cos)
+    res['pixel_rgb_loss'] = ((out_rgbs - target_rgbs).abs() * w).mean() * pixel_loss_weight * 4.5
+    loss = res['pixel_rgb_loss']
+    if not simplified:
+        res['alphas_loss'] = ((out_alphas - target_m_blur).abs() * w).mean() * pixel_loss_weight * 2.0
+        res['normal_reg_loss'] = tv_loss(nfg.permute(0, 3, 1, 2), None if target_n is None else target_n.permute(0, 3, 1, 2),
+                                         out_alphas.detach().permute(0, 3, 1, 2)) * (normal_reg_weight * 2)
+        loss = loss + res['alphas_loss'] + res['normal_reg_loss']
+    res['loss'] = loss
+    return res
+
+
+def depth_to_normal_opencv(depth, directions):
+    """geometry_utils.py:119-148, format='opencv': depth_to_normal without the axis flips"""
+    n = depth_to_normal(depth, directions) * 2 - 1
+    n = torch.cat([n[..., :1], -n[..., 1:3]], dim=-1)
+    return n / 2 + 0.5

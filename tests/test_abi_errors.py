@@ -114,3 +114,22 @@ def test_mesh_reg_argument_checks(L):
     _bad(lib, 'mve_mesh_reg_forward', p, 0, p, 200, p, p, 1 << 20, p, None, match='mesh size')
     _bad(lib, 'mve_mesh_reg_forward', p, 100, None, 200, p, p, 1 << 20, p, None, match='null pointer')
     _bad(lib, 'mve_mesh_reg_backward', p, 100, p, 200, p, p, 1 << 20, None, None, p, None, match='null output')
+
+
+def test_mesh_loss_descriptor_checks(L):
+    lib, p, _ = L
+    from mvedit_amd.recon_loss import _MeshDesc
+    raw = lib.raw('mve_mesh_loss_workspace_bytes')
+    assert raw(0, 512) == 0 and raw(6, 512) == 4 * (9 * 6 * 512 * 512 + 6 * 6144)
+
+    def desc(**kw):
+        d = _MeshDesc(n=2, size=8, mesh_is_simplified=0, pixel_loss_weight=1.2, normal_reg_weight=1.0)
+        for f in ('d_rgba', 'd_normal', 'd_depth', 'd_target_dir', 'd_target_rgbs', 'd_target_m_erode', 'd_target_m_blur', 'd_view_w'):
+            setattr(d, f, p.value)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    _bad(lib, 'mve_mesh_loss_forward', ctypes.byref(desc(size=1)), p, 1 << 20, p, p, p, None, match='view geometry')
+    _bad(lib, 'mve_mesh_loss_forward', ctypes.byref(desc(d_depth=None)), p, 1 << 20, p, p, p, None, match='null pointer')
+    _bad(lib, 'mve_mesh_loss_forward', ctypes.byref(desc()), p, 64, p, p, p, None, match='workspace')
+    _bad(lib, 'mve_mesh_loss_backward', ctypes.byref(desc()), p, 1 << 20, None, None, None, None, p, None, match='null output')

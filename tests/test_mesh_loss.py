@@ -1,0 +1,137 @@
+"""Image-space loss of one MESH optimisation iteration (csrc/recon_loss.hip + mesh_loss_core.h behind mvedit_amd.recon_loss.mesh_optim_loss)
+vs the reference's OWN statements (lib/pipelines/mvedit_3d_pipeline.py:745-782) executed on the CPU in float64 with torch autograd
+(tests/golden/mesh_loss_ref.npz, tests/golden/make_mesh_loss_golden.py).  Unlike the NeRF loss nothing here is ill-conditioned (the
+depth -> normal stencil only feeds a detached, clamped cosine): 3e-6 of each tensor's scale throughout."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pending_first_gpu_run
+from oracle import recon_loss_oracle as R
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mesh_loss_ref.npz'))
+NC = int(G['n_cases'])
+PARTS = ('loss', 'pixel_rgb_loss', 'alphas_loss', 'normal_reg_loss')
+ARGS = ('rgba', 'normal', 'depth', 'target_rgbs', 'target_m_erode', 'target_m_blur', 'target_dir')
+
+
+def case(i):
+    c = lambda k: G[f'c{i}_{k}']
+    kw = dict(target_n=c('target_n') if c('use_normal') else None, normal_reg_weight=float(c('normal_reg_weight')))
+    return [c(k) for k in ARGS] + [c('cam_w') / float(c('cam_weights_mean'))], kw, bool(c('simplified')), c
+
+
+def rel(a, b):
+    b = np.asarray(b, np.float64)
+    return float(np.abs(np.asarray(a, np.float64).reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+@pytest.mark.parametrize('i', range(NC))
+def test_oracle_restatement_equals_reference_statements(i):
+    args, kw, simp, c = case(i)
+    t = [torch.from_numpy(a) for a in args]
+    t[0].requires_grad_(True), t[1].requires_grad_(True)
+    r = R.mesh_optim_loss(*t, target_n=None if kw['target_n'] is None else torch.from_numpy(kw['target_n']), simplified=simp,
+                          normal_reg_weight=kw['normal_reg_weight'])
+    total = r['loss'] * 0.6 + (r['out_rgbs'] * torch.from_numpy(c('ext_rgb'))).sum() + (r['out_normals'] * torch.from_numpy(c('ext_nrm'))).sum()
+    gx = torch.autograd.grad(total, (t[0], t[1]))
+    assert abs(float(r['loss'].detach()) - float(c('loss'))) < 1e-12
+    assert np.abs(r['out_normals_cos'].detach().numpy() - c('out_normals_cos')).max() < 1e-12
+    assert rel(gx[0].numpy(), c('gx_rgba')) < 1e-12 and rel(gx[1].numpy(), c('gx_normal')) < 1e-12
+
+
+@pytest.mark.parametrize('i', range(NC))
+def test_kernel_arithmetic_host_build_vs_reference(i):
+    """mesh_loss_core.h -- the source the HIP kernels are made of -- built for the host and run in the kernels' launch order."""
+    from oracle import devcore as D
+    args, kw, simp, c = case(i)
+    h = D.mesh_loss(*args, simplified=simp, **kw)
+    assert np.abs(h['losses'] - np.asarray([float(c(k)) for k in PARTS])).max() < 1e-6
+    assert rel(h['out_rgbs'], c('out_rgbs')) < 3e-7 and rel(h['out_normals'], c('out_normals')) < 3e-7
+    assert rel(h['g_rgba'], c('g_rgba')) < 3e-6
+    assert np.abs(h['g_normal'].astype(np.float64) - c('g_normal')).max() <= 3e-6 * max(np.abs(c('g_normal')).max(), 1e-12)
+    hx = D.mesh_loss(*args, simplified=simp, **kw, g_rgb_ext=c('ext_rgb'), g_nrm_ext=c('ext_nrm'), gl=0.6)
+    assert rel(hx['g_rgba'], c('gx_rgba')) < 3e-6 and rel(hx['g_normal'], c('gx_normal')) < 3e-6
+
+
+def test_descriptor_layout_matches_the_header(tmp_path):
+    pytest.importorskip('mvedit_amd._lib')
+    from mvedit_amd.recon_loss import _MeshDesc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f[0] for f in _MeshDesc._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mvedit_amd.h"\nint main(void) {\n  printf("%zu", sizeof(MveMeshLossDesc));\n'
+                   + ''.join(f'  printf(" %zu", offsetof(MveMeshLossDesc, {f}));\n' for f in fields) + '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)], check=True)
+    nums = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert nums[0] == ctypes.sizeof(_MeshDesc) and nums[1:] == [getattr(_MeshDesc, f).offset for f in fields]
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pending_first_gpu_run
+@pytest.mark.parametrize('i', range(NC))
+def test_hip_vs_reference(lib, i):
+    from mvedit_amd.recon_loss import mesh_optim_loss
+    args, kw, simp, c = case(i)
+    cu = [torch.from_numpy(a).float().cuda() for a in args]
+    cu[0].requires_grad_(True), cu[1].requires_grad_(True)
+    tn = None if kw['target_n'] is None else torch.from_numpy(kw['target_n']).float().cuda()
+    r = mesh_optim_loss(*cu, target_n=tn, mesh_is_simplified=simp, normal_reg_weight=kw['normal_reg_weight'])
+    for k in PARTS:
+        assert abs(float(r[k]) - float(c(k))) < 2e-6, k
+    assert rel(r['out_rgbs'].detach().cpu().numpy(), c('out_rgbs')) < 3e-7 and rel(r['out_normals'].detach().cpu().numpy(), c('out_normals')) < 3e-7
+    total = r['loss'] * 0.6 + (r['out_rgbs'] * torch.from_numpy(c('ext_rgb')).float().cuda()).sum() \
+        + (r['out_normals'] * torch.from_numpy(c('ext_nrm')).float().cuda()).sum()
+    gx = torch.autograd.grad(total, (cu[0], cu[1]))
+    assert rel(gx[0].cpu().numpy(), c('gx_rgba')) < 3e-6 and rel(gx[1].cpu().numpy(), c('gx_normal')) < 3e-6
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_hip_full_size_views_and_timing(lib):
+    """render_bs x 512^2 views as mesh_optim renders them; vs the torch restatement in float64; prints native vs torch-statement time"""
+    import time
+    from mvedit_amd.recon_loss import mesh_optim_loss
+    n, S = 6, 512
+    g = torch.Generator().manual_seed(9)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, S), torch.linspace(-1, 1, S), indexing='ij')
+    dirs = torch.stack([xx * 0.27, yy * 0.27, torch.ones_like(xx)], -1)[None].expand(n, -1, -1, -1).contiguous()
+    alpha = (torch.rand(n, S, S, 1, generator=g) * 1.3 - 0.1).clamp(0, 1)
+    nbg = torch.tensor([0.5, 0.5, 1.0])
+    args = [torch.cat([torch.rand(n, S, S, 3, generator=g) * alpha, alpha], -1), torch.rand(n, S, S, 3, generator=g) * alpha + nbg * (1 - alpha),
+            0.3 + 0.08 * torch.rand(n, S, S, generator=g), torch.rand(n, S, S, 3, generator=g), (torch.rand(n, S, S, 1, generator=g) * 1.4 - 0.2).clamp(0, 1),
+            torch.rand(n, S, S, 1, generator=g), dirs, torch.rand(n, generator=g) + 0.5]
+    tn = torch.rand(n, S, S, 3, generator=g)
+    t64 = [a.double() for a in args]
+    t64[0].requires_grad_(True), t64[1].requires_grad_(True)
+    r64 = R.mesh_optim_loss(*t64, target_n=tn.double(), normal_reg_weight=2.0)
+    g64 = torch.autograd.grad(r64['loss'], (t64[0], t64[1]))
+    cu = [a.cuda() for a in args]
+    cu[0].requires_grad_(True), cu[1].requires_grad_(True)
+    r = mesh_optim_loss(*cu, target_n=tn.cuda(), normal_reg_weight=2.0)
+    gg = torch.autograd.grad(r['loss'], (cu[0], cu[1]))
+    assert abs(float(r['loss']) - float(r64['loss'])) < 2e-5 * float(r64['loss'])
+    assert rel(gg[0].cpu().numpy(), g64[0].numpy()) < 1e-5 and rel(gg[1].cpu().numpy(), g64[1].numpy()) < 1e-5
+
+    def native():
+        a, b = cu[0].detach().requires_grad_(True), cu[1].detach().requires_grad_(True)
+        mesh_optim_loss(a, b, *cu[2:], target_n=tn.cuda(), normal_reg_weight=2.0)['loss'].backward()
+
+    def torch_ops():
+        a, b = cu[0].detach().requires_grad_(True), cu[1].detach().requires_grad_(True)
+        R.mesh_optim_loss(a, b, *[c_.detach() for c_ in cu[2:]], target_n=tn.cuda(), normal_reg_weight=2.0)['loss'].backward()
+    for name, fn in (('native', native), ('torch statements', torch_ops)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        print(f'mesh loss fwd+bwd, 6 x 512^2 pixels, {name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms')

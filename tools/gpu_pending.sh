@@ -15,3 +15,4 @@ run lpips tests/test_lpips.py
 run attention_variant tests/test_unet_ops.py -k "experimental_variant or conflict_free or vt_store_swizzle"
 run recon_loss tests/test_recon_loss.py
 run mesh_reg tests/test_mesh_reg.py
+run mesh_loss tests/test_mesh_loss.py
