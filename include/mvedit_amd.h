@@ -352,6 +352,15 @@ MVE_API int mve_mesh_reg_forward(const float* d_verts, int V, const int32_t* d_f
 MVE_API int mve_mesh_reg_backward(const float* d_verts, int V, const int32_t* d_faces, int F, const float* d_face_normals, void* d_ws,
                                   size_t ws_bytes, const float* d_g_losses, float* d_g_verts, float* d_g_face_normals, void* stream);
 
+/* Mesh.auto_normal (lib/models/decoders/mesh_renderer/mesh_utils.py:359-382, seamless=False; once per mesh-optimisation iteration,
+ * lib/pipelines/mvedit_3d_pipeline.py:846-847): face_normals [F,3] = normalize(cross(v1 - v0, v2 - v0)), vn [V,3] = normalize of their
+ * per-vertex sum (float atomics, like the reference's scatter_add_).  vn_sum [V,3] (the unnormalised sums) is kept for the backward. */
+MVE_API int mve_mesh_normals_forward(const float* d_verts, int V, const int32_t* d_faces, int F, float* d_face_normals, float* d_vn_sum,
+                                     float* d_vn, void* stream);
+/* g_verts [V,3] = gradient w.r.t. the vertices given g_vn [V,3] and / or g_face_normals [F,3] (either may be NULL); scratch: [V,3] f32. */
+MVE_API int mve_mesh_normals_backward(const float* d_verts, int V, const int32_t* d_faces, int F, const float* d_vn_sum, const float* d_g_vn,
+                                      const float* d_g_face_normals, float* d_scratch, float* d_g_verts, void* stream);
+
 /* =========================================================================
  * 3. UNet2DCondition executor (native runtime behind the reference's UNet seam).
  *    Replaces `self.unet(sample, t, encoder_hidden_states=..., cross_attention_kwargs=...,

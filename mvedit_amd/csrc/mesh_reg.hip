@@ -117,6 +117,33 @@ __global__ __launch_bounds__(NT) void k_mr_vertex_bwd(int V, const float* __rest
     if (E > 0) mr_vertex_bwd_nc(i, b, w.cnt[i], face_normals, gl_nc / (float)E, g_fn);
 }
 
+// ---- Mesh.auto_normal -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_mn_face_fwd(const float* __restrict__ verts, const int32_t* __restrict__ faces, int F,
+                                                    float* __restrict__ face_normals, float* __restrict__ vn_sum) {
+    const int t = blockIdx.x * NT + threadIdx.x;
+    if (t < F) mr_normals_face_fwd(verts, faces, t, face_normals, vn_sum);
+}
+
+__global__ __launch_bounds__(NT) void k_mn_vertex_fwd(int V, const float* __restrict__ vn_sum, float* __restrict__ vn) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= V) return;
+    const float l = sqrtf(mr_dot3(vn_sum + 3 * i, vn_sum + 3 * i)), inv = 1.0f / fmaxf(l, 1e-12f);
+    for (int k = 0; k < 3; ++k) vn[3 * i + k] = vn_sum[3 * i + k] * inv;
+}
+
+__global__ __launch_bounds__(NT) void k_mn_vertex_bwd(int V, const float* __restrict__ vn_sum, const float* __restrict__ g_vn, float* __restrict__ g_sum) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= V) return;
+    const float zero[3] = {0.f, 0.f, 0.f};
+    mr_normalize_bwd(vn_sum + 3 * i, g_vn ? g_vn + 3 * i : zero, g_sum + 3 * i);
+}
+
+__global__ __launch_bounds__(NT) void k_mn_face_bwd(const float* __restrict__ verts, const int32_t* __restrict__ faces, int F,
+                                                    const float* __restrict__ g_fn_ext, const float* __restrict__ g_sum, float* __restrict__ g_verts) {
+    const int t = blockIdx.x * NT + threadIdx.x;
+    if (t < F) mr_normals_face_bwd(verts, faces, t, g_fn_ext, g_sum, g_verts);
+}
+
 int check(const char* who, const float* verts, int V, const int32_t* faces, int F, const float* fn, const void* ws, size_t ws_bytes) {
     MVE_CHECK(verts && faces && fn && ws, MVE_ERR_ARG, "%s: null pointer", who);
     MVE_CHECK(V > 0 && F > 0 && (long long)F * 6 < (1ll << 31), MVE_ERR_ARG, "%s: bad mesh size V=%d F=%d", who, V, F);
@@ -159,6 +186,32 @@ int mve_mesh_reg_backward(const float* d_verts, int V, const int32_t* d_faces, i
     const Ws w = carve(d_ws, V, F);
     MVE_HIP(hipMemsetAsync(d_g_face_normals, 0, sizeof(float) * 3 * (size_t)F, s));
     k_mr_vertex_bwd<<<w.nbv, NT, 0, s>>>(V, d_face_normals, w, d_g_losses, d_g_verts, d_g_face_normals);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_mesh_normals_forward(const float* d_verts, int V, const int32_t* d_faces, int F, float* d_face_normals, float* d_vn_sum, float* d_vn,
+                             void* stream) {
+    MVE_CHECK(d_verts && d_faces && d_face_normals && d_vn_sum && d_vn, MVE_ERR_ARG, "mesh_normals_forward: null pointer");
+    MVE_CHECK(V > 0 && F > 0, MVE_ERR_ARG, "mesh_normals_forward: bad mesh size V=%d F=%d", V, F);
+    hipStream_t s = (hipStream_t)stream;
+    MVE_HIP(hipMemsetAsync(d_vn_sum, 0, sizeof(float) * 3 * (size_t)V, s));
+    k_mn_face_fwd<<<mve_cdiv(F, NT), NT, 0, s>>>(d_verts, d_faces, F, d_face_normals, d_vn_sum);
+    MVE_LAUNCH_CHECK();
+    k_mn_vertex_fwd<<<mve_cdiv(V, NT), NT, 0, s>>>(V, d_vn_sum, d_vn);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_mesh_normals_backward(const float* d_verts, int V, const int32_t* d_faces, int F, const float* d_vn_sum, const float* d_g_vn,
+                              const float* d_g_face_normals, float* d_scratch, float* d_g_verts, void* stream) {
+    MVE_CHECK(d_verts && d_faces && d_vn_sum && d_scratch && d_g_verts, MVE_ERR_ARG, "mesh_normals_backward: null pointer");
+    MVE_CHECK(V > 0 && F > 0, MVE_ERR_ARG, "mesh_normals_backward: bad mesh size V=%d F=%d", V, F);
+    hipStream_t s = (hipStream_t)stream;
+    MVE_HIP(hipMemsetAsync(d_g_verts, 0, sizeof(float) * 3 * (size_t)V, s));
+    k_mn_vertex_bwd<<<mve_cdiv(V, NT), NT, 0, s>>>(V, d_vn_sum, d_g_vn, d_scratch);
+    MVE_LAUNCH_CHECK();
+    k_mn_face_bwd<<<mve_cdiv(F, NT), NT, 0, s>>>(d_verts, d_faces, F, d_g_face_normals, d_scratch, d_g_verts);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

@@ -116,3 +116,59 @@ MVE_MR_FN void mr_vertex_bwd_nc(int i, const uint64_t* b, int n, const float* fa
         s = e;
     }
 }
+
+// ---- Mesh.auto_normal (lib/models/decoders/mesh_renderer/mesh_utils.py:359-382, seamless=False) ------------------------------------------
+// face normal = normalize(cross(v1 - v0, v2 - v0)) (F.normalize: / max(|.|, 1e-12)), splatted onto the three vertices (scatter_add -> float
+// atomics, as in the reference), vertex normal = normalize(sum).
+MVE_MR_FN void mr_face_normal(const float* verts, const int32_t* face, float* n, float* len) {
+    const float* a = verts + 3 * face[0];
+    const float* b = verts + 3 * face[1];
+    const float* c = verts + 3 * face[2];
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    const float cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const float l = sqrtf(mr_dot3(cr, cr)), inv = 1.0f / fmaxf(l, 1e-12f);
+    *len = l;
+    for (int k = 0; k < 3; ++k) n[k] = cr[k] * inv;
+}
+
+// face pass of the forward: face_normals[t], vn_sum[verts of t] += face normal
+MVE_MR_FN void mr_normals_face_fwd(const float* verts, const int32_t* faces, int t, float* face_normals, float* vn_sum) {
+    float n[3], l;
+    mr_face_normal(verts, faces + 3 * t, n, &l);
+    for (int k = 0; k < 3; ++k) face_normals[3 * t + k] = n[k];
+    for (int c = 0; c < 3; ++c)
+        for (int k = 0; k < 3; ++k) mr_add(vn_sum + 3 * faces[3 * t + c] + k, n[k]);
+}
+
+// gradient of v / max(|v|, 1e-12) w.r.t. v given the incoming gradient g
+MVE_MR_FN void mr_normalize_bwd(const float* v, const float* g, float* out) {
+    const float l = sqrtf(mr_dot3(v, v)), inv = 1.0f / fmaxf(l, 1e-12f);
+    if (l >= 1e-12f) {
+        const float d = (v[0] * g[0] + v[1] * g[1] + v[2] * g[2]) * inv * inv;
+        for (int k = 0; k < 3; ++k) out[k] = (g[k] - v[k] * d) * inv;
+    } else {
+        for (int k = 0; k < 3; ++k) out[k] = g[k] * inv;
+    }
+}
+
+// face pass of the backward: g_fn = g_face_normals_ext[t] + sum over the face's vertices of g_sum (= d / d vn_sum, per vertex), then
+// through normalize and the cross product to the three vertices (atomic adds into g_verts)
+MVE_MR_FN void mr_normals_face_bwd(const float* verts, const int32_t* faces, int t, const float* g_fn_ext, const float* g_sum, float* g_verts) {
+    const int32_t* f = faces + 3 * t;
+    const float* a = verts + 3 * f[0];
+    const float* b = verts + 3 * f[1];
+    const float* c = verts + 3 * f[2];
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    const float cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    float g[3], gc[3];
+    for (int k = 0; k < 3; ++k) g[k] = (g_fn_ext ? g_fn_ext[3 * t + k] : 0.f) + g_sum[3 * f[0] + k] + g_sum[3 * f[1] + k] + g_sum[3 * f[2] + k];
+    mr_normalize_bwd(cr, g, gc);
+    // cr = e1 x e2:  g_e1 = e2 x gc,  g_e2 = gc x e1
+    const float g1[3] = {e2[1] * gc[2] - e2[2] * gc[1], e2[2] * gc[0] - e2[0] * gc[2], e2[0] * gc[1] - e2[1] * gc[0]};
+    const float g2[3] = {gc[1] * e1[2] - gc[2] * e1[1], gc[2] * e1[0] - gc[0] * e1[2], gc[0] * e1[1] - gc[1] * e1[0]};
+    for (int k = 0; k < 3; ++k) {
+        mr_add(g_verts + 3 * f[1] + k, g1[k]);
+        mr_add(g_verts + 3 * f[2] + k, g2[k]);
+        mr_add(g_verts + 3 * f[0] + k, -g1[k] - g2[k]);
+    }
+}

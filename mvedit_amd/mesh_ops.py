@@ -447,12 +447,50 @@ class MeshRenderer:
         return [mesh]
 
 
-class Mesh:
-    """Minimal stand-in for lib.models.decoders.mesh_renderer.mesh_utils.Mesh: the attributes the render/bake path touches."""
+class _AutoNormalFn(torch.autograd.Function):
+    """(vn, face_normals) = Mesh.auto_normal(v, f) with the native backward w.r.t. v."""
 
-    def __init__(self, v, f, vt=None, ft=None, vn=None, fn=None, albedo=None, vc=None):
+    @staticmethod
+    def forward(ctx, verts, faces):
+        assert verts.is_cuda and faces.is_cuda and verts.dim() == 2 and verts.shape[1] == 3 and faces.dim() == 2 and faces.shape[1] == 3
+        v = verts.detach().to(torch.float32).contiguous()
+        f = faces.to(torch.int32).contiguous()
+        V, F = v.shape[0], f.shape[0]
+        fn = torch.empty(F, 3, dtype=torch.float32, device=v.device)
+        vs, vn = torch.empty_like(v), torch.empty_like(v)
+        with torch.cuda.device(v.device):
+            _lib.call('mve_mesh_normals_forward', _lib.ptr(v), V, _lib.ptr(f), F, _lib.ptr(fn), _lib.ptr(vs), _lib.ptr(vn), _lib.stream_ptr(v.device))
+        ctx.keep, ctx.dtype = (v, f, vs), verts.dtype
+        return vn.to(verts.dtype), fn.to(verts.dtype)
+
+    @staticmethod
+    def backward(ctx, g_vn, g_fn):
+        v, f, vs = ctx.keep
+        g_vn = None if g_vn is None else g_vn.detach().to(torch.float32).contiguous()
+        g_fn = None if g_fn is None else g_fn.detach().to(torch.float32).contiguous()
+        scratch, g_v = torch.empty_like(v), torch.empty_like(v)
+        with torch.cuda.device(v.device):
+            _lib.call('mve_mesh_normals_backward', _lib.ptr(v), v.shape[0], _lib.ptr(f), f.shape[0], _lib.ptr(vs), _lib.ptr(g_vn), _lib.ptr(g_fn),
+                      _lib.ptr(scratch), _lib.ptr(g_v), _lib.stream_ptr(v.device))
+        return g_v.to(ctx.dtype), None
+
+
+class Mesh:
+    """Stand-in for lib.models.decoders.mesh_renderer.mesh_utils.Mesh: the attributes the render / bake / optimisation paths touch, and
+    `auto_normal` (mesh_utils.py:359-382) on native kernels."""
+
+    def __init__(self, v, f, vt=None, ft=None, vn=None, fn=None, albedo=None, vc=None, device=None):
         self.v, self.f, self.vt, self.ft, self.vn, self.fn, self.albedo, self.vc = v, f, vt, ft, vn, fn, albedo, vc
+        self.face_normals = None
         self.textureless = albedo is None
+
+    def auto_normal(self, seamless=False):
+        """vn, fn, face_normals as the reference sets them; differentiable w.r.t. v.  seamless=True (vertex welding through
+        torch.unique) is not on the optimisation path and not built."""
+        if seamless:
+            raise NotImplementedError('Mesh.auto_normal(seamless=True) is outside the native path')
+        self.vn, self.face_normals = _AutoNormalFn.apply(self.v, self.f)
+        self.fn = self.f.to(torch.int32)
 
 
 class _DMTetFn(torch.autograd.Function):

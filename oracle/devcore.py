@@ -23,6 +23,8 @@ _lib.dc_recon_loss.restype = None
 
 _lib.dc_mesh_loss.argtypes = [_i, _i, _i, _p, _f, _f] + [_p] * 11 + [_f] + [_p] * 6
 _lib.dc_mesh_loss.restype = None
+_lib.dc_mesh_normals.argtypes = [_p, _i, _p, _i] + [_p] * 7
+_lib.dc_mesh_normals.restype = None
 _lib.dc_mesh_reg.argtypes = [_p, _i, _p, _i, _p, _f, _f, _p, _p, _p, _p]
 _lib.dc_mesh_reg.restype = None
 
@@ -127,3 +129,14 @@ def mesh_loss(rgba, normal, depth, target_rgbs, target_m_erode, target_m_blur, t
                       losses.ctypes.data_as(_p), *[_ptr(out[k]) for k in ('out_rgbs', 'out_normals', 'g_rgba', 'g_normal')])
     out['losses'] = losses
     return out
+
+
+def mesh_normals(verts, faces, g_vn=None, g_face_normals=None):
+    """Host run of the auto_normal functions of mesh_reg_core.h -> dict(face_normals [F, 3], vn [V, 3], g_verts [V, 3])."""
+    verts, faces = _c(verts), _c(faces, np.int32)
+    f = lambda a: None if a is None else _c(a)
+    g_vn, g_fn = f(g_vn), f(g_face_normals)
+    fn, vs, vn = np.zeros((faces.shape[0], 3), np.float32), np.zeros_like(verts), np.zeros_like(verts)
+    gs, gv = np.zeros_like(verts), np.zeros_like(verts)
+    _lib.dc_mesh_normals(_ptr(verts), verts.shape[0], _ptr(faces), faces.shape[0], _ptr(g_vn), _ptr(g_fn), _ptr(fn), _ptr(vs), _ptr(vn), _ptr(gs), _ptr(gv))
+    return dict(face_normals=fn, vn=vn, g_verts=gv)

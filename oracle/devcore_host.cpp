@@ -144,4 +144,19 @@ void dc_mesh_loss(int n, int S, int simplified, const float* normal_bg, float pi
         ml_pixel_bwd(q, cosp, alpha, nfg, rgba, normal, tgt_rgb, m_erode, m_blur, tgt_n, view_w, g_rgb_ext, g_nrm_ext, gl, p, g_rgba, g_normal);
 }
 
+// Mesh.auto_normal forward + backward in mesh_reg.hip's launch order.  vn_sum / g_verts must come zero-initialised; g_sum is [V,3] scratch.
+void dc_mesh_normals(const float* verts, int V, const int32_t* faces, int F, const float* g_vn, const float* g_fn_ext, float* face_normals,
+                     float* vn_sum, float* vn, float* g_sum, float* g_verts) {
+    for (int t = 0; t < F; ++t) mr_normals_face_fwd(verts, faces, t, face_normals, vn_sum);
+    for (int i = 0; i < V; ++i) {
+        const float l = sqrtf(mr_dot3(vn_sum + 3 * i, vn_sum + 3 * i)), inv = 1.0f / fmaxf(l, 1e-12f);
+        for (int k = 0; k < 3; ++k) vn[3 * i + k] = vn_sum[3 * i + k] * inv;
+    }
+    for (int i = 0; i < V; ++i) {
+        const float zero[3] = {0.f, 0.f, 0.f};
+        mr_normalize_bwd(vn_sum + 3 * i, g_vn ? g_vn + 3 * i : zero, g_sum + 3 * i);
+    }
+    for (int t = 0; t < F; ++t) mr_normals_face_bwd(verts, faces, t, g_fn_ext, g_sum, g_verts);
+}
+
 }  // extern "C"

@@ -114,6 +114,8 @@ def test_mesh_reg_argument_checks(L):
     _bad(lib, 'mve_mesh_reg_forward', p, 0, p, 200, p, p, 1 << 20, p, None, match='mesh size')
     _bad(lib, 'mve_mesh_reg_forward', p, 100, None, 200, p, p, 1 << 20, p, None, match='null pointer')
     _bad(lib, 'mve_mesh_reg_backward', p, 100, p, 200, p, p, 1 << 20, None, None, p, None, match='null output')
+    _bad(lib, 'mve_mesh_normals_forward', p, 100, p, 0, p, p, p, None, match='mesh size')
+    _bad(lib, 'mve_mesh_normals_backward', p, 100, p, 200, p, None, None, None, p, None, match='null pointer')
 
 
 def test_mesh_loss_descriptor_checks(L):

@@ -148,3 +148,41 @@ def test_hip_timing_against_the_torch_functions_on_the_same_gpu(lib):
             fn_()
         torch.cuda.synchronize()
         print(f'mesh regularisers fwd+bwd, 131 k faces, {name}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms')
+
+
+# ================================================================================================ Mesh.auto_normal
+GN = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mesh_normals_ref.npz'))
+
+
+@pytest.mark.parametrize('i', range(int(GN['n_cases'])))
+def test_auto_normal_host_build_vs_reference_method(i):
+    """the reference's own Mesh.auto_normal executed (float64, autograd; tests/golden/make_mesh_normals_golden.py) vs the host build of
+    the kernel source: fp32 rounding only (3e-6 of scale)"""
+    from oracle import devcore as D
+    c = lambda k: GN[f'c{i}_{k}']
+    h = D.mesh_normals(c('verts'), c('faces'), c('g_vn'), c('g_fn'))
+    assert rel(h['face_normals'], c('face_normals')) < 1e-6 and rel(h['vn'], c('vn')) < 1e-6 and rel(h['g_verts'], c('g_verts')) < 3e-6
+    assert np.array_equal(c('fn'), c('faces'))
+    only_vn = D.mesh_normals(c('verts'), c('faces'), c('g_vn'), None)['g_verts'] + D.mesh_normals(c('verts'), c('faces'), None, c('g_fn'))['g_verts']
+    assert rel(only_vn, c('g_verts')) < 3e-6                                   # the two incoming gradients are optional and additive
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+@pytest.mark.parametrize('i', range(int(GN['n_cases'])))
+def test_hip_auto_normal_vs_reference_method(lib, i):
+    from mvedit_amd.mesh_ops import Mesh
+    c = lambda k: GN[f'c{i}_{k}']
+    v = torch.from_numpy(c('verts')).float().cuda().requires_grad_(True)
+    m = Mesh(v, torch.from_numpy(c('faces')).cuda())
+    m.auto_normal()
+    assert rel(m.vn.detach().cpu().numpy(), c('vn')) < 1e-6 and rel(m.face_normals.detach().cpu().numpy(), c('face_normals')) < 1e-6
+    assert m.fn.dtype == torch.int32 and np.array_equal(m.fn.cpu().numpy(), c('fn'))
+    g_v, = torch.autograd.grad((m.vn * torch.from_numpy(c('g_vn')).float().cuda()).sum()
+                               + (m.face_normals * torch.from_numpy(c('g_fn')).float().cuda()).sum(), v)
+    assert rel(g_v.cpu().numpy(), c('g_verts')) < 3e-6
+    # chained with the regularisers the way mesh_optim uses them: d normal_consistency / d verts flows through face_normals
+    from mvedit_amd.mesh_ops import mesh_regularizers
+    lap, nc = mesh_regularizers(v, m.f, m.face_normals)
+    g2, = torch.autograd.grad(lap + nc, v)
+    assert torch.isfinite(g2).all() and float(g2.abs().max()) > 0
