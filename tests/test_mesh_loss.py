@@ -135,3 +135,53 @@ def test_hip_full_size_views_and_timing(lib):
             fn()
         torch.cuda.synchronize()
         print(f'mesh loss fwd+bwd, 6 x 512^2 pixels, {name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms')
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_mesh_optim_iteration_on_native_kernels_only(lib):
+    """The mesh half of the reconstruct step wired together the way `mesh_optim` wires it (mvedit_3d_pipeline.py:716-847), every stage
+    native: Mesh.auto_normal -> MeshRenderer.forward (rasterise / interpolate / antialias with their geometry gradients) ->
+    mesh_optim_loss + mesh_regularizers -> backward -> Adam on the vertices.  A small sphere must grow into the silhouettes of a larger
+    one: the alpha term has to fall, every gradient has to be finite."""
+    from mvedit_amd.mesh_ops import Mesh, MeshRenderer, mesh_regularizers
+    from mvedit_amd.recon_loss import mesh_optim_loss
+    from scene import icosphere
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_py.npz'))
+    S, nv = 64, 6
+    poses = torch.from_numpy(gold['poses'][:nv, :3].astype(np.float32)).cuda()
+    fl = S / (2 * np.tan(np.deg2rad(15)))
+    intr = torch.tensor([[fl, fl, S / 2, S / 2]], dtype=torch.float32).repeat(nv, 1).cuda()
+    v0, f = icosphere(3, 0.6)
+    f = torch.from_numpy(f).cuda()
+    mr = MeshRenderer(near=0.01, far=100)
+
+    def render(verts):
+        m = Mesh(verts, f, vc=torch.cat([torch.full_like(verts, 0.7), torch.ones_like(verts[:, :1])], -1))
+        m.auto_normal()
+        out = mr([m], poses[None], intr[None], S, S, normal_bg=[0.5, 0.5, 1.0])
+        return m, out['rgba'][0], out['normal'][0], out['depth'][0]
+    with torch.no_grad():
+        _, rgba_t, normal_t, _ = render(torch.from_numpy(v0).cuda())
+    tgt_m = rgba_t[..., 3:].contiguous()
+    tgt_rgb = (rgba_t[..., :3] / tgt_m.clamp(min=1e-3)).contiguous()
+    erode = -torch.nn.functional.max_pool2d(-tgt_m.permute(0, 3, 1, 2), 5, stride=1, padding=2).permute(0, 2, 3, 1).contiguous()
+    # pinhole ray directions of the pixel centres in the camera frame (OpenCV), as `target_dir`
+    ys, xs = torch.meshgrid(torch.arange(S, dtype=torch.float32), torch.arange(S, dtype=torch.float32), indexing='ij')
+    dirs = torch.stack([(xs + 0.5 - S / 2) / fl, (ys + 0.5 - S / 2) / fl, torch.ones_like(xs)], -1)[None].repeat(nv, 1, 1, 1).cuda()
+    verts = (torch.from_numpy(v0).cuda() * 0.75).requires_grad_(True)
+    opt = torch.optim.Adam([verts], lr=4e-3)
+    hist = []
+    for it in range(40):
+        opt.zero_grad()
+        m, rgba, normal, depth = render(verts)
+        res = mesh_optim_loss(rgba, normal, depth.detach(), tgt_rgb, erode, tgt_m, dirs, torch.ones(nv, device='cuda'), target_n=normal_t,
+                              normal_reg_weight=1.0)
+        lap, nc = mesh_regularizers(verts, f, m.face_normals)
+        loss = res['loss'] + 5.0 * (lap + nc)
+        loss.backward()
+        assert torch.isfinite(verts.grad).all(), it
+        opt.step()
+        hist.append((float(res['alphas_loss']), float(res['pixel_rgb_loss']), float(lap), float(nc)))
+    print('mesh_optim loop (alpha, rgb, lap, nc): first', hist[0], 'last', hist[-1])
+    assert hist[-1][0] < 0.8 * hist[0][0], (hist[0], hist[-1])
