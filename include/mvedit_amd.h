@@ -272,6 +272,11 @@ MVE_API int mve_x0_prediction(const float* d_latents_scaled, const float* d_nois
  * exp2 of the result).  fp32, any shape (n elements); tables are device pointers. */
 MVE_API int mve_tonemap_lut(const float* d_x, size_t n, const float* d_lut_x, const float* d_lut_y, int steps, int inverse, int linear,
                             float* d_out, void* stream);
+/* Its backward: grad_x = grad_out * d lut / d x (the slope of the selected segment times the derivative of the log2 / exp2 around it) --
+ * the reference's lut / inverse_lut are differentiable torch expressions and sit inside the optimisation loops
+ * (lib/pipelines/mvedit_3d_pipeline.py:419-420, :438-439, :568-571). */
+MVE_API int mve_tonemap_lut_backward(const float* d_x, const float* d_grad_out, size_t n, const float* d_lut_x, const float* d_lut_y,
+                                     int steps, int inverse, int linear, float* d_grad_x, void* stream);
 /* Shading of a batch of rendered views in one pass (lib/pipelines/mvedit_3d_pipeline.py:1372-1384, same expression at :155-168):
  *   n_cv = (2 n0 - 1, 1 - 2 n1, 1 - 2 n2) from normal_fg;  shading = max(light_v . n_cv, 0) * (1 - ambient) + ambient;
  *   tables given : image = lut(inverse_lut(rgb / max(a, 1e-6)) + log2(max(shading, 1e-6))) * a + bg * (1 - a)

@@ -25,6 +25,16 @@ __global__ __launch_bounds__(NT) void k_lut(const float* __restrict__ v, size_t 
     out[i] = sh_lut(tx, ty, l.n, v[i], inverse, linear);
 }
 
+__global__ __launch_bounds__(NT) void k_lut_bwd(const float* __restrict__ v, const float* __restrict__ g_out, size_t n, Lut l, int inverse, int linear,
+                                                float* __restrict__ g_in) {
+    __shared__ float tx[MAX_STEPS], ty[MAX_STEPS];
+    if (threadIdx.x < l.n) { tx[threadIdx.x] = l.x[threadIdx.x]; ty[threadIdx.x] = l.y[threadIdx.x]; }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    g_in[i] = g_out[i] * sh_lut_grad(tx, ty, l.n, v[i], inverse, linear);
+}
+
 __global__ __launch_bounds__(NT) void k_shade_views(const float* __restrict__ rgba, const float* __restrict__ normal_fg,
                                                     const float* __restrict__ lights, unsigned n_views, unsigned pix, float ambient,
                                                     float bg, Lut l, float* __restrict__ image) {
@@ -45,6 +55,17 @@ int mve_tonemap_lut(const float* d_x, size_t n, const float* d_lut_x, const floa
     if (n == 0) return MVE_OK;
     MVE_CHECK(d_x && d_out && d_lut_x && d_lut_y && steps >= 2 && steps <= MAX_STEPS, MVE_ERR_ARG, "tonemap_lut: bad arguments (2 <= steps <= %d)", MAX_STEPS);
     k_lut<<<mve_cdiv(n, NT), NT, 0, (hipStream_t)stream>>>(d_x, n, Lut{d_lut_x, d_lut_y, steps}, inverse ? 1 : 0, linear ? 1 : 0, d_out);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_tonemap_lut_backward(const float* d_x, const float* d_grad_out, size_t n, const float* d_lut_x, const float* d_lut_y, int steps,
+                             int inverse, int linear, float* d_grad_x, void* stream) {
+    if (n == 0) return MVE_OK;
+    MVE_CHECK(d_x && d_grad_out && d_grad_x && d_lut_x && d_lut_y && steps >= 2 && steps <= MAX_STEPS, MVE_ERR_ARG,
+              "tonemap_lut_backward: bad arguments (2 <= steps <= %d)", MAX_STEPS);
+    k_lut_bwd<<<mve_cdiv(n, NT), NT, 0, (hipStream_t)stream>>>(d_x, d_grad_out, n, Lut{d_lut_x, d_lut_y, steps}, inverse ? 1 : 0, linear ? 1 : 0,
+                                                                d_grad_x);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

@@ -34,6 +34,23 @@ MVE_SH_FN float sh_lut(const float* tx, const float* ty, int n, float x, int inv
     return linear ? exp2f(r) : r;
 }
 
+// d sh_lut / d x (what torch autograd gives the reference's lut / inverse_lut: the slope of the selected segment, times the derivative of
+// the log2 / exp2 wrapped around it; clamp(min=1e-6) passes the gradient for x >= 1e-6)
+MVE_SH_FN float sh_lut_grad(const float* tx, const float* ty, int n, float x, int inverse, int linear) {
+    if (!inverse) {
+        float d = 1.0f;
+        if (linear) {
+            d = x >= 1e-6f ? 1.0f / (fmaxf(x, 1e-6f) * 0.69314718055994531f) : 0.0f;
+            x = log2f(fmaxf(x, 1e-6f));
+        }
+        const int i = sh_bucket(tx, n, x);
+        return d * ((ty[i] - ty[i - 1]) / (tx[i] - tx[i - 1]));
+    }
+    const int i = sh_bucket(ty, n, x);
+    const float slope = (tx[i] - tx[i - 1]) / (ty[i] - ty[i - 1]);
+    return linear ? exp2f(sh_interp(ty, tx, n, x)) * 0.69314718055994531f * slope : slope;
+}
+
 // one pixel of lib/pipelines/mvedit_3d_pipeline.py:1372-1384 (n = 0: `self.tonemapping is None`)
 MVE_SH_FN void sh_shade_pixel(const float* rgba, const float* normal_fg, const float* light, float ambient, float bg, const float* tx,
                               const float* ty, int n, float* out) {

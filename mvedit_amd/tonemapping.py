@@ -6,6 +6,31 @@ import torch
 from . import _lib
 
 
+class _LutFn(torch.autograd.Function):
+    """Tonemapping.lut / inverse_lut with the gradient torch autograd gives the reference's expressions (mve_tonemap_lut_backward)."""
+
+    @staticmethod
+    def forward(ctx, v, lut_x, lut_y, inverse, linear):
+        x = v.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call('mve_tonemap_lut', _lib.ptr(x), x.numel(), _lib.ptr(lut_x), _lib.ptr(lut_y), lut_x.numel(), int(inverse), int(linear),
+                      _lib.ptr(out), _lib.stream_ptr(x.device))
+        ctx.save_for_backward(x, lut_x, lut_y)
+        ctx.mode, ctx.dtype = (int(inverse), int(linear)), v.dtype
+        return out.to(v.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lut_x, lut_y = ctx.saved_tensors
+        g = g.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call('mve_tonemap_lut_backward', _lib.ptr(x), _lib.ptr(g), x.numel(), _lib.ptr(lut_x), _lib.ptr(lut_y), lut_x.numel(), ctx.mode[0],
+                      ctx.mode[1], _lib.ptr(out), _lib.stream_ptr(x.device))
+        return out.to(ctx.dtype), None, None, None, None
+
+
 class Tonemapping:
     def __init__(self, exposure=0.0, contrast=0.953, bias=0.088, sigmoid_gain=0.943, log_gain=0.011, lut_logx_min=-9, lut_logx_max=3,
                  lut_steps=16, device='cuda'):
@@ -33,13 +58,7 @@ class Tonemapping:
 
     def _run(self, v, inverse, linear):
         assert v.is_cuda, 'native path: CUDA tensors only'
-        dtype = v.dtype
-        x = v.to(torch.float32).contiguous()
-        out = torch.empty_like(x)
-        with torch.cuda.device(x.device):
-            _lib.call('mve_tonemap_lut', _lib.ptr(x), x.numel(), _lib.ptr(self.lut_x), _lib.ptr(self.lut_y), self.lut_x.numel(), int(inverse),
-                      int(linear), _lib.ptr(out), _lib.stream_ptr(x.device))
-        return out.to(dtype)
+        return _LutFn.apply(v, self.lut_x, self.lut_y, inverse, linear)       # differentiable w.r.t. v, like the reference's expressions
 
     def lut(self, x, input_mode='log'):
         assert input_mode in ['log', 'linear']

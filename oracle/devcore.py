@@ -13,6 +13,8 @@ _lib.dc_interpolate_backward_rast.argtypes = [_p, _i, _i, _i, _p, _i, _i, _i, _p
 _lib.dc_rasterize_backward.argtypes = [_p, _i, _i, _p, _i, _i, _i, _p, _p, _p]
 _lib.dc_antialias_backward_pos.argtypes = [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]
 _lib.dc_tonemap_lut.argtypes = [_p, _z, _p, _p, _i, _i, _i, _p]
+_lib.dc_tonemap_lut_grad.argtypes = [_p, _z, _p, _p, _i, _i, _i, _p]
+_lib.dc_tonemap_lut_grad.restype = None
 _lib.dc_shade_views.argtypes = [_p, _p, _p, _u, _u, _f, _f, _p, _p, _i, _p]
 for f in (_lib.dc_interpolate_backward_rast, _lib.dc_rasterize_backward, _lib.dc_antialias_backward_pos, _lib.dc_tonemap_lut, _lib.dc_shade_views):
     f.restype = None
@@ -62,6 +64,13 @@ def tonemap_lut(x, lut_x, lut_y, inverse=False, linear=False):
     x, lut_x, lut_y = _c(x), _c(lut_x), _c(lut_y)
     out = np.empty_like(x)
     _lib.dc_tonemap_lut(_ptr(x), x.size, _ptr(lut_x), _ptr(lut_y), lut_x.size, int(inverse), int(linear), _ptr(out))
+    return out
+
+
+def tonemap_lut_grad(x, lut_x, lut_y, inverse=False, linear=False):
+    x, lut_x, lut_y = _c(x), _c(lut_x), _c(lut_y)
+    out = np.empty_like(x)
+    _lib.dc_tonemap_lut_grad(_ptr(x), x.size, _ptr(lut_x), _ptr(lut_y), lut_x.size, int(inverse), int(linear), _ptr(out))
     return out
 
 

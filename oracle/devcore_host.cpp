@@ -46,6 +46,10 @@ void dc_tonemap_lut(const float* x, size_t n, const float* lut_x, const float* l
     for (size_t i = 0; i < n; ++i) out[i] = sh_lut(lut_x, lut_y, steps, x[i], inverse, linear);
 }
 
+void dc_tonemap_lut_grad(const float* x, size_t n, const float* lut_x, const float* lut_y, int steps, int inverse, int linear, float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = sh_lut_grad(lut_x, lut_y, steps, x[i], inverse, linear);
+}
+
 void dc_shade_views(const float* rgba, const float* normal_fg, const float* lights, unsigned n_views, unsigned pix, float ambient, float bg,
                     const float* lut_x, const float* lut_y, int steps, float* image) {
     for (size_t i = 0; i < (size_t)n_views * pix; ++i)

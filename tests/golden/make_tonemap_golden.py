@@ -28,6 +28,13 @@ def main():
     out.update(x_log=xlog.numpy(), x_lin=xlin.numpy(), y=yv.numpy(),
                lut_log=tm.lut(xlog).numpy(), lut_lin=tm.lut(xlin, input_mode='linear').numpy(),
                inv_log=tm.inverse_lut(yv).numpy(), inv_lin=tm.inverse_lut(yv, output_mode='linear').numpy())
+    # gradients of the four maps as torch autograd gives them for the reference's expressions (float64 leaves, away from the knots)
+    tm64 = mod.Tonemapping().double()
+    for key, src, fn in (('log', xlog[:4000], lambda v: tm64.lut(v)), ('lin', xlin, lambda v: tm64.lut(v, input_mode='linear')),
+                         ('inv_log', yv[:4000], lambda v: tm64.inverse_lut(v)), ('inv_lin', yv[:4000], lambda v: tm64.inverse_lut(v, output_mode='linear'))):
+        leaf = src.double().requires_grad_(True)
+        gr, = torch.autograd.grad(fn(leaf).sum(), leaf)
+        out['grad_' + key] = gr.numpy()
     # a rendered batch: 3 views of 20 x 24 pixels, alpha in [0, 1] with exact zeros and ones
     b, S1, S2 = 3, 20, 24
     alpha = torch.rand(1, b, S1, S2, 1, generator=g)

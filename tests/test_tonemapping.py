@@ -83,3 +83,32 @@ def test_shade_views_vs_reference_output(lib):
     lb = torch.nn.functional.normalize(torch.randn(6, 3, device='cuda'), dim=-1)
     full = shade_views(big, nfb, lb, 0.1, 1.0, Tonemapping())
     assert torch.isfinite(full).all() and torch.equal(full[:, 2:3], shade_views(big[:, 2:3], nfb[:, 2:3], lb[2:3], 0.1, 1.0, Tonemapping()))
+
+
+def test_lut_gradient_host_build_vs_reference_autograd():
+    """lut / inverse_lut sit inside the optimisation loops (mvedit_3d_pipeline.py:419-420, :568-571): their gradient must be the one torch
+    autograd gives the reference's expressions (golden: float64 autograd over the reference class).  Host build of sh_lut_grad, 2e-6."""
+    from oracle import devcore as D
+    for key, x, inv, lin in (('log', G['x_log'][:4000], 0, 0), ('lin', G['x_lin'], 0, 1), ('inv_log', G['y'][:4000], 1, 0), ('inv_lin', G['y'][:4000], 1, 1)):
+        got = D.tonemap_lut_grad(x, G['lut_x'], G['lut_y'], inv, lin)
+        ref = G['grad_' + key]
+        assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max(), key
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_hip_lut_is_differentiable_like_the_reference():
+    from mvedit_amd.tonemapping import Tonemapping
+    tm = Tonemapping(device='cuda')
+    for key, x, fn in (('log', G['x_log'][:4000], lambda v: tm.lut(v)), ('lin', G['x_lin'], lambda v: tm.lut(v, input_mode='linear')),
+                       ('inv_log', G['y'][:4000], lambda v: tm.inverse_lut(v)), ('inv_lin', G['y'][:4000], lambda v: tm.inverse_lut(v, output_mode='linear'))):
+        leaf = torch.from_numpy(x).float().cuda().requires_grad_(True)
+        gr, = torch.autograd.grad(fn(leaf).sum(), leaf)
+        ref = G['grad_' + key]
+        assert np.abs(gr.cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max(), key
+    # the shading expression of the loops, end to end through autograd: lut(inverse_lut(albedo) + log2(shading))
+    albedo = torch.rand(1000, 3, device='cuda').requires_grad_(True)
+    shading = (torch.rand(1000, 1, device='cuda') + 0.2).requires_grad_(True)
+    out = tm.lut(tm.inverse_lut(albedo) + shading.clamp(min=1e-6).log2())
+    ga, gs = torch.autograd.grad(out.sum(), (albedo, shading))
+    assert torch.isfinite(ga).all() and torch.isfinite(gs).all() and float(ga.abs().max()) > 0 and float(gs.abs().max()) > 0
