@@ -4,10 +4,18 @@ import torch
 from . import _lib
 
 
+def _inference_only(name, *tensors):
+    """Ops whose reference counterparts are differentiable torch expressions but which the optimisation loops never differentiate
+    (ssaa = 1 and dilate_edges = 0 there): refuse loudly instead of silently cutting the graph."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(f'{name}: native forward only -- no backward is built for it (call it under torch.no_grad())')
+
+
 def edge_dilation(img, mask, radius=3, iters=7):
     """Same signature and result as lib.ops.edge_dilation.edge_dilation: img (n,c,h,w), mask (n,1,h,w) -> dilated img."""
     if radius == 0 or iters == 0:
         return img
+    _inference_only('edge_dilation', img, mask)
     assert img.is_cuda and mask.is_cuda and img.dim() == 4 and mask.shape[1] == 1
     dtype = img.dtype
     x = img.float().contiguous()
@@ -212,6 +220,7 @@ def _texture_raw(tex, uv, rast=None):
 
 def box_downsample(x, factor):
     """interpolate_hwc(x, 1/factor) (mode='area') for x [..., H, W, C]."""
+    _inference_only('box_downsample', x)
     lead = x.shape[:-3]
     H, W, C = x.shape[-3:]
     x = x.float().contiguous()

@@ -73,6 +73,8 @@ def shade_views(rgba, normal_fg, cam_lights, ambient_light, bg_color, tonemappin
     """rgba [..., b, S, S, 4], normal_fg [..., b, S, S, 3] (as `BaseNeRF.render` returns them), cam_lights [b, 3] ->
     image [..., b, S, S, 3]: the reference's `image_batch` (mvedit_3d_pipeline.py:1372-1384) in one launch."""
     assert rgba.is_cuda and rgba.shape[-1] == 4 and normal_fg.shape[-1] == 3 and rgba.shape[:-1] == normal_fg.shape[:-1]
+    if torch.is_grad_enabled() and (rgba.requires_grad or normal_fg.requires_grad):
+        raise NotImplementedError('shade_views: render-step shading, forward only (the optimisation loops use recon_loss.nerf_optim_loss)')
     b = cam_lights.shape[0]
     lead = rgba.shape[:-1]
     n = rgba.numel() // 4
