@@ -264,3 +264,51 @@ def test_hip_timing_against_the_torch_statements_on_the_same_gpu(lib):
             fn()
         torch.cuda.synchronize()
         print(f'recon loss fwd+bwd, 8 x 128^2 rays, {name}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms')
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_nerf_optim_iteration_on_native_kernels_only(lib):
+    """The NeRF half of the reconstruct step wired together the way `nerf_optim` wires it (mvedit_3d_pipeline.py:507-633), every stage
+    native: VolumeRenderer training forward (march -> cull -> decode -> composite) -> nerf_optim_loss (shading, tone mapping, L1, TV,
+    entropy) -> backward through composite and the hash grid -> Adam on the decoder parameters.  The colour + alpha terms must fall and
+    every parameter gradient must be finite."""
+    from mvedit_amd.nerf import VolumeRenderer
+    from mvedit_amd.recon_loss import nerf_optim_loss
+    from mvedit_amd.tonemapping import Tonemapping
+    from oracle import raymarching as ORM
+    from scene import camera_rays as scene_rays, sphere_density_grid
+    from test_nerf import _decoder
+    _, dec = _decoder(12, 320, table_scale=0.1)
+    H, P, ps = 64, 2, 32
+    bits = torch.from_numpy(ORM.packbits(sphere_density_grid(H, radius=0.6), 0.5)).cuda()
+    o, d = scene_rays(P, ps, seed=5)                                              # view-major, row-major: one patch per view
+    o, d = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    dec.max_steps = 256
+    for t in dec.parameters().values():
+        t.requires_grad_(True)
+    vr = VolumeRenderer(dec)
+    vr.training = True
+    fl = ps / (2 * np.tan(np.deg2rad(15)))
+    ys, xs = torch.meshgrid(torch.arange(ps, dtype=torch.float32), torch.arange(ps, dtype=torch.float32), indexing='ij')
+    dirs = torch.stack([(xs + 0.5 - ps / 2) / fl, (ys + 0.5 - ps / 2) / fl, torch.ones_like(xs)], -1)[None].repeat(P, 1, 1, 1).cuda()
+    with torch.no_grad():
+        hit = vr.forward(o, d, bits, H)['weights_sum'].reshape(P, ps, ps, 1) > 0.0   # rays that meet the occupied sphere at all
+    target_m = hit.float()
+    target_rgbs = torch.tensor([0.8, 0.3, 0.2], device='cuda').expand(P, ps, ps, 3) * target_m + (1 - target_m)
+    tm = Tonemapping(device='cuda')
+    opt = torch.optim.Adam(list(dec.parameters().values()), lr=1e-2, eps=1e-15)
+    hist = []
+    for it in range(30):
+        opt.zero_grad()
+        out = vr.forward(o, d, bits, H, dt_gamma=0.0)
+        res = nerf_optim_loss(out['image'], out['weights_sum'], out['depth'], out['weights'], out['ts'][0], target_rgbs, target_m, dirs,
+                              torch.ones(P, device='cuda'), torch.nn.functional.normalize(torch.tensor([[0.3, -0.5, -1.0]] * P, device='cuda'), dim=-1),
+                              tonemapping=tm, shaded=True, normal_reg_weight=0.5, entropy_weight=0.2)
+        res['loss'].backward()
+        for k, t in dec.parameters().items():
+            assert t.grad is not None and torch.isfinite(t.grad).all(), (it, k)
+        opt.step()
+        hist.append((float(res['pixel_rgb_loss']), float(res['alphas_loss']), float(res['normal_reg_loss']), float(res['entropy_loss'])))
+    print('nerf_optim loop (rgb, alpha, tv, entropy): first', hist[0], 'last', hist[-1])
+    assert hist[-1][0] + hist[-1][1] < 0.7 * (hist[0][0] + hist[0][1]), (hist[0], hist[-1])
