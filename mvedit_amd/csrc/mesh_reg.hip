@@ -6,6 +6,7 @@
 // reference's own functions).  The atomics of the fill pass only decide the order inside a bucket BEFORE it is sorted; the loss sums
 // are fixed-order trees: the forward is bitwise reproducible.  The face-normal gradient is a float-atomic scatter (3 adds per face).
 #include "common.h"
+#include "reduce.h"
 #include "scan.h"
 
 #include "mesh_reg_core.h"
@@ -59,18 +60,6 @@ __global__ __launch_bounds__(NT) void k_mr_fill(const int32_t* __restrict__ face
     }
 }
 
-__device__ __forceinline__ float block_sum(float v, float* sh) {
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    const float r = sh[0];
-    __syncthreads();
-    return r;
-}
-
 __global__ __launch_bounds__(NT) void k_mr_vertex_fwd(const float* __restrict__ verts, int V, const float* __restrict__ face_normals, Ws w) {
     __shared__ float sh[NT];
     const int i = blockIdx.x * NT + threadIdx.x;
@@ -81,7 +70,7 @@ __global__ __launch_bounds__(NT) void k_mr_vertex_fwd(const float* __restrict__ 
         mr_sort(b, w.cnt[i]);
         lap = mr_vertex_fwd(i, b, w.cnt[i], verts, face_normals, w.u + 3 * i, &nc, &ne);
     }
-    const float s0 = block_sum(lap, sh), s1 = block_sum(nc, sh), s2 = block_sum((float)ne, sh);   // ne <= a few thousand per block: exact in f32
+    const float s0 = mve_block_sum<NT>(lap, sh), s1 = mve_block_sum<NT>(nc, sh), s2 = mve_block_sum<NT>((float)ne, sh);   // ne <= a few thousand per block: exact in f32
     if (threadIdx.x == 0) { w.part[blockIdx.x] = s0; w.part[w.nbv + blockIdx.x] = s1; w.ne_part[blockIdx.x] = (int)s2; }
 }
 
@@ -91,7 +80,7 @@ __global__ __launch_bounds__(NT) void k_mr_reduce(Ws w, int V, float* __restrict
     float a = 0.f, b = 0.f;
     int e = 0;
     for (unsigned c = threadIdx.x; c < w.nbv; c += NT) { a += w.part[c]; b += w.part[w.nbv + c]; e += w.ne_part[c]; }
-    const float lap = block_sum(a, sh), nc = block_sum(b, sh);
+    const float lap = mve_block_sum<NT>(a, sh), nc = mve_block_sum<NT>(b, sh);
     shi[threadIdx.x] = e;
     __syncthreads();
     for (int s = NT / 2; s > 0; s >>= 1) {

@@ -5,6 +5,7 @@
 // against the reference's own statements; this file only assigns pixels to threads and reduces the loss terms (fixed-order tree per
 // block, then one block over the partials: run-to-run deterministic).  Compiled without fma contraction, like the host build.
 #include "common.h"
+#include "reduce.h"
 
 #include "recon_loss_core.h"
 #include "mesh_loss_core.h"
@@ -37,19 +38,6 @@ __device__ __forceinline__ void load_lut(const RlParams& q, Lut l, float* tx, fl
     __syncthreads();
 }
 
-// fixed-order tree over the block; thread 0 returns the sum
-__device__ __forceinline__ float block_sum(float v, float* sh) {
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    const float r = sh[0];
-    __syncthreads();
-    return r;
-}
-
 __global__ __launch_bounds__(NT) void k_rl_xyz(int N, const float* __restrict__ depth, const float* __restrict__ alpha,
                                                const float* __restrict__ dir, float* __restrict__ xyz) {
     const int p = blockIdx.x * NT + threadIdx.x;
@@ -68,7 +56,7 @@ __global__ __launch_bounds__(NT) void k_rl_pixel(RlParams q, Lut l, MveReconLoss
                      d.d_patch_w, d.d_patch_lights, p, w.nfg, w.wfg, out_rgbs, out_normals, part);
     const int slot[4] = {0, 1, 3, 4};
     for (int k = 0; k < 4; ++k) {
-        const float s = block_sum(part[k], sh);
+        const float s = mve_block_sum<NT>(part[k], sh);
         if (threadIdx.x == 0) w.part[slot[k] * w.nb + blockIdx.x] = s;
     }
     if (threadIdx.x == 0) w.part[2 * w.nb + blockIdx.x] = 0.f;
@@ -80,7 +68,7 @@ __global__ __launch_bounds__(NT) void k_rl_tv(RlParams q, const float* __restric
     float v = 0.f;
     if (p < N && q.c_tv != 0.f)
         v = q.c_tv * rl_tv_term(w.nfg, w.wfg, tgt_n, q.ps, p / (q.ps * q.ps), (p / q.ps) % q.ps, p % q.ps, nullptr, nullptr, nullptr, nullptr);
-    const float s = block_sum(v, sh);
+    const float s = mve_block_sum<NT>(v, sh);
     if (threadIdx.x == 0)
         for (int k = 0; k < NPART; ++k) w.part[k * w.nb + w.nbp + blockIdx.x] = k == 2 ? s : 0.f;
 }
@@ -94,7 +82,7 @@ __global__ __launch_bounds__(NT) void k_rl_entropy(RlParams q, const float* __re
     float v = 0.f;
     if (i < M) v = rl_entropy_sample(q, weights[i], ts[2 * i + 1], gl, g_w ? g_w + i : nullptr);
     if (g_w) return;
-    const float s = block_sum(v, sh);
+    const float s = mve_block_sum<NT>(v, sh);
     if (threadIdx.x == 0)
         for (int k = 0; k < NPART; ++k) w.part[k * w.nb + 2 * w.nbp + blockIdx.x] = k == 4 ? s : 0.f;
 }
@@ -106,7 +94,7 @@ __global__ __launch_bounds__(NT) void k_rl_reduce(Ws w, float* __restrict__ loss
     for (int k = 0; k < NPART; ++k) {
         float v = 0.f;
         for (unsigned c = threadIdx.x; c < w.nb; c += NT) v += w.part[k * w.nb + c];
-        const float s = block_sum(v, sh);
+        const float s = mve_block_sum<NT>(v, sh);
         total += s;
         if (threadIdx.x == 0) losses[1 + k] = s;
     }
@@ -182,7 +170,7 @@ __global__ __launch_bounds__(NT) void k_ml_pixel(MlParams q, MveMeshLossDesc d, 
     if (p < N)
         ml_pixel_fwd(q, w.craw, d.d_rgba, d.d_normal, d.d_target_rgbs, d.d_target_m_erode, d.d_target_m_blur, d.d_view_w, p, w.cosp, w.alpha, w.nfg,
                      out_rgbs, out_normals, part);
-    const float s0 = block_sum(part[0], sh), s1 = block_sum(part[1], sh);
+    const float s0 = mve_block_sum<NT>(part[0], sh), s1 = mve_block_sum<NT>(part[1], sh);
     if (threadIdx.x == 0) { w.part[blockIdx.x] = s0; w.part[2 * w.nbp + blockIdx.x] = s1; w.part[4 * w.nbp + blockIdx.x] = 0.f; }
 }
 
@@ -192,7 +180,7 @@ __global__ __launch_bounds__(NT) void k_ml_tv(MlParams q, const float* __restric
     float v = 0.f;
     if (p < N && q.c_tv != 0.f)
         v = q.c_tv * rl_tv_term(w.nfg, w.alpha, tgt_n, q.S, p / (q.S * q.S), (p / q.S) % q.S, p % q.S, nullptr, nullptr, nullptr, nullptr);
-    const float s = block_sum(v, sh);
+    const float s = mve_block_sum<NT>(v, sh);
     if (threadIdx.x == 0) { w.part[w.nbp + blockIdx.x] = 0.f; w.part[3 * w.nbp + blockIdx.x] = 0.f; w.part[5 * w.nbp + blockIdx.x] = s; }
 }
 
@@ -203,7 +191,7 @@ __global__ __launch_bounds__(NT) void k_ml_reduce(MWs w, float* __restrict__ los
     for (int k = 0; k < 3; ++k) {
         float v = 0.f;
         for (unsigned c = threadIdx.x; c < 2 * w.nbp; c += NT) v += w.part[k * 2 * w.nbp + c];
-        const float s = block_sum(v, sh);
+        const float s = mve_block_sum<NT>(v, sh);
         total += s;
         if (threadIdx.x == 0) losses[1 + k] = s;
     }
