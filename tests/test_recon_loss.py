@@ -297,6 +297,10 @@ def test_nerf_optim_iteration_on_native_kernels_only(lib):
     target_m = hit.float()
     target_rgbs = torch.tensor([0.8, 0.3, 0.2], device='cuda').expand(P, ps, ps, 3) * target_m + (1 - target_m)
     tm = Tonemapping(device='cuda')
+    # the patch loss of :611-616 on top: LPIPS (bf16, synthetic VGG weights) over out_rgbs -- its gradient re-enters the native backward
+    from mvedit_amd.lpips import LPIPSEngine
+    from test_lpips import _case as lpips_case
+    lp = LPIPSEngine.from_state_dict({k: v.to(torch.bfloat16).float() for k, v in lpips_case()[0].items()}, torch.bfloat16)
     opt = torch.optim.Adam(list(dec.parameters().values()), lr=1e-2, eps=1e-15)
     hist = []
     for it in range(30):
@@ -305,7 +309,8 @@ def test_nerf_optim_iteration_on_native_kernels_only(lib):
         res = nerf_optim_loss(out['image'], out['weights_sum'], out['depth'], out['weights'], out['ts'][0], target_rgbs, target_m, dirs,
                               torch.ones(P, device='cuda'), torch.nn.functional.normalize(torch.tensor([[0.3, -0.5, -1.0]] * P, device='cuda'), dim=-1),
                               tonemapping=tm, shaded=True, normal_reg_weight=0.5, entropy_weight=0.2)
-        res['loss'].backward()
+        patch = lp(res['out_rgbs'].permute(0, 3, 1, 2), target_rgbs.permute(0, 3, 1, 2)).mean()
+        (res['loss'] + 0.3 * patch).backward()
         for k, t in dec.parameters().items():
             assert t.grad is not None and torch.isfinite(t.grad).all(), (it, k)
         opt.step()
