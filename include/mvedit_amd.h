@@ -277,6 +277,15 @@ MVE_API int mve_tonemap_lut(const float* d_x, size_t n, const float* d_lut_x, co
  * (lib/pipelines/mvedit_3d_pipeline.py:419-420, :438-439, :568-571). */
 MVE_API int mve_tonemap_lut_backward(const float* d_x, const float* d_grad_out, size_t n, const float* d_lut_x, const float* d_lut_y,
                                      int steps, int inverse, int linear, float* d_grad_x, void* stream);
+
+/* torchvision.transforms.functional.gaussian_blur on `planes` f32 images [H, W] (reflect padding by ksize / 2, normalised float32 kernel;
+ * evaluated separably) as the pipelines use it: target-mask blur (lib/pipelines/mvedit_3d_pipeline.py:473, :671) and `highpass`
+ * (lib/pipelines/utils.py:187-188: offset + x - blur(x, 6 round(std) + 1, std), applied to normal patches every iteration, :623-624).
+ *   d_base == NULL : out = blur(x)                 d_base != NULL : out = offset + base - blur(x)      (highpass: base = x)
+ *   adjoint != 0   : the transposed operator (backward of either form: pass the incoming gradient as x, and as base with offset 0
+ *                    for highpass).  tmp: planes * H * W floats, distinct from x and out; out may alias base. */
+MVE_API int mve_gaussian_blur(const float* d_x, int planes, int H, int W, int ksize, float sigma, int adjoint, const float* d_base,
+                              float offset, float* d_tmp, float* d_out, void* stream);
 /* Shading of a batch of rendered views in one pass (lib/pipelines/mvedit_3d_pipeline.py:1372-1384, same expression at :155-168):
  *   n_cv = (2 n0 - 1, 1 - 2 n1, 1 - 2 n2) from normal_fg;  shading = max(light_v . n_cv, 0) * (1 - ambient) + ambient;
  *   tables given : image = lut(inverse_lut(rgb / max(a, 1e-6)) + log2(max(shading, 1e-6))) * a + bg * (1 - a)

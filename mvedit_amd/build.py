@@ -35,6 +35,7 @@ EXTRA_FLAGS = {
     'shading.hip': ['-ffp-contract=off'],
     'recon_loss.hip': ['-ffp-contract=off'],
     'mesh_reg.hip': ['-ffp-contract=off'],
+    'blur.hip': ['-ffp-contract=off'],
 }
 
 

@@ -50,3 +50,44 @@ def prune_cameras(dists, num_keep_views, max_num_cameras, device, pixel_dist=Non
         if pixel_dist is not None:
             pixel_dist = pixel_dist[mask]
     return keep_ids, dists
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# torchvision's gaussian_blur and the reference's `highpass` (lib/pipelines/utils.py:187-188) on the native separable kernel
+# (csrc/blur.hip), differentiable w.r.t. the image like the torch expressions they replace.  CUDA tensors only: no fallback.
+class _BlurFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ksize, sigma, highpass_offset):
+        from .. import _lib
+        assert x.is_cuda and x.dim() >= 2, 'native path: CUDA tensors [..., H, W]'
+        xf = x.detach().to(torch.float32).contiguous()
+        H, W = xf.shape[-2:]
+        out, tmp = torch.empty_like(xf), torch.empty_like(xf)
+        hp = highpass_offset is not None
+        with torch.cuda.device(xf.device):
+            _lib.call('mve_gaussian_blur', _lib.ptr(xf), xf.numel() // (H * W), H, W, int(ksize), float(sigma), 0, _lib.ptr(xf) if hp else None,
+                      float(highpass_offset or 0.0), _lib.ptr(tmp), _lib.ptr(out), _lib.stream_ptr(xf.device))
+        ctx.args, ctx.dtype = (int(ksize), float(sigma), hp), x.dtype
+        return out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib
+        ksize, sigma, hp = ctx.args
+        gf = g.detach().to(torch.float32).contiguous()
+        H, W = gf.shape[-2:]
+        out, tmp = torch.empty_like(gf), torch.empty_like(gf)
+        with torch.cuda.device(gf.device):
+            _lib.call('mve_gaussian_blur', _lib.ptr(gf), gf.numel() // (H * W), H, W, ksize, sigma, 1, _lib.ptr(gf) if hp else None, 0.0,
+                      _lib.ptr(tmp), _lib.ptr(out), _lib.stream_ptr(gf.device))
+        return out.to(ctx.dtype), None, None, None
+
+
+def gaussian_blur(img, kernel_size, sigma):
+    """torchvision.transforms.functional.gaussian_blur(img [..., H, W], kernel_size (odd int), sigma (float)); reflect padding."""
+    return _BlurFn.apply(img, kernel_size, sigma, None)
+
+
+def highpass(x, std=5, offset=0.5):
+    """lib/pipelines/utils.py:187-188: offset + x - gaussian_blur(x, int(round(std)) * 6 + 1, std), one fused pass pair"""
+    return _BlurFn.apply(x, int(round(std)) * 6 + 1, std, float(offset))

@@ -27,6 +27,8 @@ _lib.dc_mesh_loss.argtypes = [_i, _i, _i, _p, _f, _f] + [_p] * 11 + [_f] + [_p] 
 _lib.dc_mesh_loss.restype = None
 _lib.dc_mesh_normals.argtypes = [_p, _i, _p, _i] + [_p] * 7
 _lib.dc_mesh_normals.restype = None
+_lib.dc_gaussian_blur.argtypes = [_p, _i, _i, _i, _i, _f, _i, _p, _f, _p]
+_lib.dc_gaussian_blur.restype = None
 _lib.dc_mesh_reg.argtypes = [_p, _i, _p, _i, _p, _f, _f, _p, _p, _p, _p]
 _lib.dc_mesh_reg.restype = None
 
@@ -149,3 +151,13 @@ def mesh_normals(verts, faces, g_vn=None, g_face_normals=None):
     gs, gv = np.zeros_like(verts), np.zeros_like(verts)
     _lib.dc_mesh_normals(_ptr(verts), verts.shape[0], _ptr(faces), faces.shape[0], _ptr(g_vn), _ptr(g_fn), _ptr(fn), _ptr(vs), _ptr(vn), _ptr(gs), _ptr(gv))
     return dict(face_normals=fn, vn=vn, g_verts=gv)
+
+
+def gaussian_blur(x, ksize, sigma, adjoint=False, base=None, offset=0.0):
+    """Host run of blur_core.h: x [..., H, W] -> blur (or its adjoint); base given: offset + base - blur(x) (highpass and its backward)."""
+    x = _c(x)
+    H, W = x.shape[-2:]
+    out = np.empty_like(x)
+    b = None if base is None else _c(base)
+    _lib.dc_gaussian_blur(_ptr(x), x.size // (H * W), H, W, int(ksize), float(sigma), int(adjoint), _ptr(b), float(offset), _ptr(out))
+    return out

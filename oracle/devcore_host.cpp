@@ -10,6 +10,7 @@
 #include "../mvedit_amd/csrc/recon_loss_core.h"
 #include "../mvedit_amd/csrc/mesh_reg_core.h"
 #include "../mvedit_amd/csrc/mesh_loss_core.h"
+#include "../mvedit_amd/csrc/blur_core.h"
 #include <vector>
 
 extern "C" {
@@ -161,6 +162,25 @@ void dc_mesh_normals(const float* verts, int V, const int32_t* faces, int F, con
         mr_normalize_bwd(vn_sum + 3 * i, g_vn ? g_vn + 3 * i : zero, g_sum + 3 * i);
     }
     for (int t = 0; t < F; ++t) mr_normals_face_bwd(verts, faces, t, g_fn_ext, g_sum, g_verts);
+}
+
+// gaussian blur of `planes` images [H, W] (rows then columns, as blur.hip), or its adjoint; base != NULL: out = offset + base - blur (highpass)
+void dc_gaussian_blur(const float* x, int planes, int H, int W, int ksize, float sigma, int adjoint, const float* base, float offset, float* out) {
+    std::vector<float> w(ksize), tmp((size_t)H * W);
+    bl_kernel1d(ksize, sigma, w.data());
+    const int r = ksize / 2;
+    for (int p = 0; p < planes; ++p) {
+        const float* xp = x + (size_t)p * H * W;
+        for (int y = 0; y < H; ++y)
+            for (int c = 0; c < W; ++c)
+                tmp[(size_t)y * W + c] = adjoint ? bl_adj1d(xp + (size_t)y * W, W, 1, w.data(), r, c) : bl_fwd1d(xp + (size_t)y * W, W, 1, w.data(), r, c);
+        for (int y = 0; y < H; ++y)
+            for (int c = 0; c < W; ++c) {
+                const float b = adjoint ? bl_adj1d(tmp.data() + c, H, W, w.data(), r, y) : bl_fwd1d(tmp.data() + c, H, W, w.data(), r, y);
+                const size_t i = (size_t)p * H * W + (size_t)y * W + c;
+                out[i] = base ? offset + base[i] - b : b;
+            }
+    }
 }
 
 }  // extern "C"

@@ -135,3 +135,13 @@ def test_mesh_loss_descriptor_checks(L):
     _bad(lib, 'mve_mesh_loss_forward', ctypes.byref(desc(d_depth=None)), p, 1 << 20, p, p, p, None, match='null pointer')
     _bad(lib, 'mve_mesh_loss_forward', ctypes.byref(desc()), p, 64, p, p, p, None, match='workspace')
     _bad(lib, 'mve_mesh_loss_backward', ctypes.byref(desc()), p, 1 << 20, None, None, None, None, p, None, match='null output')
+
+
+def test_gaussian_blur_argument_checks(L):
+    lib, p, buf = L
+    q = ctypes.c_void_p(buf.data_ptr() + 4096)
+    o = ctypes.c_void_p(buf.data_ptr() + 8192)
+    _bad(lib, 'mve_gaussian_blur', p, 1, 64, 64, 30, 5.0, 0, None, 0.0, q, o, None, match='odd')
+    _bad(lib, 'mve_gaussian_blur', p, 1, 64, 64, 31, 0.0, 0, None, 0.0, q, o, None, match='sigma')
+    _bad(lib, 'mve_gaussian_blur', p, 1, 12, 64, 31, 5.0, 0, None, 0.0, q, o, None, match='reflect padding')
+    _bad(lib, 'mve_gaussian_blur', p, 1, 64, 64, 31, 5.0, 0, None, 0.0, p, o, None, match='alias')

@@ -16,3 +16,4 @@ run attention_variant tests/test_unet_ops.py -k "experimental_variant or conflic
 run recon_loss tests/test_recon_loss.py
 run mesh_reg tests/test_mesh_reg.py
 run mesh_loss tests/test_mesh_loss.py
+run blur tests/test_blur.py
