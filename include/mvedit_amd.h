@@ -286,6 +286,13 @@ MVE_API int mve_tonemap_lut_backward(const float* d_x, const float* d_grad_out, 
  *                    for highpass).  tmp: planes * H * W floats, distinct from x and out; out may alias base. */
 MVE_API int mve_gaussian_blur(const float* d_x, int planes, int H, int W, int ksize, float sigma, int adjoint, const float* d_base,
                               float offset, float* d_tmp, float* d_out, void* stream);
+
+/* lib/ops/shencoder (src/shencoder.cu:28-337, :359-384; sphere_harmonics.py): real spherical harmonics of inputs [B,3] f32 up to `degree`
+ * (1..8) -> outputs [B, degree^2], index l^2 + l + m, Condon-Shortley phase, the un-normalised polynomial form (equal to Y_lm on the unit
+ * sphere); dy_dx (nullable) [B, 3, degree^2] = d outputs / d (x, y, z).  Backward: grad_inputs [B,3] = sum_ch grad[b][ch] dy_dx[b][d][ch]
+ * (written, not accumulated: the reference's wrapper hands in zeros). */
+MVE_API int mve_sh_encode(const float* d_inputs, uint32_t B, int degree, float* d_outputs, float* d_dy_dx, void* stream);
+MVE_API int mve_sh_encode_backward(const float* d_grad, const float* d_dy_dx, uint32_t B, int degree, float* d_grad_inputs, void* stream);
 /* Shading of a batch of rendered views in one pass (lib/pipelines/mvedit_3d_pipeline.py:1372-1384, same expression at :155-168):
  *   n_cv = (2 n0 - 1, 1 - 2 n1, 1 - 2 n2) from normal_fg;  shading = max(light_v . n_cv, 0) * (1 - ambient) + ambient;
  *   tables given : image = lut(inverse_lut(rgb / max(a, 1e-6)) + log2(max(shading, 1e-6))) * a + bg * (1 - a)

@@ -36,6 +36,7 @@ EXTRA_FLAGS = {
     'recon_loss.hip': ['-ffp-contract=off'],
     'mesh_reg.hip': ['-ffp-contract=off'],
     'blur.hip': ['-ffp-contract=off'],
+    'sh.hip': ['-ffp-contract=off'],
 }
 
 

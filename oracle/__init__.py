@@ -30,7 +30,7 @@ def build_devcore(force=False):
     per-pixel arithmetic of kernels whose first GPU run is pending."""
     src = os.path.join(HERE, 'devcore_host.cpp')
     core = os.path.join(os.path.dirname(HERE), 'mvedit_amd', 'csrc')
-    deps = [src] + [os.path.join(core, h) for h in ('raster_grad_core.h', 'shading_core.h', 'recon_loss_core.h', 'mesh_reg_core.h', 'mesh_loss_core.h', 'blur_core.h')]
+    deps = [src] + [os.path.join(core, h) for h in ('raster_grad_core.h', 'shading_core.h', 'recon_loss_core.h', 'mesh_reg_core.h', 'mesh_loss_core.h', 'blur_core.h', 'sh_core.h')]
     if force or not os.path.exists(DEVCORE) or any(os.path.getmtime(d) > os.path.getmtime(DEVCORE) for d in deps):
         subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-Wall', '-shared', '-o', DEVCORE, src, '-lm'],
                        check=True, capture_output=True)

@@ -31,11 +31,38 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, '_ref')
 REF_SRC = '/root/reference/lib/ops/raymarching/src'
 NAME = '_raymarching_ref'
+# the reference's second native op, lib/ops/shencoder (pins csrc/sh.hip the same way: tests/test_shencoder.py)
+SH_SRC = '/root/reference/lib/ops/shencoder/src'
+SH_NAME = '_shencoder_ref'
 
 
-def built_module_path():
-    hits = glob.glob(os.path.join(OUT, NAME + '*.so'))
+def built_module_path(name=NAME):
+    hits = glob.glob(os.path.join(OUT, name + '*.so'))
     return hits[0] if hits else None
+
+
+def build_shencoder(verbose=False):
+    """same recipe for lib/ops/shencoder/src/{shencoder.cu,bindings.cpp} (lib/ops/shencoder/backend.py)"""
+    if not os.path.isdir(SH_SRC) or built_module_path(SH_NAME):
+        return built_module_path(SH_NAME)
+    os.environ.setdefault('PYTORCH_ROCM_ARCH', 'gfx950')
+    from torch.utils.cpp_extension import load
+    os.makedirs(OUT, exist_ok=True)
+    stage = tempfile.mkdtemp(prefix='mve_ref_stage_')
+    build_dir = tempfile.mkdtemp(prefix='mve_ref_build_')
+    try:
+        for f in ('shencoder.cu', 'shencoder.h', 'bindings.cpp'):
+            shutil.copy(os.path.join(SH_SRC, f), os.path.join(stage, f))
+        load(name=SH_NAME, sources=[os.path.join(stage, 'shencoder.cu'), os.path.join(stage, 'bindings.cpp')],
+             extra_cflags=['-O3', '-std=c++17'], extra_cuda_cflags=['-O3', '-std=c++17', '-ffp-contract=off'],
+             build_directory=build_dir, verbose=verbose, is_python_module=False)
+        so = glob.glob(os.path.join(build_dir, SH_NAME + '*.so'))
+        assert so, 'extension build produced no .so'
+        shutil.copy(so[0], os.path.join(OUT, os.path.basename(so[0])))
+    finally:
+        shutil.rmtree(stage, ignore_errors=True)
+        shutil.rmtree(build_dir, ignore_errors=True)
+    return built_module_path(SH_NAME)
 
 
 def build(verbose=False):
@@ -65,14 +92,14 @@ def build(verbose=False):
     return built_module_path()
 
 
-def load_module():
+def load_module(name=NAME):
     """Import the prebuilt reference extension (requires a GPU process with torch imported)."""
     import importlib.util
     import torch  # noqa: F401
-    path = built_module_path()
+    path = built_module_path(name)
     if path is None:
         return None
-    spec = importlib.util.spec_from_file_location(NAME, path)
+    spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -80,3 +107,4 @@ def load_module():
 
 if __name__ == '__main__':
     print(build(verbose='-v' in sys.argv))
+    print(build_shencoder(verbose='-v' in sys.argv))

@@ -29,6 +29,8 @@ _lib.dc_mesh_normals.argtypes = [_p, _i, _p, _i] + [_p] * 7
 _lib.dc_mesh_normals.restype = None
 _lib.dc_gaussian_blur.argtypes = [_p, _i, _i, _i, _i, _f, _i, _p, _f, _p]
 _lib.dc_gaussian_blur.restype = None
+_lib.dc_sh_encode.argtypes = [_p, _i, _i, _p, _p]
+_lib.dc_sh_encode.restype = None
 _lib.dc_mesh_reg.argtypes = [_p, _i, _p, _i, _p, _f, _f, _p, _p, _p, _p]
 _lib.dc_mesh_reg.restype = None
 
@@ -161,3 +163,13 @@ def gaussian_blur(x, ksize, sigma, adjoint=False, base=None, offset=0.0):
     b = None if base is None else _c(base)
     _lib.dc_gaussian_blur(_ptr(x), x.size // (H * W), H, W, int(ksize), float(sigma), int(adjoint), _ptr(b), float(offset), _ptr(out))
     return out
+
+
+def sh_encode(xyz, degree, jacobian=False):
+    """Host run of sh_core.h -> out [B, degree^2] (and jac [B, 3, degree^2])"""
+    xyz = _c(xyz)
+    B = xyz.shape[0]
+    out = np.zeros((B, degree * degree), np.float32)
+    jac = np.zeros((B, 3, degree * degree), np.float32) if jacobian else None
+    _lib.dc_sh_encode(_ptr(xyz), B, int(degree), _ptr(out), _ptr(jac))
+    return (out, jac) if jacobian else out

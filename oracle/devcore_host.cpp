@@ -11,6 +11,7 @@
 #include "../mvedit_amd/csrc/mesh_reg_core.h"
 #include "../mvedit_amd/csrc/mesh_loss_core.h"
 #include "../mvedit_amd/csrc/blur_core.h"
+#include "../mvedit_amd/csrc/sh_core.h"
 #include <vector>
 
 extern "C" {
@@ -181,6 +182,13 @@ void dc_gaussian_blur(const float* x, int planes, int H, int W, int ksize, float
                 out[i] = base ? offset + base[i] - b : b;
             }
     }
+}
+
+void dc_sh_encode(const float* xyz, int B, int degree, float* out, float* jac) {
+    float k[MVE_SH_MAX_DEGREE * MVE_SH_MAX_DEGREE];
+    she_constants(k);
+    const int C2 = degree * degree;
+    for (int b = 0; b < B; ++b) she_eval(k, xyz[3 * b], xyz[3 * b + 1], xyz[3 * b + 2], degree, out + (size_t)b * C2, jac ? jac + (size_t)b * 3 * C2 : nullptr);
 }
 
 }  // extern "C"

@@ -145,3 +145,11 @@ def test_gaussian_blur_argument_checks(L):
     _bad(lib, 'mve_gaussian_blur', p, 1, 64, 64, 31, 0.0, 0, None, 0.0, q, o, None, match='sigma')
     _bad(lib, 'mve_gaussian_blur', p, 1, 12, 64, 31, 5.0, 0, None, 0.0, q, o, None, match='reflect padding')
     _bad(lib, 'mve_gaussian_blur', p, 1, 64, 64, 31, 5.0, 0, None, 0.0, p, o, None, match='alias')
+
+
+def test_sh_encode_argument_checks(L):
+    lib, p, _ = L
+    _bad(lib, 'mve_sh_encode', p, 16, 9, p, None, None, match='degree')
+    _bad(lib, 'mve_sh_encode', p, 16, 0, p, None, None, match='degree')
+    _bad(lib, 'mve_sh_encode', None, 16, 4, p, None, None, match='null pointer')
+    _bad(lib, 'mve_sh_encode_backward', p, None, 16, 4, p, None, match='null pointer')

@@ -17,3 +17,4 @@ run recon_loss tests/test_recon_loss.py
 run mesh_reg tests/test_mesh_reg.py
 run mesh_loss tests/test_mesh_loss.py
 run blur tests/test_blur.py
+run shencoder tests/test_shencoder.py
