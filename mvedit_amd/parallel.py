@@ -62,3 +62,29 @@ def repartition(per_view, old_num, keep_ids, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = partition_views(len(keep_ids), world, rank)
     return kept[lo:hi].contiguous()
+
+
+def sync_scene(tensors, src=0, group=None):
+    """Re-align the replicated scene (hash table, MLP weights, density grid / bitfield, or SDF / deformation / texture) with rank `src`.
+
+    The 3D update is replicated, not sharded, and several of its backward kernels scatter with float atomics (hash-table gradient, texture
+    and vertex-attribute gradients, vertex-normal splat), as tiny-cuda-nn / nvdiffrast do in the reference: the ranks' scenes agree to
+    rounding after one iteration, not bitwise, and hundreds of optimiser iterations per denoise step would let them drift apart.  One
+    broadcast per outer step of the whole scene (about 52 MiB for the hash grid + 4 MiB of density grid: well under a millisecond over
+    xGMI) removes the drift at its source.  ONE collective per dtype: the tensors are coalesced into a flat buffer and copied back in place.
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), ts in by_dtype.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        with torch.no_grad():
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+    return tensors

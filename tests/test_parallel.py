@@ -98,3 +98,30 @@ def _prune_worker(rank, world, port):
 
 def test_prune_then_repartition_gloo():
     mp.spawn(_prune_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _sync_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mvedit_amd.parallel import sync_scene
+        g = torch.Generator().manual_seed(7)
+        base = [torch.rand(1000, 2, generator=g), torch.rand(16, 64, generator=g), torch.randint(0, 255, (4096,), generator=g, dtype=torch.uint8),
+                torch.rand(33, generator=g).half()]
+        # every rank's replica has drifted by its own rounding-sized perturbation, as float-atomic gradients make it
+        mine = [t.clone() if t.dtype == torch.uint8 else t + (rank * 1e-4) for t in base]
+        mine[2] = (mine[2].int() + rank).clamp(max=255).to(torch.uint8)
+        ptrs = [t.data_ptr() for t in mine]
+        out = sync_scene(mine, src=0)
+        assert all(o.data_ptr() == p for o, p in zip(out, ptrs))                      # in place: optimiser state keeps pointing at them
+        for o, b in zip(out, base):
+            assert torch.equal(o, b), (rank, o.dtype)                                  # every rank now holds rank 0's scene bit for bit
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_scene_gloo():
+    mp.spawn(_sync_worker, args=(3, _free_port()), nprocs=3, join=True)
+    from mvedit_amd.parallel import sync_scene
+    t = [torch.ones(3)]
+    assert sync_scene(t) is t                                                          # no process group: a no-op
