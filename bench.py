@@ -249,6 +249,9 @@ def main():
     del sd
     if os.environ.get('MVE_BENCH_GRAPH') == '1':          # experiment: hipGraph replay of the forward (off by default)
         eng.enable_graph(True)
+        side = torch.cuda.Stream(dev)                      # stream capture is not allowed on the legacy default stream
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(side)
     g = torch.Generator().manual_seed(0)
     latents_all = torch.randn(V, 4, LATENT, LATENT, generator=g)
     ctx_uncond = torch.randn(1, CTX_LEN, cfg['cross_attention_dim'], generator=g)

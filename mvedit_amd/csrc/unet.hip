@@ -438,6 +438,8 @@ int mve_unet_forward(void* handle, int phase, const void* d_sample, int io_dtype
     const size_t lo = phase == 2 ? pl.enc_end : 0, hi = phase == 1 ? pl.enc_end : pl.ops.size();
     if (u->graph_mode && !op_ms) {
         // hipGraph replay (opt-in): identical plan + pointers as an earlier call -> capture on the second sighting, replay afterwards
+        MVE_CHECK(stream != nullptr, MVE_ERR_ARG,
+                  "unet_forward: hipGraph replay cannot capture the legacy default stream -- run under a non-default stream (torch.cuda.stream(...))");
         std::vector<const void*> key = {d_sample, d_timesteps, d_ctx, d_out, d_workspace, d_mid_residual, u->ref_store, stream};
         if (has_res) for (int i = 0; i < u->cfg.n_levels * (u->cfg.layers_per_block + 1); ++i) key.push_back(down_residuals[i]);
         Unet::GraphEntry* ge = nullptr;

@@ -13,6 +13,7 @@ run tonemapping tests/test_tonemapping.py
 run mesh_grad tests/test_mesh_grad.py
 run lpips tests/test_lpips.py
 run attention_variant tests/test_unet_ops.py -k "experimental_variant or conflict_free or vt_store_swizzle"
+run graph_replay tests/test_unet.py -k graph_replay
 run recon_loss tests/test_recon_loss.py
 run mesh_reg tests/test_mesh_reg.py
 run mesh_loss tests/test_mesh_loss.py

@@ -21,6 +21,9 @@ for n_gpu in (1, 2, 4, 8):
 # same sweep with the opt-in hipGraph replay (mve_unet_graph): the forward is captured on its second call with identical tensors
 if '--graph' in sys.argv:
     eng.enable_graph(True)
+    side = torch.cuda.Stream()                     # stream capture is not allowed on the legacy default stream
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(side)
     for n_gpu in (1, 2, 4, 8):
         B = 64 // n_gpu
         x = torch.randn(B, 4, 64, 64, device='cuda', dtype=torch.float16)
