@@ -7,7 +7,7 @@ export MVE_RUN_PENDING=1
 run() {   # run <log name> <pytest args...>
     local name=$1; shift
     echo "== $name"
-    timeout 120 python -m pytest "$@" -q -m gpu -p no:cacheprovider -s 2>&1 | tail -25 | tee "gpurun_out/pending_${name}.log" | grep -E "passed|failed|^E  |rel|engine|^FAILED| ms$|loop" | head -20
+    timeout 120 python -m pytest "$@" -q -m gpu -p no:cacheprovider -s 2>&1 | tail -25 | tee "gpurun_out/pending_${name}.log" | grep -E "passed|failed|^E  |rel|engine|^FAILED| ms$|loop|reference kernel" | head -20
 }
 run tonemapping tests/test_tonemapping.py
 run mesh_grad tests/test_mesh_grad.py
