@@ -407,3 +407,56 @@ def test_engine_graph_replay_equals_eager(lib):
     side.synchronize()
     eng.enable_graph(False)
     assert torch.equal(o2, eng(xs, t, cs)[0]) and not torch.equal(o2, eager)
+
+
+def test_oracle_blocks_against_torch_modules():
+    """The UNet oracle's block arithmetic is third-party (diffusers 0.27.2, absent): UNPINNED.  As for the VAE, cross-check it against the
+    same blocks assembled INDEPENDENTLY from torch.nn modules and F.scaled_dot_product_attention (ResnetBlock2D: GroupNorm-SiLU-conv /
+    time projection / GroupNorm-SiLU-conv / 1x1 shortcut; Transformer2DModel with one BasicTransformerBlock: GroupNorm(eps 1e-6), 1x1
+    proj_in, LayerNorm + self-attention, LayerNorm + cross-attention, LayerNorm + GEGLU feed-forward, proj_out, residual) loaded with the
+    oracle's state-dict names, and the sinusoidal time embedding against its closed form in float64."""
+    nn = torch.nn
+    cfg = U.TINY
+    sd = U.make_state_dict(cfg, seed=5)
+    c = U._Ctx(sd, cfg, None, None)
+    g = torch.Generator().manual_seed(0)
+    # ---- time embedding: [cos(t w_k), sin(t w_k)], w_k = 10000^(-k / half)
+    t = torch.tensor([0.0, 3.0, 499.0, 999.0])
+    k = torch.arange(160, dtype=torch.float64)
+    ang = t.double()[:, None] * torch.pow(torch.tensor(10000.0, dtype=torch.float64), -k / 160)[None]
+    assert (U.timestep_embedding(t, 320).double() - torch.cat([ang.cos(), ang.sin()], -1)).abs().max() < 2e-4      # fp32 angles up to 999 rad
+    # ---- ResnetBlock2D with channel change (down_blocks.1.resnets.0: 320 -> 640)
+    p = 'down_blocks.1.resnets.0'
+    cin, cout = sd[p + '.conv1.weight'].shape[1], sd[p + '.conv1.weight'].shape[0]
+    mods = dict(norm1=nn.GroupNorm(32, cin, eps=1e-5), conv1=nn.Conv2d(cin, cout, 3, padding=1), time_emb_proj=nn.Linear(1280, cout),
+                norm2=nn.GroupNorm(32, cout, eps=1e-5), conv2=nn.Conv2d(cout, cout, 3, padding=1), conv_shortcut=nn.Conv2d(cin, cout, 1))
+    for name, m in mods.items():
+        m.load_state_dict({kk: sd[f'{p}.{name}.{kk}'] for kk in ('weight', 'bias')})
+    x, temb = torch.randn(2, cin, 8, 8, generator=g), torch.randn(2, 1280, generator=g)
+    with torch.no_grad():
+        h = mods['conv1'](nn.functional.silu(mods['norm1'](x))) + mods['time_emb_proj'](nn.functional.silu(temb))[:, :, None, None]
+        ref = mods['conv_shortcut'](x) + mods['conv2'](nn.functional.silu(mods['norm2'](h)))
+        assert (U._resnet(c, p, x, temb) - ref).abs().max() < 1e-4 * ref.abs().max()
+    # ---- Transformer2DModel (down_blocks.0.attentions.0: 320 channels, 8 heads of 40, text context 768)
+    p, C, heads = 'down_blocks.0.attentions.0', 320, 8
+    b = p + '.transformer_blocks.0'
+    lin = lambda name, bias=True: (lambda v: nn.functional.linear(v, sd[name + '.weight'], sd[name + '.bias'] if bias else None))
+    ln = lambda name: (lambda v: nn.functional.layer_norm(v, (C,), sd[name + '.weight'], sd[name + '.bias'], 1e-5))
+
+    def attn(prefix, q_in, kv_in):
+        split = lambda v: v.view(v.shape[0], v.shape[1], heads, C // heads).transpose(1, 2)
+        o = nn.functional.scaled_dot_product_attention(split(lin(prefix + '.to_q', False)(q_in)), split(lin(prefix + '.to_k', False)(kv_in)),
+                                                       split(lin(prefix + '.to_v', False)(kv_in)))
+        return lin(prefix + '.to_out.0')(o.transpose(1, 2).reshape(q_in.shape))
+    x, ctx = torch.randn(2, C, 8, 8, generator=g), torch.randn(2, 77, 768, generator=g)
+    with torch.no_grad():
+        gn = nn.GroupNorm(32, C, eps=1e-6)
+        gn.load_state_dict({kk: sd[f'{p}.norm.{kk}'] for kk in ('weight', 'bias')})
+        hcl = nn.functional.conv2d(gn(x), sd[p + '.proj_in.weight'], sd[p + '.proj_in.bias']).permute(0, 2, 3, 1).reshape(2, 64, C)
+        hcl = hcl + attn(b + '.attn1', ln(b + '.norm1')(hcl), ln(b + '.norm1')(hcl))
+        hcl = hcl + attn(b + '.attn2', ln(b + '.norm2')(hcl), ctx)
+        val, gate = lin(b + '.ff.net.0.proj')(ln(b + '.norm3')(hcl)).chunk(2, dim=-1)
+        hcl = hcl + lin(b + '.ff.net.2')(val * nn.functional.gelu(gate))
+        ref = nn.functional.conv2d(hcl.reshape(2, 8, 8, C).permute(0, 3, 1, 2), sd[p + '.proj_out.weight'], sd[p + '.proj_out.bias']) + x
+        got = U._transformer(c, p, x, ctx, heads, 1, 1)
+        assert (got - ref).abs().max() < 2e-4 * ref.abs().max()
