@@ -91,3 +91,23 @@ def gaussian_blur(img, kernel_size, sigma):
 def highpass(x, std=5, offset=0.5):
     """lib/pipelines/utils.py:187-188: offset + x - gaussian_blur(x, int(round(std)) * 6 + 1, std), one fused pass pair"""
     return _BlurFn.apply(x, int(round(std)) * 6 + 1, std, float(offset))
+
+
+def init_tet(decoder, tet_vertices, tet_indices, density_thresh=5.0):
+    """NeRF -> DMTet hand-over (lib/pipelines/utils.py:156-184 `init_tet`; once per request, when the loop switches to the mesh stage):
+    scale the tetrahedral grid to the bounding box of the NeRF's occupied region and initialise the SDF from its density.
+
+    decoder: anything with `point_decode(xyzs [N,3], density_only=True) -> (sigma [N], None)` (mvedit_amd.nerf.INGPDecoderParams);
+    tet_vertices [Nv,3] / tet_indices [Nt,4]: the contents of the reference's `demo/tets/{resolution}_tets.npz` ('vertices', 'indices'),
+    which it downloads (no network here: the caller supplies them).  -> (verts [Nv,3] f32, indices [Nt,4] i64, sdf [Nv] f32)"""
+    verts = -torch.as_tensor(tet_vertices, dtype=torch.float32) * 2                     # covers [-1, 1]
+    dev = getattr(decoder, 'device', verts.device)
+    verts = verts.to(dev)
+    indices = torch.as_tensor(tet_indices).to(device=dev, dtype=torch.long)
+    with torch.no_grad():
+        occupied = verts[decoder.point_decode(verts, density_only=True)[0] > density_thresh]
+        hi, lo = occupied.amax(dim=0) + 0.1, occupied.amin(dim=0) - 0.1
+        verts = verts * ((hi - lo).max() / 2) + (hi + lo) / 2
+        sdf = (decoder.point_decode(verts, density_only=True)[0] - density_thresh).clamp(-1, 1)
+        sdf[(verts < -1).any(dim=-1) | (verts > 1).any(dim=-1)] = -1
+    return verts, indices, sdf
