@@ -301,6 +301,14 @@ MVE_API int mve_sh_encode_backward(const float* d_grad, const float* d_dy_dx, ui
 MVE_API int mve_shade_views(const float* d_rgba, const float* d_normal_fg, const float* d_cam_lights, uint32_t n_views,
                             uint32_t pix_per_view, float ambient_light, float bg_color, const float* d_lut_x, const float* d_lut_y,
                             int steps, float* d_image, void* stream);
+/* Per-point Lambertian shading of the mesh path, forward and backward: the `shading_fun`s handed to MeshRenderer.forward
+ * (lib/pipelines/mvedit_3d_pipeline.py:410-440):  shading = max(light_i . normal_i, 0) * (1 - ambient) + ambient;
+ *   tables given: out = lut(inverse_lut(albedo) + log2(max(shading, 1e-6)))      tables NULL: out = albedo * shading
+ * albedo / normal / lights / out [N,3] f32.  d_grad_out == NULL: forward into d_out.  Otherwise: d_grad_albedo / d_grad_normal [N,3]
+ * receive the gradients of <grad_out, out> (d_out may be NULL). */
+MVE_API int mve_shade_points(const float* d_albedo, const float* d_normal, const float* d_lights, size_t N, float ambient_light,
+                             const float* d_lut_x, const float* d_lut_y, int steps, float* d_out, const float* d_grad_out,
+                             float* d_grad_albedo, float* d_grad_normal, void* stream);
 
 /* Image-space loss of one NeRF optimisation iteration and its gradients: lib/pipelines/mvedit_3d_pipeline.py:542-603 (`nerf_optim`,
  * from `out_rgbs = outputs['image']...` to `loss = loss + entropy_loss`) with depth_to_normal (lib/core/utils/geometry_utils.py:119-148),

@@ -46,6 +46,19 @@ __global__ __launch_bounds__(NT) void k_shade_views(const float* __restrict__ rg
     sh_shade_pixel(rgba + i * 4, normal_fg + i * 3, lights + 3 * (i / pix), ambient, bg, tx, ty, l.n, image + i * 3);
 }
 
+// forward (g_out == nullptr) or backward of sh_shade_point over N points
+__global__ __launch_bounds__(NT) void k_shade_points(const float* __restrict__ albedo, const float* __restrict__ normal, const float* __restrict__ lights,
+                                                     size_t N, float ambient, Lut l, float* __restrict__ out, const float* __restrict__ g_out,
+                                                     float* __restrict__ g_albedo, float* __restrict__ g_normal) {
+    __shared__ float tx[MAX_STEPS], ty[MAX_STEPS];
+    if (l.n > 0 && threadIdx.x < l.n) { tx[threadIdx.x] = l.x[threadIdx.x]; ty[threadIdx.x] = l.y[threadIdx.x]; }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    sh_shade_point(albedo + 3 * i, normal + 3 * i, lights + 3 * i, ambient, tx, ty, l.n, out ? out + 3 * i : nullptr, g_out ? g_out + 3 * i : nullptr,
+                   g_albedo ? g_albedo + 3 * i : nullptr, g_normal ? g_normal + 3 * i : nullptr);
+}
+
 }  // namespace
 
 extern "C" {
@@ -66,6 +79,20 @@ int mve_tonemap_lut_backward(const float* d_x, const float* d_grad_out, size_t n
               "tonemap_lut_backward: bad arguments (2 <= steps <= %d)", MAX_STEPS);
     k_lut_bwd<<<mve_cdiv(n, NT), NT, 0, (hipStream_t)stream>>>(d_x, d_grad_out, n, Lut{d_lut_x, d_lut_y, steps}, inverse ? 1 : 0, linear ? 1 : 0,
                                                                 d_grad_x);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_shade_points(const float* d_albedo, const float* d_normal, const float* d_lights, size_t N, float ambient_light, const float* d_lut_x,
+                     const float* d_lut_y, int steps, float* d_out, const float* d_grad_out, float* d_grad_albedo, float* d_grad_normal, void* stream) {
+    if (N == 0) return MVE_OK;
+    MVE_CHECK(d_albedo && d_normal && d_lights, MVE_ERR_ARG, "shade_points: null pointer");
+    MVE_CHECK((d_grad_out == nullptr) ? (d_out != nullptr) : (d_grad_albedo && d_grad_normal), MVE_ERR_ARG,
+              "shade_points: forward needs out, backward needs grad_out, grad_albedo and grad_normal");
+    MVE_CHECK((d_lut_x == nullptr) == (d_lut_y == nullptr) && (d_lut_x == nullptr || (steps >= 2 && steps <= MAX_STEPS)), MVE_ERR_ARG,
+              "shade_points: pass both tables (2 <= steps <= %d) or neither", MAX_STEPS);
+    k_shade_points<<<mve_cdiv(N, NT), NT, 0, (hipStream_t)stream>>>(d_albedo, d_normal, d_lights, N, ambient_light,
+                                                                   Lut{d_lut_x, d_lut_y, d_lut_x ? steps : 0}, d_out, d_grad_out, d_grad_albedo, d_grad_normal);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

@@ -65,3 +65,37 @@ MVE_SH_FN void sh_shade_pixel(const float* rgba, const float* normal_fg, const f
         for (int k = 0; k < 3; ++k) out[k] = rgba[k] * shading + back;
     }
 }
+
+// ---- per-point Lambertian shading of the mesh path: the `shading_fun`s handed to MeshRenderer.forward (lib/pipelines/mvedit_3d_pipeline.py:
+// 410-440 make_shading_fun / make_nerf_shading_fun):  shading = clamp(light . normal, 0) (1 - ambient) + ambient;
+//   tables given : out = lut(inverse_lut(albedo) + log2(clamp(shading, 1e-6)))        tables absent (n = 0): out = albedo * shading
+// Backward (g_out != nullptr): g_albedo[3], g_normal[3] of sum_k g_out[k] out[k]; the light is a constant.
+MVE_SH_FN void sh_shade_point(const float* albedo, const float* normal, const float* light, float ambient, const float* tx, const float* ty, int n,
+                              float* out, const float* g_out, float* g_albedo, float* g_normal) {
+    const float dot = (light[0] * normal[0] + light[1] * normal[1]) + light[2] * normal[2];
+    const float shading = fmaxf(dot, 0.0f) * (1.0f - ambient) + ambient;
+    float g_shading = 0.f;
+    if (n > 0) {
+        const float sc = fmaxf(shading, 1e-6f), ls = log2f(sc);
+        float g_ls = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            const int ii = sh_bucket(ty, n, albedo[k]);
+            const float s_inv = (tx[ii] - tx[ii - 1]) / (ty[ii] - ty[ii - 1]);
+            const float u = tx[ii - 1] + (tx[ii] - tx[ii - 1]) * ((albedo[k] - ty[ii - 1]) / (ty[ii] - ty[ii - 1])) + ls;
+            const int io = sh_bucket(tx, n, u);
+            const float s_lut = (ty[io] - ty[io - 1]) / (tx[io] - tx[io - 1]);
+            if (out) out[k] = ty[io - 1] + (ty[io] - ty[io - 1]) * ((u - tx[io - 1]) / (tx[io] - tx[io - 1]));
+            if (g_out) { g_albedo[k] = g_out[k] * s_lut * s_inv; g_ls += g_out[k] * s_lut; }
+        }
+        if (g_out && shading >= 1e-6f) g_shading = g_ls / (sc * 0.69314718055994531f);
+    } else {
+        for (int k = 0; k < 3; ++k) {
+            if (out) out[k] = albedo[k] * shading;
+            if (g_out) { g_albedo[k] = g_out[k] * shading; g_shading += g_out[k] * albedo[k]; }
+        }
+    }
+    if (g_out) {
+        const float gd = dot >= 0.0f ? g_shading * (1.0f - ambient) : 0.0f;
+        for (int k = 0; k < 3; ++k) g_normal[k] = gd * light[k];
+    }
+}

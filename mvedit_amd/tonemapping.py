@@ -88,3 +88,62 @@ def shade_views(rgba, normal_fg, cam_lights, ambient_light, bg_color, tonemappin
         _lib.call('mve_shade_views', _lib.ptr(c), _lib.ptr(nf), _lib.ptr(lights), b, n // b, float(ambient_light), float(bg_color),
                   _lib.ptr(lx), _lib.ptr(ly), steps, _lib.ptr(out), _lib.stream_ptr(c.device))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The shading functions the pipelines hand to MeshRenderer.forward (lib/pipelines/mvedit_3d_pipeline.py:410-450), on one fused kernel
+# (mve_shade_points) with its backward: they run inside every mesh-optimisation iteration and back-propagate into the decoder (albedo)
+# and the mesh (world_normal).
+class _ShadePointsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, albedo, normal, lights, ambient, lut_x, lut_y):
+        assert albedo.is_cuda and albedo.dim() == 2 and albedo.shape[1] == 3 and normal.shape == albedo.shape and lights.shape == albedo.shape
+        a, n, l = (t.detach().to(torch.float32).contiguous() for t in (albedo, normal, lights))
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.call('mve_shade_points', _lib.ptr(a), _lib.ptr(n), _lib.ptr(l), a.shape[0], float(ambient), _lib.ptr(lut_x), _lib.ptr(lut_y),
+                      0 if lut_x is None else lut_x.numel(), _lib.ptr(out), None, None, None, _lib.stream_ptr(a.device))
+        ctx.keep, ctx.ambient, ctx.dtypes = (a, n, l, lut_x, lut_y), float(ambient), (albedo.dtype, normal.dtype)
+        return out.to(albedo.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, n, l, lut_x, lut_y = ctx.keep
+        g = g.detach().to(torch.float32).contiguous()
+        ga, gn = torch.empty_like(a), torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.call('mve_shade_points', _lib.ptr(a), _lib.ptr(n), _lib.ptr(l), a.shape[0], ctx.ambient, _lib.ptr(lut_x), _lib.ptr(lut_y),
+                      0 if lut_x is None else lut_x.numel(), None, _lib.ptr(g), _lib.ptr(ga), _lib.ptr(gn), _lib.stream_ptr(a.device))
+        return ga.to(ctx.dtypes[0]), gn.to(ctx.dtypes[1]), None, None, None, None
+
+
+def shade_points(albedo, world_normal, lights, ambient_light, tonemapping=None):
+    """albedo / world_normal / lights [N, 3] -> shaded colour [N, 3]; differentiable w.r.t. albedo and world_normal"""
+    lx, ly = (tonemapping.lut_x, tonemapping.lut_y) if tonemapping is not None else (None, None)
+    return _ShadePointsFn.apply(albedo, world_normal, lights, ambient_light, lx, ly)
+
+
+def make_shading_fun(worldspace_point_lights, ambient_light, tonemapping=None):
+    """`MVEdit3DPipeline.make_shading_fun` (:410-423): worldspace_point_lights [b, h, w, 3] per pixel; the mesh's own albedo is shaded"""
+    def shading_fun(world_pos=None, albedo=None, world_normal=None, fg_mask=None, **kwargs):
+        return shade_points(albedo, world_normal, worldspace_point_lights[fg_mask.squeeze(0)], ambient_light, tonemapping)
+    return shading_fun
+
+
+def make_nerf_shading_fun(point_albedo, worldspace_point_lights, ambient_light, tonemapping=None):
+    """`make_nerf_shading_fun` (:425-442).  point_albedo(world_pos [N, 3]) -> [N, 3] stands for
+    `self.nerf.decoder.point_decode(world_pos[None], None, nerf_code)[1].squeeze(0)`, e.g. `lambda x: dec.point_decode_autograd(x)[1]`."""
+    def shading_fun(world_pos=None, albedo=None, world_normal=None, fg_mask=None, **kwargs):
+        if len(world_pos) == 0:
+            return world_pos if albedo is None else albedo
+        return shade_points(point_albedo(world_pos), world_normal, worldspace_point_lights[fg_mask.squeeze(0)], ambient_light, tonemapping)
+    return shading_fun
+
+
+def make_nerf_albedo_shading_fun(point_albedo):
+    """`make_nerf_albedo_shading_fun` (:444-450): the decoder's colour at the surface points, unshaded"""
+    def shading_fun(world_pos=None, albedo=None, **kwargs):
+        if len(world_pos) == 0:
+            return world_pos if albedo is None else albedo
+        return point_albedo(world_pos)
+    return shading_fun

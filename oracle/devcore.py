@@ -15,6 +15,8 @@ _lib.dc_antialias_backward_pos.argtypes = [_p, _p, _i, _i, _i, _i, _p, _p, _i, _
 _lib.dc_tonemap_lut.argtypes = [_p, _z, _p, _p, _i, _i, _i, _p]
 _lib.dc_tonemap_lut_grad.argtypes = [_p, _z, _p, _p, _i, _i, _i, _p]
 _lib.dc_tonemap_lut_grad.restype = None
+_lib.dc_shade_points.argtypes = [_p, _p, _p, _z, _f, _p, _p, _i, _p, _p, _p, _p]
+_lib.dc_shade_points.restype = None
 _lib.dc_shade_views.argtypes = [_p, _p, _p, _u, _u, _f, _f, _p, _p, _i, _p]
 for f in (_lib.dc_interpolate_backward_rast, _lib.dc_rasterize_backward, _lib.dc_antialias_backward_pos, _lib.dc_tonemap_lut, _lib.dc_shade_views):
     f.restype = None
@@ -173,3 +175,18 @@ def sh_encode(xyz, degree, jacobian=False):
     jac = np.zeros((B, 3, degree * degree), np.float32) if jacobian else None
     _lib.dc_sh_encode(_ptr(xyz), B, int(degree), _ptr(out), _ptr(jac))
     return (out, jac) if jacobian else out
+
+
+def shade_points(albedo, normal, lights, ambient, lut_x=None, lut_y=None, grad_out=None):
+    """Host run of sh_shade_point -> out [N, 3], or (g_albedo, g_normal) when grad_out is given"""
+    albedo, normal, lights = _c(albedo), _c(normal), _c(lights)
+    lx, ly = (_c(lut_x), _c(lut_y)) if lut_x is not None else (None, None)
+    N = albedo.shape[0]
+    if grad_out is None:
+        out = np.empty_like(albedo)
+        _lib.dc_shade_points(_ptr(albedo), _ptr(normal), _ptr(lights), N, ambient, _ptr(lx), _ptr(ly), 0 if lx is None else lx.size, _ptr(out), None, None, None)
+        return out
+    g = _c(grad_out)
+    ga, gn = np.empty_like(albedo), np.empty_like(albedo)
+    _lib.dc_shade_points(_ptr(albedo), _ptr(normal), _ptr(lights), N, ambient, _ptr(lx), _ptr(ly), 0 if lx is None else lx.size, None, _ptr(g), _ptr(ga), _ptr(gn))
+    return ga, gn

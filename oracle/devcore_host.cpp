@@ -52,6 +52,13 @@ void dc_tonemap_lut_grad(const float* x, size_t n, const float* lut_x, const flo
     for (size_t i = 0; i < n; ++i) out[i] = sh_lut_grad(lut_x, lut_y, steps, x[i], inverse, linear);
 }
 
+void dc_shade_points(const float* albedo, const float* normal, const float* lights, size_t N, float ambient, const float* lut_x, const float* lut_y,
+                     int steps, float* out, const float* g_out, float* g_albedo, float* g_normal) {
+    for (size_t i = 0; i < N; ++i)
+        sh_shade_point(albedo + 3 * i, normal + 3 * i, lights + 3 * i, ambient, lut_x, lut_y, lut_x ? steps : 0, out ? out + 3 * i : nullptr,
+                       g_out ? g_out + 3 * i : nullptr, g_albedo ? g_albedo + 3 * i : nullptr, g_normal ? g_normal + 3 * i : nullptr);
+}
+
 void dc_shade_views(const float* rgba, const float* normal_fg, const float* lights, unsigned n_views, unsigned pix, float ambient, float bg,
                     const float* lut_x, const float* lut_y, int steps, float* image) {
     for (size_t i = 0; i < (size_t)n_views * pix; ++i)

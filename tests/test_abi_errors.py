@@ -153,3 +153,11 @@ def test_sh_encode_argument_checks(L):
     _bad(lib, 'mve_sh_encode', p, 16, 0, p, None, None, match='degree')
     _bad(lib, 'mve_sh_encode', None, 16, 4, p, None, None, match='null pointer')
     _bad(lib, 'mve_sh_encode_backward', p, None, 16, 4, p, None, match='null pointer')
+
+
+def test_shade_points_argument_checks(L):
+    lib, p, _ = L
+    _bad(lib, 'mve_shade_points', p, p, p, 8, 0.2, None, None, 0, None, None, None, None, None, match='forward needs out')
+    _bad(lib, 'mve_shade_points', p, p, p, 8, 0.2, None, None, 0, None, p, None, p, None, match='backward needs')
+    _bad(lib, 'mve_shade_points', p, p, p, 8, 0.2, p, None, 16, p, None, None, None, None, match='both tables')
+    _bad(lib, 'mve_shade_points', p, None, p, 8, 0.2, None, None, 0, p, None, None, None, None, match='null pointer')

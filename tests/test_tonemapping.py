@@ -112,3 +112,50 @@ def test_hip_lut_is_differentiable_like_the_reference():
     out = tm.lut(tm.inverse_lut(albedo) + shading.clamp(min=1e-6).log2())
     ga, gs = torch.autograd.grad(out.sum(), (albedo, shading))
     assert torch.isfinite(ga).all() and torch.isfinite(gs).all() and float(ga.abs().max()) > 0 and float(gs.abs().max()) > 0
+
+
+# ================================================================================================ shading functions of the mesh path
+GS = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'shading_fun_ref.npz'))
+
+
+def test_shade_points_host_build_vs_reference_shading_funs():
+    """sh_shade_point (the body of mve_shade_points, forward and backward) against the reference's own `make_shading_fun` /
+    `make_nerf_shading_fun` executed in float64 with autograd (tests/golden/make_shading_fun_golden.py): 3e-6 of each tensor's scale."""
+    from oracle import devcore as D
+    fg = GS['fg'][0]
+    lights = GS['lights'][fg]                                                        # worldspace_point_lights[fg_mask.squeeze(0)]
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+    for tag, lut in (('tm', (GS['lut_x'], GS['lut_y'])), ('plain', (None, None))):
+        out = D.shade_points(GS['albedo'], GS['normal'], lights, 0.2, *lut)
+        ga, gn = D.shade_points(GS['albedo'], GS['normal'], lights, 0.2, *lut, grad_out=GS['gy'])
+        assert rel(out, GS[f'{tag}_mesh_out']) < 3e-6 and rel(ga, GS[f'{tag}_mesh_g_albedo']) < 3e-6 and rel(gn, GS[f'{tag}_mesh_g_normal']) < 3e-6, tag
+        # the NeRF variant: same kernel fed with the decoder's colour; the chain into the decoder weights closes through torch
+        W = torch.from_numpy(GS['W']).requires_grad_(True)
+        col = torch.sigmoid(torch.from_numpy(GS['pos']) @ W)
+        out = D.shade_points(col.detach().numpy(), GS['normal'], lights, 0.2, *lut)
+        ga, gn = D.shade_points(col.detach().numpy(), GS['normal'], lights, 0.2, *lut, grad_out=GS['gy'])
+        gW, = torch.autograd.grad(col, W, torch.from_numpy(ga.astype(np.float64)))
+        assert rel(out, GS[f'{tag}_nerf_out']) < 3e-6 and rel(gW.numpy(), GS[f'{tag}_nerf_g_W']) < 3e-6 and rel(gn, GS[f'{tag}_nerf_g_normal']) < 3e-6, tag
+
+
+@pytest.mark.gpu
+@pending_first_gpu_run
+def test_hip_shading_funs_vs_reference():
+    from mvedit_amd.tonemapping import Tonemapping, make_nerf_albedo_shading_fun, make_nerf_shading_fun, make_shading_fun
+    cu = lambda k: torch.from_numpy(GS[k]).float().cuda()
+    fg = torch.from_numpy(GS['fg']).cuda()
+    rel = lambda a, k: float((a.detach().cpu().double() - torch.from_numpy(GS[k])).abs().max() / max(np.abs(GS[k]).max(), 1e-12))
+    for tag, tm in (('tm', Tonemapping(device='cuda')), ('plain', None)):
+        albedo, normal = cu('albedo').requires_grad_(True), cu('normal').requires_grad_(True)
+        y = make_shading_fun(cu('lights'), 0.2, tm)(world_pos=cu('pos'), albedo=albedo, world_normal=normal, fg_mask=fg)
+        ga, gn = torch.autograd.grad((y * cu('gy')).sum(), (albedo, normal))
+        assert rel(y, f'{tag}_mesh_out') < 3e-6 and rel(ga, f'{tag}_mesh_g_albedo') < 3e-6 and rel(gn, f'{tag}_mesh_g_normal') < 3e-6, tag
+        W = cu('W').requires_grad_(True)
+        y = make_nerf_shading_fun(lambda x: torch.sigmoid(x @ W), cu('lights'), 0.2, tm)(world_pos=cu('pos'), albedo=None, world_normal=normal, fg_mask=fg)
+        gW, gn = torch.autograd.grad((y * cu('gy')).sum(), (W, normal))
+        assert rel(y, f'{tag}_nerf_out') < 3e-6 and rel(gW, f'{tag}_nerf_g_W') < 1e-5 and rel(gn, f'{tag}_nerf_g_normal') < 3e-6, tag
+    W = cu('W')
+    f3 = make_nerf_albedo_shading_fun(lambda x: torch.sigmoid(x @ W))
+    assert rel(f3(world_pos=cu('pos')), 'albedo_fun_out') < 1e-6
+    empty = torch.zeros(0, 3, device='cuda')
+    assert f3(world_pos=empty) is empty and make_nerf_shading_fun(None, None, 0.2)(world_pos=empty, albedo=None) is empty
