@@ -1,5 +1,6 @@
 """The C-ABI library builds, loads, and exports every symbol include/mvedit_amd.h declares (no compute)."""
 import ctypes
+import os
 import subprocess
 
 
@@ -58,3 +59,34 @@ def test_product_never_imports_the_oracle():
     for f in os.listdir(os.path.join(root, 'mvedit_amd', 'csrc')):
         for inc in re.findall(r'#include\s+[<"]([^>"]+)[>"]', open(os.path.join(root, 'mvedit_amd', 'csrc', f)).read()):
             assert 'oracle' not in inc, (f, inc)
+
+
+def test_every_python_call_site_passes_the_declared_number_of_arguments():
+    """ctypes would accept a call with a missing trailing argument and read garbage for it: check every `_lib.call('mve_x', ...)` /
+    `_lib.raw('mve_x')(...)` in the package, the tools, bench.py and the tests against the prototypes parsed from include/mvedit_amd.h."""
+    import ast
+    import glob
+    from mvedit_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, 'mvedit_amd', '**', '*.py'), recursive=True) + glob.glob(os.path.join(root, 'tools', '*.py')) \
+        + glob.glob(os.path.join(root, 'tests', '*.py')) + [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')]
+    checked, problems = 0, []
+    for path in files:
+        for node in ast.walk(ast.parse(open(path).read())):
+            if not isinstance(node, ast.Call) or any(isinstance(a, ast.Starred) for a in node.args):
+                continue
+            f, name = node.func, None
+            if isinstance(f, ast.Attribute) and f.attr == 'call' and node.args and isinstance(node.args[0], ast.Constant) \
+                    and isinstance(node.args[0].value, str):
+                name, nargs = node.args[0].value, len(node.args) - 1
+            elif isinstance(f, ast.Call) and isinstance(f.func, ast.Attribute) and f.func.attr == 'raw' and f.args \
+                    and isinstance(f.args[0], ast.Constant):
+                name, nargs = f.args[0].value, len(node.args)
+            if name is None or not str(name).startswith('mve_'):
+                continue
+            checked += 1
+            if name not in _lib.PROTOS:
+                problems.append(f'{path}:{node.lineno} calls undeclared {name}')
+            elif len(_lib.PROTOS[name][1]) != nargs:
+                problems.append(f'{path}:{node.lineno} {name}: passes {nargs} arguments, the header declares {len(_lib.PROTOS[name][1])}')
+    assert checked > 100 and not problems, problems
