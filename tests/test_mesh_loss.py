@@ -155,11 +155,16 @@ def test_mesh_optim_iteration_on_native_kernels_only(lib):
     v0, f = icosphere(3, 0.6)
     f = torch.from_numpy(f).cuda()
     mr = MeshRenderer(near=0.01, far=100)
+    # point-light Lambert + tone mapping through the fused shading function (mvedit_3d_pipeline.py:410-423): gradients reach the vertices
+    # through world_normal as well
+    from mvedit_amd.tonemapping import Tonemapping, make_shading_fun
+    lights = torch.nn.functional.normalize(torch.tensor([0.3, 0.5, 1.0], device='cuda'), dim=0).expand(nv, S, S, 3).contiguous()
+    shade = make_shading_fun(lights, 0.2, Tonemapping(device='cuda'))
 
     def render(verts):
         m = Mesh(verts, f, vc=torch.cat([torch.full_like(verts, 0.7), torch.ones_like(verts[:, :1])], -1))
         m.auto_normal()
-        out = mr([m], poses[None], intr[None], S, S, normal_bg=[0.5, 0.5, 1.0])
+        out = mr([m], poses[None], intr[None], S, S, shading_fun=shade, normal_bg=[0.5, 0.5, 1.0])
         return m, out['rgba'][0], out['normal'][0], out['depth'][0]
     with torch.no_grad():
         _, rgba_t, normal_t, _ = render(torch.from_numpy(v0).cuda())
