@@ -167,7 +167,8 @@ __global__ __launch_bounds__(NT) void k_lpips_layer(const typename Tag::T* __res
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float x = Tag::to_f32(a[e]);
-                const float d = x * i0 - Tag::to_f32(b[e]) * i1, wc = w[c * 8 + e];
+                // both products rounded before the subtraction (no fma contraction): identical features give d = 0 exactly, as in the reference
+                const float d = __fmul_rn(x, i0) - __fmul_rn(Tag::to_f32(b[e]), i1), wc = w[c * 8 + e];
                 val += wc * d * d;
                 dot += 2.0f * wc * d * x;
             }
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NT) void k_lpips_layer(const typename Tag::T* __res
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float x = Tag::to_f32(a[e]);
-                    const float d = x * i0 - Tag::to_f32(b[e]) * i1;
+                    const float d = __fmul_rn(x, i0) - __fmul_rn(Tag::to_f32(b[e]), i1);
                     o[e] = Tag::from_f32(coef * (2.0f * w[c * 8 + e] * d * i0 - k2 * x));
                 }
                 go[c] = o;

@@ -111,7 +111,20 @@ def test_hip_large_mesh_vs_oracle(lib):
     g_v, g_fn = torch.autograd.grad(lap + nc, (vc, fc))
     assert abs(float(lap) - float(lap64)) < 1e-5 * float(lap64) and abs(float(nc) - float(nc64)) < 1e-5 * float(nc64) + 1e-9
     # u = deg v_i - sum v_j cancels from O(1) coordinates down to O(edge^2): fp32 leaves ~1e-4 of relative error in u / |u|
-    assert rel(g_v.cpu().numpy(), gv64.numpy()) < 1e-3 and rel(g_fn.cpu().numpy(), gf64.numpy()) < 1e-5
+    assert rel(g_v.cpu().numpy(), gv64.numpy()) < 1e-3
+    # d |1 - clamp(n0 . n1)| / d n jumps from -n1 to 0 where the dot product crosses 1: on this smooth mesh a few hundred of the 49152 edges
+    # have 1 - n0 . n1 < 1e-6 and single precision puts ~60 of them at or above 1 (first GPU run: 120 faces off by exactly one of their
+    # three edge terms, reproduced bit for bit by the host build of the same source).  The reference's own fp32 evaluation has the same
+    # ambiguity; compare the faces whose three edges are all safely below the clamp, and bound the others by their edge terms.
+    _, tpe = M.edge_to_face(f)
+    near = (1.0 - (fn[tpe[:, 0]] * fn[tpe[:, 1]]).sum(-1)) < 1e-6
+    touchy = torch.zeros(f.shape[0], dtype=torch.bool)
+    touchy[tpe[near].flatten()] = True
+    touchy = touchy.numpy()
+    assert 0 < int(touchy.sum()) < f.shape[0] // 20
+    a, b = g_fn.cpu().numpy(), gf64.numpy()
+    assert np.abs(a[~touchy] - b[~touchy]).max() < 1e-5 * np.abs(b).max()
+    assert np.abs(a[touchy] - b[touchy]).max() < 3.01 / tpe.shape[0]
 
 
 @pytest.mark.gpu

@@ -234,7 +234,8 @@ def _check(out, ref16, ref32, dtype=torch.float16):
     emu_l2, _ = _rel(ref16, ref32)
     msg = f'vs fp16 oracle l2={l2_16:.2e} max={mx_16:.2e}; vs fp32 l2={l2_32:.2e}; emulated l2={emu_l2:.2e}'
     print(msg)
-    assert l2_16 <= 3e-3 and mx_16 <= 6e-3, msg
+    tol = 3e-3 if dtype == torch.float16 else 2.4e-2                # the bounds of _parity
+    assert l2_16 <= tol and mx_16 <= 2 * tol, msg
     assert l2_32 <= 1.05 * emu_l2 + 1e-4, msg
 
 
@@ -338,6 +339,68 @@ def test_engine_sd21_topology_zero123pp_tiling(lib):
     eng(cond.to(dtype).cuda(), 400, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='w', ref_dict=d, is_cfg_guidance=True))
     out = eng(x.to(dtype).cuda(), 400, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='r', ref_dict=d, is_cfg_guidance=True))[0]
     assert out.shape == (B, 4, 48, 32)
+    _check(out, ref16, ref32)
+
+
+# ------------------------------------------------------------------------------------------------ benchmark shapes vs the oracle
+def _parity_hw(cfg, B, H, W, dtype, n_img=1, seed=0, t=499, ctx_len=77, sd_seed=1234):
+    """_parity for a rectangular latent: engine vs the fp32 oracle and vs the oracle emulating PyTorch's half path, same bounds."""
+    from mvedit_amd.unet import UNet2DConditionEngine
+    sd_q = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=sd_seed).items()}
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cfg['in_channels'], H, W, generator=g).to(dtype).float()
+    ctx = torch.randn(B, ctx_len, cfg['cross_attention_dim'], generator=g).to(dtype).float()
+    with torch.no_grad():
+        ref32 = U.unet_forward(sd_q, cfg, x, t, ctx, n_img)
+        ref16 = U.unet_forward(sd_q, cfg, x, t, ctx, n_img, q=U.quantizer(dtype))
+    eng = UNet2DConditionEngine.from_state_dict(sd_q, cfg, dtype)
+    cak = dict(num_cross_attn_imgs=n_img) if n_img > 1 else None
+    out = eng(x.to(dtype).cuda(), t, ctx.to(dtype).cuda(), cross_attention_kwargs=cak)[0]
+    assert out.dtype == dtype and out.shape == ref32.shape and torch.isfinite(out).all()
+    _check(out, ref16, ref32, dtype)
+    return eng, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
+def test_engine_sd15_benchmark_shape_vs_oracle(lib, dtype):
+    """The shape bench.py times (SD-1.5, 64x64 latents = 512^2 views; adapter3d_mixin.py:68-135 feeds the CFG pair of every view as one batch)
+    compared with the oracle at FULL size: a CFG pair (B = 2) in fp16 and in bf16 -- the reference's default dtype."""
+    _parity_hw(U.SD15, 2, 64, 64, dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['fp16', 'bf16'])
+def test_engine_sd15_cross_image_pairing_full_size_vs_oracle(lib, dtype):
+    """CrossImageAttnProcWrapper at the size the 3D pipelines use it (joint_attn.py:11-37 with num_cross_attn_imgs = 2 on a [2, 4, 128, 64]
+    latent, i.e. one 2 x 8192-token self-attention at level 0): full-size oracle comparison."""
+    _parity_hw(U.SD15, 2, 128, 64, dtype, n_img=2, t=torch.tensor([20.0, 20.0]))
+
+
+@pytest.mark.gpu
+def test_engine_sd21_zero123pp_true_tiling_vs_oracle(lib):
+    """BASELINE config 2 at its true size: the full 4-level SD-2.1 topology on the 3 x 2 tiling of six 320^2 views = a 120 x 80 latent
+    (lib/pipelines/zero123plus.py:349-350), reference-only attention written by the condition pass and read by the denoising pass with the
+    CFG-first item exempt (zero123plus.py:43-77, :107-150)."""
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg, dtype, B = U.SD21, torch.float16, 2
+    sd = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=12).items()}
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 4, 120, 80, generator=g).to(dtype).float()
+    cond = torch.randn(B, 4, 40, 40, generator=g).to(dtype).float()       # the 320^2 condition image's latent
+    ctx = torch.randn(B, 77, 1024, generator=g).to(dtype).float()
+
+    def oracle(q):
+        d = {}
+        U.unet_forward(sd, cfg, cond, 400, ctx, attn_opts=dict(mode='w', ref_dict=d, ref_skip=1), q=q)
+        return U.unet_forward(sd, cfg, x, 400, ctx, attn_opts=dict(mode='r', ref_dict=d, ref_skip=1), q=q)
+    with torch.no_grad():
+        ref32, ref16 = oracle(None), oracle(U.quantizer(dtype))
+    eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype)
+    d = {}
+    eng(cond.to(dtype).cuda(), 400, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='w', ref_dict=d, is_cfg_guidance=True))
+    out = eng(x.to(dtype).cuda(), 400, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='r', ref_dict=d, is_cfg_guidance=True))[0]
+    assert out.shape == (B, 4, 120, 80)
     _check(out, ref16, ref32)
 
 
