@@ -28,6 +28,8 @@ COMMON_FLAGS = [
 # Per-file extra flags.  The ray marcher must not contract a*b+c into fma: its
 # index buffers are compared bit-for-bit with the C oracle.
 EXTRA_FLAGS = {
+    # softmax maxima of MFMA outputs: without this every fmaxf operand gets a canonicalising v_max_f32 x, x (NaN inputs give NaN outputs either way)
+    'attention.hip': ['-fno-honor-nans'],
     'raymarching.hip': ['-ffp-contract=off'],
     'nerf.hip': ['-ffp-contract=off'],
     'raster.hip': ['-ffp-contract=off'],

@@ -410,6 +410,271 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_attention3 (d = 40, the head width of every level-0 SD-1.5 attention = 86 % of the UNet's attention FLOPs).
+// The 16x16x32 kernel above pads d = 40 to 64 for Q K^T and spends a third of its VALU on transposing V through registers.  Here:
+//   * S^T = K Q^T on v_mfma_f32_32x32x16: d = 40 is three 16-deep steps (48, 83 % useful instead of 62 %); a wave owns 32 queries, its lane
+//     holds query (lane & 31) and 16 of the 32 keys of a block, so the row maximum needs ONE cross-lane step (v_permlane32_swap);
+//   * O^T = V^T P^T stays on v_mfma_f32_16x16x32 (dv = 40 -> 48 rows; row 40 is the all-ones row that accumulates the softmax denominator).
+//     P moves from the 32x32 accumulator layout into its B-operand layout with four v_permlane16_swap per 32 keys (after packing to 16 bit);
+//     the MFMA's contraction slots are DEFINED by where those swaps leave the keys: lane group g of the operand holds keys
+//     {0-3, 16-19} + {0, 8, 4, 12}[g] of the block;
+//   * V is staged ROW-MAJOR by LDS-DMA (no register transpose, no ds_write) into 96-byte rows [40 values | 1 0 0 0 0 0 0 0] -- the last
+//     chunk comes from a constant page -- and the V^T fragments are read with the LDS transpose read ds_read_b64_tr_b16: a 16-lane group
+//     reads a [4 keys][16 dv] sub-matrix and each lane receives one dv column.  Key k sits in LDS row k with bits 2 and 3 swapped, so the
+//     rows a half-wave touches in one read are 8 consecutive ones (24 banks apart: conflict-free);
+//   * K rows are 80 bytes, unpadded: ds_read_b128 lane groups cover 16 distinct rows mod 16 and 20 banks per row generate every multiple
+//     of 4 -- conflict-free without a swizzle.  The upper half of the third d-step reads chunk 4 again (finite data) against zero Q.
+// 64 keys per LDS stage (11 KiB = 11 LDS-DMA instructions per block), double buffered, one barrier per stage; OCC blocks per CU.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned short g_attn_ones_f16[8] = {0x3C00u, 0, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) unsigned short g_attn_ones_bf16[8] = {0x3F80u, 0, 0, 0, 0, 0, 0, 0};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <class Tag, bool SEG2, int OCC>
+__global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
+    constexpr int D = 40, KB = 64, QB = 128;
+    constexpr int K_ROW = 80, V_ROW = 96;
+    constexpr int K_BYTES = KB * K_ROW, V_BYTES = KB * V_ROW, STAGE = K_BYTES + V_BYTES;
+    constexpr int N_DMA = STAGE / 1024, K_DMA = K_BYTES / 1024, DMA_PER_WAVE = (N_DMA + 3) / 4;
+    static_assert(STAGE % 1024 == 0 && K_BYTES % 1024 == 0, "stage must split into whole LDS-DMA instructions");
+    typedef typename Tag::V8 V8;
+    typedef typename Tag::T T;
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    typedef T T4 __attribute__((ext_vector_type(4)));
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l32 = lane & 31, hi = lane >> 5, l16 = lane & 15, g = lane >> 4;
+
+    const int q_tiles = (p.Lq + QB - 1) / QB;
+    const unsigned nblk = (unsigned)(q_tiles * p.heads * p.B);
+    const unsigned bid = mve_xcd_remap(blockIdx.x, nblk);
+    const int qt = bid % q_tiles;
+    const int h = (bid / q_tiles) % p.heads;
+    const int b = bid / (q_tiles * p.heads);
+    const int Ltot = p.Lk + p.Lk2;
+
+    const T* kb1 = reinterpret_cast<const T*>(p.K) + (size_t)b * p.Lk * p.ldk + h * D;
+    const T* vb1 = reinterpret_cast<const T*>(p.V) + (size_t)b * p.Lk * p.ldv + h * D;
+    const T* kb2 = SEG2 ? reinterpret_cast<const T*>(p.K2) + (size_t)b * p.Lk2 * p.ldk2 + h * D : nullptr;
+    const T* vb2 = SEG2 ? reinterpret_cast<const T*>(p.V2) + (size_t)b * p.Lk2 * p.ldv2 + h * D : nullptr;
+    const T* ones = reinterpret_cast<const T*>(std::is_same<T, f16>::value ? g_attn_ones_f16 : g_attn_ones_bf16);
+    auto k_row = [&](int j) -> const T* {
+        if constexpr (SEG2) { if (j >= p.Lk) return kb2 + (size_t)(j - p.Lk) * p.ldk2; }
+        return kb1 + (size_t)j * p.ldk;
+    };
+    auto v_row = [&](int j) -> const T* {
+        if constexpr (SEG2) { if (j >= p.Lk) return vb2 + (size_t)(j - p.Lk) * p.ldv2; }
+        return vb1 + (size_t)j * p.ldv;
+    };
+
+    // Q fragments (B operand of the 32x32x16 MFMA): lane = (query l32, d half hi), step s covers d = 16 s + 8 hi .. + 7
+    const int q_base = qt * QB + wid * 32;
+    V8 qf[3];
+    {
+        int q = q_base + l32;
+        q = q < p.Lq ? q : p.Lq - 1;
+        const T* row = reinterpret_cast<const T*>(p.Q) + ((size_t)b * p.Lq + q) * p.ldq + h * D;
+        qf[0] = __builtin_bit_cast(V8, *reinterpret_cast<const u32x4*>(row + 8 * hi));
+        qf[1] = __builtin_bit_cast(V8, *reinterpret_cast<const u32x4*>(row + 16 + 8 * hi));
+        u32x4 t = {0u, 0u, 0u, 0u};
+        if (hi == 0) t = *reinterpret_cast<const u32x4*>(row + 32);
+        qf[2] = __builtin_bit_cast(V8, t);
+    }
+
+    // LDS-DMA slots of this lane: instruction `inst` = wv + 4 i writes stage bytes [1024 inst, 1024 inst + 1024), 16 per lane.
+    // d_src[i] = source of the lane's chunk for key row 0 of a tile, d_ld[i] = elements per key row (0 for the constant chunk), so that the
+    // source for tile t is d_src + t * 64 * d_ld: one 64-bit add per instruction and tile (single KV segment, full tiles).  The general
+    // path (second KV segment, clamped rows of the last tile) recomputes the row from d_key / d_col.
+    const int wv = __builtin_amdgcn_readfirstlane(wid);            // provably wave-uniform: scalar branches around the per-wave DMA slots
+    int d_key[DMA_PER_WAVE], d_col[DMA_PER_WAVE];
+    const T* d_src[DMA_PER_WAVE];
+    int d_ld[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int inst = wv + 4 * i;
+        const int o = inst * 1024 + lane * 16;
+        if (inst < K_DMA) {
+            const int c = o >> 4;
+            d_key[i] = c / 5; d_col[i] = (c - d_key[i] * 5) * 8;
+            d_ld[i] = p.ldk;
+            d_src[i] = kb1 + (size_t)d_key[i] * p.ldk + d_col[i];
+        } else {
+            const int c = (o - K_BYTES) >> 4;
+            const int r = c / 6, col = c - r * 6;
+            d_key[i] = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);      // LDS row r holds key r with bits 2 and 3 swapped
+            d_col[i] = col < 5 ? col * 8 : -1;                            // chunk 5: the constant [1 0 0 0 0 0 0 0]
+            d_ld[i] = col < 5 ? p.ldv : 0;
+            d_src[i] = col < 5 ? vb1 + (size_t)d_key[i] * p.ldv + d_col[i] : ones;
+        }
+    }
+    // full tile of a single-segment problem: running pointers
+    auto dma_fast = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int inst = wv + 4 * i;
+            if (inst < N_DMA) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)d_src[i], (lds_ptr_t)(smem + buf * STAGE + inst * 1024), 16, 0, 0);
+                d_src[i] += (size_t)KB * d_ld[i];
+            }
+        }
+    };
+    auto dma_any = [&](int t, int buf) {
+        const int j0 = t * KB;
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int inst = wv + 4 * i;
+            if (inst < N_DMA) {
+                int j = j0 + d_key[i];
+                j = j < Ltot ? j : Ltot - 1;                  // clamped rows hold finite data; their scores are masked
+                const T* src = inst < K_DMA ? k_row(j) + d_col[i] : (d_col[i] >= 0 ? v_row(j) + d_col[i] : ones);
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + buf * STAGE + inst * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // tile t (t >= 1 is always issued one tile ahead, in order)
+    const int n_tiles = (Ltot + KB - 1) / KB, n_full = Ltot / KB;
+    auto dma = [&](int t, int buf) {
+        if constexpr (SEG2) dma_any(t, buf);
+        else { if (t < n_full) dma_fast(buf); else dma_any(t, buf); }
+    };
+
+    // fragment read offsets (lane constants)
+    const int k_off01 = l32 * K_ROW + hi * 16;                  // d-steps 0, 1: + 32 s
+    const int k_off2 = l32 * K_ROW + 64;                        // d-step 2: chunk 4 for both halves (Q is zero in the upper one)
+    const int v_off = K_BYTES + (lane >> 2) * V_ROW + (lane & 3) * 8;
+
+    f32x4 oacc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) oacc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY;
+    const float sc = p.scale_log2e;
+
+    auto tile = [&](const unsigned char* St, int key0, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const V8 ka = *reinterpret_cast<const V8*>(St + (st < 2 ? k_off01 + 32 * st : k_off2) + kb * 32 * K_ROW);
+                s[kb] = Tag::mfma32(ka, qf[st], s[kb]);
+            }
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Ltot) s[kb][r] = -INFINITY;
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);        // v_max3_f32 (built with -fno-honor-nans: no canonicalising v_max)
+        mx = mve_max_xor32(mx);
+        const float mxs = mx * sc;
+        if (__builtin_expect(__any(mxs > m_run), 0)) {   // some query's running maximum grows: rescale (exact); rare after the first tiles
+            const float m_new = fmaxf(m_run, mxs);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            // O^T's lane column is query (lane & 15) of its 16-query group: alpha of lanes {0-15, 32-47} resp. {16-31, 48-63}
+            const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+            const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { oacc[i][0][r] *= a0; oacc[i][1][r] *= a1; }
+        }
+        const float nm = -m_run;
+        unsigned pb[2][2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            unsigned pk[8];
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][2 * r2], sc, nm));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][2 * r2 + 1], sc, nm));
+                pk[r2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e0, e1}, T2));
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ai = v < 2 ? v : v + 2;
+                const auto r = __builtin_amdgcn_permlane16_swap(pk[ai], pk[ai + 2], false, false);
+                pb[kb][0][v] = r[0];
+                pb[kb][1][v] = r[1];
+            }
+        }
+        // V^T fragments by LDS transpose reads.  Issued from inline asm with their own lgkmcnt wait: hipcc has no memory operand for the
+        // transpose-read builtin and would drain the LDS-DMA of the NEXT tile (s_waitcnt vmcnt(0)) in front of it.  In-order LDS returns make
+        // the extra entries on the counter harmless for the compiler's own counted waits (they can only over-wait).
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            s16x4 lo[3], up[3];
+            const unsigned va0 = (unsigned)(uintptr_t)(lds_ptr_t)(St + v_off + kb * 32 * V_ROW);
+            asm volatile("ds_read_b64_tr_b16 %0, %6\n\t"
+                         "ds_read_b64_tr_b16 %1, %6 offset:%7\n\t"
+                         "ds_read_b64_tr_b16 %2, %6 offset:32\n\t"
+                         "ds_read_b64_tr_b16 %3, %6 offset:%8\n\t"
+                         "ds_read_b64_tr_b16 %4, %6 offset:64\n\t"
+                         "ds_read_b64_tr_b16 %5, %6 offset:%9\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(lo[0]), "=&v"(up[0]), "=&v"(lo[1]), "=&v"(up[1]), "=&v"(lo[2]), "=&v"(up[2])
+                         : "v"(va0), "i"(16 * V_ROW), "i"(16 * V_ROW + 32), "i"(16 * V_ROW + 64)
+                         : "memory");
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const V8 va = __builtin_bit_cast(V8, __builtin_shufflevector(lo[i], up[i], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const u32x4 pw = {pb[kb][f][0], pb[kb][f][1], pb[kb][f][2], pb[kb][f][3]};
+                    oacc[i][f] = Tag::mfma16(va, __builtin_bit_cast(V8, pw), oacc[i][f]);
+                }
+            }
+        }
+    };
+
+    dma(0, 0);
+    __syncthreads();          // the barrier drains the LDS-DMA: stage 0 visible
+    for (int t = 0; t < n_full; ++t) {                     // full tiles: no key mask
+        const int cur = t & 1;
+        if (t + 1 < n_tiles) dma(t + 1, cur ^ 1);
+        tile(smem + cur * STAGE, t * KB, std::false_type{});
+        __syncthreads();
+    }
+    if (n_full < n_tiles) tile(smem + (n_full & 1) * STAGE, n_full * KB, std::true_type{});    // ragged last tile (Lk = 77, ...)
+
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const float l = __shfl(oacc[2][f][0], 32 + l16, 64);       // row dv = 40 of O^T (fragment 2, lane group 2, register 0) = sum_j P
+        const float inv = 1.0f / l;
+        const int q = q_base + f * 16 + l16;
+        if (q < p.Lq) {
+            T* orow = reinterpret_cast<T*>(p.O) + ((size_t)b * p.Lq + q) * p.ldo + h * D;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int dv = i * 16 + g * 4;
+                if (dv < D) {
+                    T4 o4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o4[r] = Tag::from_f32(oacc[i][f][r] * inv);
+                    *reinterpret_cast<T4*>(orow + dv) = o4;
+                }
+            }
+        }
+    }
+}
+
 // 0: the measured configuration.  2 (d = 80 / 160, single KV segment): conflict-free K swizzle, same arithmetic (bit-identical results).
 // 4 (single KV segment): V^T store swizzle VSW2, same arithmetic (bit-identical results); 6 = 2 + 4.
 // 1 (d = 40 only, single KV segment): 16 query rows per wave, 64-key fills, 3 blocks per CU --
@@ -420,6 +685,13 @@ int g_attn_variant = 0;
 template <class Tag, int D>
 int launch(const AttnParams& p, hipStream_t s) {
     if constexpr (D == 40) {
+        if (g_attn_variant == 8 || g_attn_variant == 9) {                          // k_attention3: 32x32x16 Q K^T, LDS-transposed V
+            const unsigned grid3 = (unsigned)(((p.Lq + 127) / 128) * p.heads * p.B);
+            if (g_attn_variant == 8) { if (p.Lk2 > 0) k_attention3<Tag, true, 3><<<grid3, NT, 0, s>>>(p); else k_attention3<Tag, false, 3><<<grid3, NT, 0, s>>>(p); }
+            else { if (p.Lk2 > 0) k_attention3<Tag, true, 4><<<grid3, NT, 0, s>>>(p); else k_attention3<Tag, false, 4><<<grid3, NT, 0, s>>>(p); }
+            MVE_LAUNCH_CHECK();
+            return MVE_OK;
+        }
         if (g_attn_variant == 1 && p.Lk2 == 0) {
             const unsigned grid1 = (unsigned)(((p.Lq + 63) / 64) * p.heads * p.B);
             k_attention2<Tag, D, false, 1, 64, 3><<<grid1, NT, 0, s>>>(p);

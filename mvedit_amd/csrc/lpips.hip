@@ -141,6 +141,9 @@ template <class Tag, int MODE>
 __global__ __launch_bounds__(NT) void k_lpips_layer(const typename Tag::T* __restrict__ f, const float* __restrict__ w, int B, int HW, int C,
                                                     int pix_per_block, float* __restrict__ partial, const float* __restrict__ grad_out,
                                                     typename Tag::T* __restrict__ g) {
+    // no fma contraction in this kernel: d = x i0 - y i1 must round both products before the subtraction, so that identical features give
+    // d = 0 exactly as in the reference (first GPU run: a contracted fma left 2e-17 for identical images); the kernel is HBM-bound
+#pragma clang fp contract(off)
     typedef typename Tag::V8 V8;
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,8 +170,7 @@ __global__ __launch_bounds__(NT) void k_lpips_layer(const typename Tag::T* __res
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float x = Tag::to_f32(a[e]);
-                // both products rounded before the subtraction (no fma contraction): identical features give d = 0 exactly, as in the reference
-                const float d = __fmul_rn(x, i0) - __fmul_rn(Tag::to_f32(b[e]), i1), wc = w[c * 8 + e];
+                const float d = x * i0 - Tag::to_f32(b[e]) * i1, wc = w[c * 8 + e];
                 val += wc * d * d;
                 dot += 2.0f * wc * d * x;
             }
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(NT) void k_lpips_layer(const typename Tag::T* __res
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float x = Tag::to_f32(a[e]);
-                    const float d = __fmul_rn(x, i0) - __fmul_rn(Tag::to_f32(b[e]), i1);
+                    const float d = x * i0 - Tag::to_f32(b[e]) * i1;
                     o[e] = Tag::from_f32(coef * (2.0f * w[c * 8 + e] * d * i0 - k2 * x));
                 }
                 go[c] = o;

@@ -218,6 +218,47 @@ def test_attention_packed_qkv_spike_and_segments(lib):
           attn_ref(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B // 2, 2 * L, 2 * L, heads, d), dtype)
 
 
+@pytest.mark.parametrize('variant', [8, 9])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_attention_d40_transposed_v_kernel(lib, dtype, variant):
+    """k_attention3 (mve_attention_tune(8 | 9): 32x32x16 Q K^T, V staged row-major by LDS-DMA and read through ds_read_b64_tr_b16, P moved
+    into its operand layout with v_permlane16_swap) on every d = 40 situation the UNet produces: full tiles, a ragged last key tile
+    (Lk = 77 / 93 / 16 / 300), query counts that do not fill the 128-row block, the rescale path (a key dominating a late tile), strided
+    packed-QKV views, two KV segments, cross-image pairing -- against fp32 torch with the per-kernel bar of test_attention."""
+    from mvedit_amd import _lib, ops
+    tune = _lib.raw('mve_attention_tune')
+    old = tune(-1)
+    try:
+        tune(variant)
+        heads, d = 8, 40
+        C = heads * d
+        for B, Lq, Lk in [(2, 256, 256), (1, 4096, 4096), (2, 1000, 77), (1, 128, 16), (2, 300, 300), (3, 576, 93), (1, 64, 4096)]:
+            q, k, v = rnd((B * Lq, C), dtype, 1), rnd((B * Lk, C), dtype, 2), rnd((B * Lk, C), dtype, 3)
+            out = ops.attention(q.cuda(), k.cuda(), v.cuda(), B, Lq, Lk, heads, d)
+            check(f'attention variant {variant}', out, attn_ref(q, k, v, B, Lq, Lk, heads, d), dtype, f'{(B, Lq, Lk)}')
+        B, L = 2, 320
+        qkv = rnd((B * L, 3 * C), dtype, 1)
+        qkv[5, :C] *= 6
+        qkv[300, C:2 * C] = qkv[5, :C]
+        g = qkv.cuda()
+        out = ops.attention(g[:, :C], g[:, C:2 * C], g[:, 2 * C:], B, L, L, heads, d)
+        check('variant packed qkv + spike', out, attn_ref(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, L, L, heads, d), dtype)
+        L2 = 150
+        k2, v2 = rnd((B * L2, C), dtype, 4), rnd((B * L2, C), dtype, 5)
+        kc = torch.cat([qkv[:, C:2 * C].reshape(B, L, C), k2.reshape(B, L2, C)], 1).reshape(-1, C)
+        vc = torch.cat([qkv[:, 2 * C:].reshape(B, L, C), v2.reshape(B, L2, C)], 1).reshape(-1, C)
+        out = ops.attention(g[:, :C], g[:, C:2 * C], g[:, 2 * C:], B, L, L, heads, d, k2=k2.cuda(), v2=v2.cuda(), Lk2=L2)
+        check('variant 2 segments', out, attn_ref(qkv[:, :C], kc, vc, B, L, L + L2, heads, d), dtype)
+        out = ops.attention(g[:, :C], g[:, C:2 * C], g[:, 2 * C:], B // 2, 2 * L, 2 * L, heads, d)
+        check('variant cross-image', out, attn_ref(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B // 2, 2 * L, 2 * L, heads, d), dtype)
+        # a non-default softmax scale and a value spread that makes the ones-row denominator matter
+        q, k, v = rnd((256, C), dtype, 7) * 3, rnd((256, C), dtype, 8) * 3, rnd((256, C), dtype, 9) + 2
+        out = ops.attention(q.cuda(), k.cuda(), v.cuda(), 1, 256, 256, heads, d)
+        check('variant large logits', out, attn_ref(q, k, v, 1, 256, 256, heads, d), dtype)
+    finally:
+        tune(old)
+
+
 def test_boundary_helpers(lib):
     from mvedit_amd import ops
     x = rnd((3, 4, 8, 6), torch.float32, 1)
