@@ -226,9 +226,19 @@ MVE_API int mve_attention(int dtype, const void* d_Q, int ldq, const void* d_K, 
  * query rows per wave, 64-key fills and 3-4 waves per SIMD (the d = 40 case is VALU / exp bound at 2 waves per SIMD).  Results of the
  * two variants agree to rounding, not bitwise (the online-softmax rescale points differ); 2 = for head_dim 80 / 160 a K-tile chunk
  * permutation whose fragment reads are free of LDS bank conflicts (same arithmetic: bit-identical results); 4 = a V^T-tile swizzle
- * that also spreads the transposing stores over the LDS banks (single KV segment, any head_dim; bit-identical results); 6 = 2 + 4.
+ * that also spreads the transposing stores over the LDS banks (single KV segment, any head_dim; bit-identical results); 6 = 2 + 4;
+ * 8..11 = for head_dim 40 the kernel with 32x32x16 Q K^T, LDS-DMA-staged row-major V read through the LDS transpose read and
+ * v_permlane16_swap for P (8: 4 waves / 2 LDS stages, 9: 8 waves / 2, 10: 4 waves / 3, 11: 8 waves / 3 stages); other head dims keep 0.
  * Negative: query only.  Returns the previous value.  tools/ab_attention.py measures them on one box. */
 MVE_API int mve_attention_tune(int variant);
+/* The same attention with Q ALREADY multiplied by softmax_scale * log2(e) (= head_dim^-1/2 * 1.442695...): the logits are in log2 units
+ * and no per-logit multiply remains.  This is how the UNet / ControlNet executors call it: they fold the factor into the to_q rows when the
+ * weights are packed (fp32 multiply, then the one rounding to 16 bit), which replaces the `scale=` handling of
+ * F.scaled_dot_product_attention in the reference's processors (lib/models/architecture/ip_adapter/attention_processor.py:246-248,
+ * :348-350, :364-366).  For head_dim 40 and variants 8..11 the running maximum is subtracted by the first MFMA of Q K^T itself. */
+MVE_API int mve_attention_prescaled(int dtype, const void* d_Q, int ldq, const void* d_K, int ldk, const void* d_V, int ldv,
+                                    const void* d_K2, int ldk2, const void* d_V2, int ldv2, void* d_O, int ldo,
+                                    int B, int Lq, int Lk, int Lk2, int heads, int head_dim, void* stream);
 
 /* GroupNorm over NHWC input (optionally the channel-concat of two tensors) with optional fused SiLU:
  *   out[B*HW][C1+C2] = act( (x - mean_g) * rstd_g * gamma + beta ), torch.nn.GroupNorm semantics.

@@ -39,7 +39,8 @@ struct AttnParams {
     const void* Q; const void* K; const void* V; const void* K2; const void* V2; void* O;
     int ldq, ldk, ldv, ldk2, ldv2, ldo;
     int B, Lq, Lk, Lk2, heads;
-    float scale_log2e;   // softmax scale * log2(e)
+    float scale_log2e;   // softmax scale * log2(e); 1 when the caller folded it into Q (mve_attention_prescaled)
+    int prescaled;
 };
 
 // chunk permutation of K row `row` (a bijection inside every group of 4 chunks, applied identically by the LDS-DMA source side and the
@@ -434,19 +435,36 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <class Tag, bool SEG2, int OCC>
-__global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
-    constexpr int D = 40, KB = 64, QB = 128;
+// NW waves per block (32 queries each: 128 or 256 queries share one K/V stage -- the K/V bytes pulled through the LDS-DMA path per FLOP
+// halve with NW = 8), NST LDS stages: 2 = the next tile is in flight during a tile, drained by __syncthreads(); 3 = two tiles in flight,
+// raw s_barrier + counted s_waitcnt vmcnt(n) so that only the older tile is waited for.
+// LDS-DMA issued from inline asm (one 16-byte chunk per lane, wave-uniform LDS destination in M0): hipcc does not see the LDS write, so it
+// neither drains it in front of LDS reads it cannot disambiguate nor at barriers -- the kernel counts vmcnt itself.
+__device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// PRE: Q arrives multiplied by softmax_scale * log2(e) (the UNet executor folds the factor into the to_q weights when it packs them, one
+// rounding either way), so the logits leave the MFMA in log2 units and the running maximum is subtracted BY the MFMA: the first d-step
+// takes C = -m_run (16 registers holding the lane's own query's value) instead of 0.  exp2 is then applied to the accumulator as it is:
+// the 32 v_fma per tile of the generic path disappear (rocprofv3: the kernel is VALU-issue bound -- SQ_ACTIVE_INST_VALU 77 % of the
+// SIMD cycles against 38 % MFMA busy).  A growing maximum (rare after the first tiles) subtracts the growth from S and rescales O.
+template <class Tag, bool SEG2, int NW, int NST, int WPS, bool PRE>
+__global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p) {
+    constexpr int D = 40, KB = 64, QB = 32 * NW;
     constexpr int K_ROW = 80, V_ROW = 96;
     constexpr int K_BYTES = KB * K_ROW, V_BYTES = KB * V_ROW, STAGE = K_BYTES + V_BYTES;
-    constexpr int N_DMA = STAGE / 1024, K_DMA = K_BYTES / 1024, DMA_PER_WAVE = (N_DMA + 3) / 4;
+    constexpr int N_DMA = STAGE / 1024, K_DMA = K_BYTES / 1024, DMA_PER_WAVE = (N_DMA + NW - 1) / NW;
     static_assert(STAGE % 1024 == 0 && K_BYTES % 1024 == 0, "stage must split into whole LDS-DMA instructions");
+    static_assert(NST == 2 || NST == 3, "2 or 3 LDS stages");
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
     typedef T T2 __attribute__((ext_vector_type(2)));
     typedef T T4 __attribute__((ext_vector_type(4)));
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l32 = lane & 31, hi = lane >> 5, l16 = lane & 15, g = lane >> 4;
@@ -487,17 +505,18 @@ __global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
         qf[2] = __builtin_bit_cast(V8, t);
     }
 
-    // LDS-DMA slots of this lane: instruction `inst` = wv + 4 i writes stage bytes [1024 inst, 1024 inst + 1024), 16 per lane.
+    // LDS-DMA slots of this lane: instruction `inst` = wv + NW i writes stage bytes [1024 inst, 1024 inst + 1024), 16 per lane.
     // d_src[i] = source of the lane's chunk for key row 0 of a tile, d_ld[i] = elements per key row (0 for the constant chunk), so that the
     // source for tile t is d_src + t * 64 * d_ld: one 64-bit add per instruction and tile (single KV segment, full tiles).  The general
     // path (second KV segment, clamped rows of the last tile) recomputes the row from d_key / d_col.
     const int wv = __builtin_amdgcn_readfirstlane(wid);            // provably wave-uniform: scalar branches around the per-wave DMA slots
+    const unsigned smem_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     int d_key[DMA_PER_WAVE], d_col[DMA_PER_WAVE];
     const T* d_src[DMA_PER_WAVE];
     int d_ld[DMA_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) {
-        const int inst = wv + 4 * i;
+        const int inst = wv + NW * i;
         const int o = inst * 1024 + lane * 16;
         if (inst < K_DMA) {
             const int c = o >> 4;
@@ -514,35 +533,37 @@ __global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
         }
     }
     // full tile of a single-segment problem: running pointers
-    auto dma_fast = [&](int buf) {
+    auto dma_fast = [&](int stage_off) {
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            const int inst = wv + 4 * i;
+            const int inst = wv + NW * i;
             if (inst < N_DMA) {
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)d_src[i], (lds_ptr_t)(smem + buf * STAGE + inst * 1024), 16, 0, 0);
+                attn_dma16(d_src[i], smem_base + stage_off + inst * 1024);
                 d_src[i] += (size_t)KB * d_ld[i];
             }
         }
     };
-    auto dma_any = [&](int t, int buf) {
+    auto dma_any = [&](int t, int stage_off) {
         const int j0 = t * KB;
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            const int inst = wv + 4 * i;
+            const int inst = wv + NW * i;
             if (inst < N_DMA) {
                 int j = j0 + d_key[i];
                 j = j < Ltot ? j : Ltot - 1;                  // clamped rows hold finite data; their scores are masked
                 const T* src = inst < K_DMA ? k_row(j) + d_col[i] : (d_col[i] >= 0 ? v_row(j) + d_col[i] : ones);
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + buf * STAGE + inst * 1024), 16, 0, 0);
+                attn_dma16(src, smem_base + stage_off + inst * 1024);
             }
         }
     };
     // tile t (t >= 1 is always issued one tile ahead, in order)
     const int n_tiles = (Ltot + KB - 1) / KB, n_full = Ltot / KB;
-    auto dma = [&](int t, int buf) {
-        if constexpr (SEG2) dma_any(t, buf);
-        else { if (t < n_full) dma_fast(buf); else dma_any(t, buf); }
+    auto dma = [&](int t, int stage_off) {
+        if constexpr (SEG2) dma_any(t, stage_off);
+        else { if (t < n_full) dma_fast(stage_off); else dma_any(t, stage_off); }
     };
+    // number of LDS-DMA instructions this wave issues per tile (wave-uniform): what a counted vmcnt leaves in flight
+    const int n_mine = (N_DMA - wv + NW - 1) / NW;
 
     // fragment read offsets (lane constants)
     const int k_off01 = l32 * K_ROW + hi * 16;                  // d-steps 0, 1: + 32 s
@@ -554,22 +575,24 @@ __global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int f = 0; f < 2; ++f) oacc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY;
+    float m_run = PRE ? 0.f : -INFINITY;
     const float sc = p.scale_log2e;
 
-    auto tile = [&](const unsigned char* St, int key0, auto masked_tag) {
+    f32x16 negm;                                   // PRE: -m_run in all 16 accumulator registers (C operand of the first d-step)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+
+    auto tile = [&](const unsigned char* St, int key0, auto masked_tag, bool first) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        f32x16 s[2];
+        f32x16 s[2], zero16;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const V8 ka = *reinterpret_cast<const V8*>(St + (st < 2 ? k_off01 + 32 * st : k_off2) + kb * 32 * K_ROW);
-                s[kb] = Tag::mfma32(ka, qf[st], s[kb]);
+                s[kb] = Tag::mfma32(ka, qf[st], st == 0 ? (PRE ? negm : zero16) : s[kb]);
             }
         }
         if constexpr (MASKED) {
@@ -583,18 +606,41 @@ __global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);        // v_max3_f32 (built with -fno-honor-nans: no canonicalising v_max)
         mx = mve_max_xor32(mx);
-        const float mxs = mx * sc;
-        if (__builtin_expect(__any(mxs > m_run), 0)) {   // some query's running maximum grows: rescale (exact); rare after the first tiles
-            const float m_new = fmaxf(m_run, mxs);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            // O^T's lane column is query (lane & 15) of its 16-query group: alpha of lanes {0-15, 32-47} resp. {16-31, 48-63}
-            const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
-            const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
+        if constexpr (PRE) {
+            // s = logit - m_run (m_run = 0 before the first tile): the maximum grows where mx > 0
+            if (__builtin_expect(first || __any(mx > 0.f), 0)) {
+                const float delta = first ? mx : fmaxf(mx, 0.f);
+                m_run += delta;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { oacc[i][0][r] *= a0; oacc[i][1][r] *= a1; }
+                    for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+                if (!first) {                            // O is still zero on the first tile (and exp2(-delta) may overflow there)
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+                    const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { oacc[i][0][r] *= a0; oacc[i][1][r] *= a1; }
+                }
+            }
+        } else {
+            const float mxs = mx * sc;
+            if (__builtin_expect(__any(mxs > m_run), 0)) {   // some query's running maximum grows: rescale (exact); rare after the first tiles
+                const float m_new = fmaxf(m_run, mxs);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                // O^T's lane column is query (lane & 15) of its 16-query group: alpha of lanes {0-15, 32-47} resp. {16-31, 48-63}
+                const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+                const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { oacc[i][0][r] *= a0; oacc[i][1][r] *= a1; }
+            }
         }
         const float nm = -m_run;
         unsigned pb[2][2][4];
@@ -603,8 +649,14 @@ __global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
             unsigned pk[8];
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
-                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][2 * r2], sc, nm));
-                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][2 * r2 + 1], sc, nm));
+                float e0, e1;
+                if constexpr (PRE) {
+                    e0 = __builtin_amdgcn_exp2f(s[kb][2 * r2]);
+                    e1 = __builtin_amdgcn_exp2f(s[kb][2 * r2 + 1]);
+                } else {
+                    e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][2 * r2], sc, nm));
+                    e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][2 * r2 + 1], sc, nm));
+                }
                 pk[r2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e0, e1}, T2));
             }
 #pragma unroll
@@ -644,15 +696,34 @@ __global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
         }
     };
 
-    dma(0, 0);
-    __syncthreads();          // the barrier drains the LDS-DMA: stage 0 visible
-    for (int t = 0; t < n_full; ++t) {                     // full tiles: no key mask
-        const int cur = t & 1;
-        if (t + 1 < n_tiles) dma(t + 1, cur ^ 1);
-        tile(smem + cur * STAGE, t * KB, std::false_type{});
-        __syncthreads();
+    // NST stages, PD = NST - 1 tiles in flight.  Iteration t: issue tile t + PD into the stage tile t - 1 left (every wave is past the
+    // barrier that ended iteration t - 1), compute tile t, wait until only this wave's instructions of the tiles AFTER t + 1 are outstanding
+    // (VMEM returns in order: tile t + 1 has landed), drain the LDS reads, barrier.
+    constexpr int PD = NST - 1;
+    static_assert(DMA_PER_WAVE * (PD - 1) <= 3, "wait_sync covers at most three outstanding instructions");
+    auto wait_sync = [&](int keep) {          // keep: wave-uniform, 0..3
+        if (keep >= 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+        if (i < n_tiles) dma(i, i * STAGE);
+    // make hipcc wait for the Q loads HERE: left alone it puts their s_waitcnt vmcnt(0) at the first use inside the tile loop, where it
+    // would drain the in-flight LDS-DMA of every iteration
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]));
+    wait_sync(n_mine * ((n_tiles < PD ? n_tiles : PD) - 1));
+    int cur = 0, nxt = PD * STAGE;            // stage offsets of tile t and of tile t + PD
+    for (int t = 0; t < n_full; ++t) {        // full tiles: no key mask
+        if (t + PD < n_tiles) dma(t + PD, nxt);
+        tile(smem + cur, t * KB, std::false_type{}, t == 0);
+        const int last_issued = t + PD < n_tiles ? t + PD : n_tiles - 1;
+        wait_sync(last_issued > t + 1 ? n_mine * (last_issued - (t + 1)) : 0);
+        nxt = cur;
+        cur = cur + STAGE == NST * STAGE ? 0 : cur + STAGE;
     }
-    if (n_full < n_tiles) tile(smem + (n_full & 1) * STAGE, n_full * KB, std::true_type{});    // ragged last tile (Lk = 77, ...)
+    if (n_full < n_tiles) tile(smem + cur, n_full * KB, std::true_type{}, n_full == 0);      // ragged last tile (Lk = 77, ...): already landed
 
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -680,15 +751,21 @@ __global__ __launch_bounds__(NT, OCC) void k_attention3(const AttnParams p) {
 // 1 (d = 40 only, single KV segment): 16 query rows per wave, 64-key fills, 3 blocks per CU --
 // an experiment for the VALU-bound d = 40 case (mve_attention_tune; results are NOT bit-identical across variants: the online-softmax
 // rescale points move with the fill size).
-int g_attn_variant = 0;
+int g_attn_variant = 11;
 
 template <class Tag, int D>
 int launch(const AttnParams& p, hipStream_t s) {
     if constexpr (D == 40) {
-        if (g_attn_variant == 8 || g_attn_variant == 9) {                          // k_attention3: 32x32x16 Q K^T, LDS-transposed V
-            const unsigned grid3 = (unsigned)(((p.Lq + 127) / 128) * p.heads * p.B);
-            if (g_attn_variant == 8) { if (p.Lk2 > 0) k_attention3<Tag, true, 3><<<grid3, NT, 0, s>>>(p); else k_attention3<Tag, false, 3><<<grid3, NT, 0, s>>>(p); }
-            else { if (p.Lk2 > 0) k_attention3<Tag, true, 4><<<grid3, NT, 0, s>>>(p); else k_attention3<Tag, false, 4><<<grid3, NT, 0, s>>>(p); }
+        if (g_attn_variant >= 8 && g_attn_variant <= 11) {                        // k_attention3: 32x32x16 Q K^T, LDS-transposed V
+            // 8: 4 waves, 2 stages; 9: 8 waves, 2 stages; 10: 4 waves, 3 stages; 11: 8 waves, 3 stages
+            const bool w8 = g_attn_variant == 9 || g_attn_variant == 11, s3 = g_attn_variant >= 10;
+            const unsigned grid3 = (unsigned)(((p.Lq + (w8 ? 255 : 127)) / (w8 ? 256 : 128)) * p.heads * p.B);
+#define MVE_A3P(SEG, NW_, NST_, PRE_) k_attention3<Tag, SEG, NW_, NST_, 4, PRE_><<<grid3, 64 * NW_, 0, s>>>(p)
+#define MVE_A3(SEG, NW_, NST_) do { if (p.prescaled) MVE_A3P(SEG, NW_, NST_, true); else MVE_A3P(SEG, NW_, NST_, false); } while (0)
+            if (p.Lk2 > 0) { if (w8) { if (s3) MVE_A3(true, 8, 3); else MVE_A3(true, 8, 2); } else { if (s3) MVE_A3(true, 4, 3); else MVE_A3(true, 4, 2); } }
+            else { if (w8) { if (s3) MVE_A3(false, 8, 3); else MVE_A3(false, 8, 2); } else { if (s3) MVE_A3(false, 4, 3); else MVE_A3(false, 4, 2); } }
+#undef MVE_A3P
+#undef MVE_A3
             MVE_LAUNCH_CHECK();
             return MVE_OK;
         }
@@ -741,9 +818,9 @@ extern "C" int mve_attention_tune(int variant) {
     return old;
 }
 
-extern "C" int mve_attention(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                             const void* K2, int ldk2, const void* V2, int ldv2, void* O, int ldo, int B, int Lq,
-                             int Lk, int Lk2, int heads, int head_dim, float scale, void* stream) {
+static int attention_entry(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                           const void* K2, int ldk2, const void* V2, int ldv2, void* O, int ldo, int B, int Lq,
+                           int Lk, int Lk2, int heads, int head_dim, float scale, int prescaled, void* stream) {
     if (B == 0 || Lq == 0) return MVE_OK;
     MVE_CHECK(Q && K && V && O, MVE_ERR_ARG, "attention: null pointer");
     MVE_CHECK(Lk > 0 && Lk2 >= 0 && heads > 0, MVE_ERR_ARG, "attention: bad sizes Lk=%d Lk2=%d heads=%d", Lk, Lk2, heads);
@@ -754,9 +831,22 @@ extern "C" int mve_attention(int dtype, const void* Q, int ldq, const void* K, i
     p.Q = Q; p.K = K; p.V = V; p.K2 = K2; p.V2 = V2; p.O = O;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldk2 = ldk2; p.ldv2 = ldv2; p.ldo = ldo;
     p.B = B; p.Lq = Lq; p.Lk = Lk; p.Lk2 = Lk2; p.heads = heads;
-    p.scale_log2e = scale * 1.4426950408889634f;
+    p.scale_log2e = prescaled ? 1.0f : scale * 1.4426950408889634f;
+    p.prescaled = prescaled;
     if (dtype == MVE_F16) return dispatch_d<F16Tag>(p, head_dim, (hipStream_t)stream);
     if (dtype == MVE_BF16) return dispatch_d<BF16Tag>(p, head_dim, (hipStream_t)stream);
     mve_set_error("attention: unsupported dtype %d", dtype);
     return MVE_ERR_ARG;
+}
+
+extern "C" int mve_attention(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                             const void* K2, int ldk2, const void* V2, int ldv2, void* O, int ldo, int B, int Lq,
+                             int Lk, int Lk2, int heads, int head_dim, float scale, void* stream) {
+    return attention_entry(dtype, Q, ldq, K, ldk, V, ldv, K2, ldk2, V2, ldv2, O, ldo, B, Lq, Lk, Lk2, heads, head_dim, scale, 0, stream);
+}
+
+extern "C" int mve_attention_prescaled(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                       const void* K2, int ldk2, const void* V2, int ldv2, void* O, int ldo, int B, int Lq,
+                                       int Lk, int Lk2, int heads, int head_dim, void* stream) {
+    return attention_entry(dtype, Q, ldq, K, ldk, V, ldv, K2, ldk2, V2, ldv2, O, ldo, B, Lq, Lk, Lk2, heads, head_dim, 1.0f, 1, stream);
 }

@@ -14,6 +14,7 @@ int mve_gemm(int, const void*, int, const void*, int, void*, int, int, int, int,
 int mve_conv3x3(int, const void*, int, const void*, int, int, int, int, int, int, const void*, int, void*, int,
                 const float*, const float*, int, const void*, int, int, float, void*, size_t, void*);
 size_t mve_gemm_workspace_bytes(int, int, int, int);
+int mve_attention_prescaled(int, const void*, int, const void*, int, const void*, int, const void*, int, const void*, int, void*, int, int, int, int, int, int, int, void*);
 int mve_attention(int, const void*, int, const void*, int, const void*, int, const void*, int, const void*, int, void*, int,
                   int, int, int, int, int, int, float, void*);
 size_t mve_groupnorm_workspace_bytes(int, int, int, int);
@@ -45,7 +46,7 @@ constexpr int MAX_LEVELS = 8;
 // ---------------------------------------------------------------------------------------------------
 // weight packing kernel: dst[d0*t0 + d1*t1 + d2*t2 + d3*t3] = (d3 < valid3) ? src[d0*s0 + d1*s1 + d2*s2 + d3*s3] : 0
 // ---------------------------------------------------------------------------------------------------
-struct PackDims { long long D[4], s[4], t[4]; long long valid3; };
+struct PackDims { long long D[4], s[4], t[4]; long long valid3; float mul = 1.0f; };   // mul: applied in fp32 before the single rounding
 
 template <class Src, class Dst>
 __global__ void k_pack(const Src* __restrict__ src, Dst* __restrict__ dst, PackDims p) {
@@ -57,7 +58,7 @@ __global__ void k_pack(const Src* __restrict__ src, Dst* __restrict__ dst, PackD
         const long long d1 = r % p.D[1]; r /= p.D[1];
         const long long d0 = r;
         float v = 0.f;
-        if (d3 < p.valid3) v = (float)src[d0 * p.s[0] + d1 * p.s[1] + d2 * p.s[2] + d3 * p.s[3]];
+        if (d3 < p.valid3) v = (float)src[d0 * p.s[0] + d1 * p.s[1] + d2 * p.s[2] + d3 * p.s[3]] * p.mul;
         dst[d0 * p.t[0] + d1 * p.t[1] + d2 * p.t[2] + d3 * p.t[3]] = (Dst)v;
     }
 }

@@ -98,8 +98,9 @@ struct Builder {
         if (Bn <= 0) return;
         live(q, what); live(k, what); live(v, what); live(o, what);
         op(OC_ATTN, 4.0 * Bn * heads * (double)Lq * (Lk + Lk2) * hd, what, [=](const Run& r) {
-            return mve_attention(d, r.p(q), ldq, r.p(k), ldk, r.p(v), ldv, r.p(k2), ldk2, r.p(v2), ldv2, r.p(o), ldo, Bn, Lq, Lk, Lk2, heads,
-                                 hd, 1.0f / sqrtf((float)hd), r.stream);
+            // Q comes out of to_q already multiplied by hd^-1/2 * log2(e) (executor_params.h: q_fold)
+            return mve_attention_prescaled(d, r.p(q), ldq, r.p(k), ldk, r.p(v), ldv, r.p(k2), ldk2, r.p(v2), ldv2, r.p(o), ldo, Bn, Lq, Lk, Lk2,
+                                           heads, hd, r.stream);
         });
     }
     // device-to-device 2-D copy (rows x width bytes) between pitched buffers

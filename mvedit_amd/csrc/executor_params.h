@@ -244,11 +244,21 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         d = PackDims{{1, 1, 1, n}, {0, 0, 0, 1}, {0, 0, 0, dst_stride}, n};
         return pack(src_dtype, p->f32 ? MVE_F32 : c.dtype, src, dstp(p, off), d, s);
     };
-    auto mat = [&](Param* p, size_t elem_off, long long N, long long K, long long dst_row_stride) -> int {   // [N][K] rows
+    auto mat = [&](Param* p, size_t elem_off, long long N, long long K, long long dst_row_stride, float mul = 1.0f) -> int {   // [N][K] rows
         MVE_CHECK(p, MVE_ERR_ARG, "load_param: no slot for %s", name.c_str());
         MVE_CHECK(numel() == N * K, MVE_ERR_ARG, "load_param(%s): expected %lldx%lld, got %lld elements", name.c_str(), N, K, numel());
         d = PackDims{{1, 1, N, K}, {0, 0, K, 1}, {0, 0, dst_row_stride, 1}, K};
+        d.mul = mul;
         return pack(src_dtype, c.dtype, src, dstp(p, elem_off), d, s);
+    };
+    // to_q rows carry softmax_scale * log2(e) = head_dim^-1/2 * log2(e): the attention kernel then works in log2 units without a multiply per
+    // logit (mve_attention_prescaled).  One rounding either way: the factor is applied in fp32 before the weight is rounded to 16 bits.
+    auto q_fold = [&](const std::string& block) -> float {
+        std::vector<ResnetDesc> rs; std::vector<XfDesc> xs;
+        enumerate(c, rs, xs);
+        for (const XfDesc& x : xs)
+            if (block.compare(0, x.name.size() + 1, x.name + ".") == 0) return 1.4426950408889634f / sqrtf((float)(x.c / x.heads));
+        return 0.f;
     };
     long long conv_row = 0;    // destination row length of the conv packer when the row also holds a fused shortcut (0: 9 * I)
     auto conv = [&](Param* p, long long O, long long I, long long Opad, long long Ipad) -> int {   // OIHW -> [O][3][3][Ipad]
@@ -413,7 +423,9 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         const int which = name[name.size() - 8] == 'q' ? 0 : (name[name.size() - 8] == 'k' ? 1 : 2);
         const std::string b = name.substr(0, name.size() - std::string(".attn1.to_q.weight").size());
         const long long C = shape[0];
-        rc = mat(P(b + ".qkv.w"), (size_t)which * C * C, C, C, C);
+        const float fold = which == 0 ? q_fold(b) : 1.0f;
+        MVE_CHECK(fold > 0.f, MVE_ERR_ARG, "load_param: %s is not in a known transformer block", name.c_str());
+        rc = mat(P(b + ".qkv.w"), (size_t)which * C * C, C, C, C, fold);
     } else if (ends_with(name, ".attn2.to_k.weight") || ends_with(name, ".attn2.to_v.weight")) {
         const int which = name[name.size() - 8] == 'k' ? 0 : 1;
         const std::string b = name.substr(0, name.size() - std::string(".attn2.to_k.weight").size());
@@ -427,7 +439,11 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         const long long C = shape[0];
         rc = mat(P("ip_kv.w"), ((size_t)u.kv_off[b] + (size_t)which * C) * c.ctx_dim, C, c.ctx_dim, c.ctx_dim);
         if (rc == MVE_OK && !u.loaded.count(name)) ++u.n_ip_loaded;
-    } else if (ends_with(name, ".attn2.to_q.weight")) rc = mat(P(strip(name, ".attn2.to_q.weight") + ".q2.w"), 0, shape[0], shape[1], shape[1]);
+    } else if (ends_with(name, ".attn2.to_q.weight")) {
+        const float fold = q_fold(strip(name, ".attn2.to_q.weight"));
+        MVE_CHECK(fold > 0.f, MVE_ERR_ARG, "load_param: %s is not in a known transformer block", name.c_str());
+        rc = mat(P(strip(name, ".attn2.to_q.weight") + ".q2.w"), 0, shape[0], shape[1], shape[1], fold);
+    }
     else if (ends_with(name, ".attn1.to_out.0.weight")) rc = mat(P(strip(name, ".attn1.to_out.0.weight") + ".o1.w"), 0, shape[0], shape[1], shape[1]);
     else if (ends_with(name, ".attn1.to_out.0.bias")) rc = vec(P(strip(name, ".attn1.to_out.0.bias") + ".o1.b"), 0, shape[0], 1);
     else if (ends_with(name, ".attn2.to_out.0.weight")) rc = mat(P(strip(name, ".attn2.to_out.0.weight") + ".o2.w"), 0, shape[0], shape[1], shape[1]);

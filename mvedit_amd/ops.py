@@ -128,8 +128,9 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
-def attention(q, k, v, B, Lq, Lk, heads, head_dim, scale=None, k2=None, v2=None, Lk2=0, out=None):
-    """q: [B*Lq, >=heads*d] view (any row stride), k/v: [B*Lk, ...] views; returns [B*Lq, heads*d]."""
+def attention(q, k, v, B, Lq, Lk, heads, head_dim, scale=None, k2=None, v2=None, Lk2=0, out=None, prescaled=False):
+    """q: [B*Lq, >=heads*d] view (any row stride), k/v: [B*Lk, ...] views; returns [B*Lq, heads*d].
+    prescaled: q already carries softmax_scale * log2(e) (mve_attention_prescaled)."""
     for t in (q, k, v, k2, v2):
         if t is not None:
             assert t.is_cuda and t.stride(1) == 1 and t.dtype in (torch.float16, torch.bfloat16)
@@ -138,9 +139,13 @@ def attention(q, k, v, B, Lq, Lk, heads, head_dim, scale=None, k2=None, v2=None,
     if out is None:
         out = torch.empty(B * Lq, heads * head_dim, dtype=q.dtype, device=q.device)
     with torch.cuda.device(q.device):
-        _lib.call('mve_attention', dt(q), _lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0),
-                  _lib.ptr(k2), k2.stride(0) if k2 is not None else 0, _lib.ptr(v2), v2.stride(0) if v2 is not None else 0,
-                  _lib.ptr(out), out.stride(0), B, Lq, Lk, int(Lk2), heads, head_dim, float(scale), _s(q))
+        args = (dt(q), _lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0),
+                _lib.ptr(k2), k2.stride(0) if k2 is not None else 0, _lib.ptr(v2), v2.stride(0) if v2 is not None else 0,
+                _lib.ptr(out), out.stride(0), B, Lq, Lk, int(Lk2), heads, head_dim)
+        if prescaled:
+            _lib.call('mve_attention_prescaled', *args, _s(q))
+        else:
+            _lib.call('mve_attention', *args, float(scale), _s(q))
     return out
 
 

@@ -25,12 +25,16 @@ def db(tag):
     return sqlite3.connect(fs[0]) if fs else None
 
 
-c = db('prof_stats')
-if c:
-    print('== rocprofv3 --kernel-trace --stats : per-kernel totals (all launches of the run)')
-    rows = c.execute('select name, total_calls, total_duration, average, percentage from top_kernels').fetchall()
-    for name, calls, tot, avg, pct in rows[:30]:
-        print(f'{short(name):66s} calls={calls:6d} total_ms={tot / 1e3:10.3f} avg_us={avg:10.2f} pct={pct:6.2f}')
+# extra arguments: kernel-trace directories to summarise instead of prof_stats (python tools/summarize_prof.py gpurun_out prof_pending ...)
+for tag in (sys.argv[2:] or ['prof_stats']):
+    c = db(tag)
+    if c:
+        print(f'== rocprofv3 --kernel-trace --stats ({tag}) : per-kernel totals (all launches of the run)')
+        rows = c.execute('select name, total_calls, total_duration, average, percentage from top_kernels').fetchall()
+        for name, calls, tot, avg, pct in rows[:(30 if tag == 'prof_stats' else 60)]:
+            print(f'{short(name):66s} calls={calls:6d} total_ms={tot / 1e3:10.3f} avg_us={avg:10.2f} pct={pct:6.2f}')
+if len(sys.argv) > 2:
+    sys.exit(0)
 
 for tag in ('prof_fetch', 'prof_write', 'prof_mfma'):
     c = db(tag)
