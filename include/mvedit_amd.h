@@ -709,6 +709,39 @@ MVE_API int mve_texture_bilinear_backward(const float* d_grad_out, int Bt, int t
 MVE_API int mve_antialias_backward(const float* d_grad_out, int B, int H, int W, int C, const float* d_rast, const float* d_pos, int V,
                                    const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_color, void* stream);
 
+/* Mip-mapped texture path: what the reference gets from nvdiffrast with MeshRenderer(texture_filter='linear-mipmap-linear') -- its default
+ * (lib/models/decoders/mesh_renderer/base_mesh_renderer.py:196) -- in forward (:241, :260-264, :357-361), get_cam_weights_uv (:442, :466-475,
+ * :496-500) and bake_multiview (:521, :543-552, :573-577).  nvdiffrast is not vendored: algorithm restated in oracle/texture_mip_oracle.py.
+ *   rasterize_db        dr.rasterize(...)[1]: d_rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY) of the barycentrics, 0 on empty pixels
+ *   interpolate_da      dr.interpolate(attr, rast, tri, rast_db=..., diff_attrs='all')[1]: d_out [B,npix,2C] = (dA0/dX, dA0/dY, dA1/dX, ...)
+ *   mip_levels          number of levels above level 0 of the full stack (down to 1 x 1); mip_texels = texels of levels 1..max_level
+ *   mip_build           d_mips [Bt][mip_texels*C]: level l+1 = 2x2 box filter of level l (extents must be even at every level, or 1)
+ *   texture_mip         dr.texture(tex [Bt,H,W,C], uv [n,h,w,2], uv_da [n,h,w,4], filter_mode='linear-mipmap-linear'), wrap addressing;
+ *                       Bt = 1 broadcasts; pixels with rast[..,3] == 0 give 0 when d_rast is given (albedo[~fg] = 0, :264); C <= 8
+ *   texture_mip_backward  gradient w.r.t. the texture: overwrites d_g_tex0 [Bt,H,W,C]; d_g_mips is scratch of the mip stack's size
+ *   visibility_mip      `visibility_grad` (:470-475, :547-552): d sum(dr.texture(ones [n,map,map,1], texc, uv_da)) / d ones per view, accumulated
+ *                       in 2^-32 fixed point (order independent) -> d_vis [n,map,map] fp32
+ *   bake_accumulate_mip per texel and view: mip-mapped fetch of (rgb, view weight) from d_img0 [n,h,w,4] (+ its mip stack) at the texel's
+ *                       projection, times d_vis; d_accum [map,map,4] += (rgb * weight, weight)   (:573-582) */
+MVE_API int mve_rasterize_db(const float* d_pos, int B, int V, const int32_t* d_tri, int F, const float* d_rast, int H, int W,
+                             float* d_rast_db, void* stream);
+MVE_API int mve_interpolate_da(const float* d_attr, int attr_batch, int V, int C, const float* d_rast, const float* d_rast_db, int B, int npix,
+                               const int32_t* d_tri, int F, float* d_out, void* stream);
+MVE_API int mve_mip_levels(int H, int W);
+MVE_API size_t mve_mip_texels(int H, int W, int max_level);
+MVE_API int mve_mip_build(const float* d_tex0, int Bt, int H, int W, int C, int max_level, float* d_mips, void* stream);
+MVE_API int mve_texture_mip(const float* d_tex0, const float* d_mips, int Bt, int H, int W, int C, int max_level, const float* d_uv,
+                            const float* d_uv_da, const float* d_rast, int n, int h, int w, float* d_out, void* stream);
+MVE_API int mve_texture_mip_backward(const float* d_g_out, int Bt, int H, int W, int C, int max_level, const float* d_uv,
+                                     const float* d_uv_da, const float* d_rast, int n, int h, int w, float* d_g_tex0, float* d_g_mips,
+                                     void* stream);
+MVE_API size_t mve_visibility_mip_workspace_bytes(int n, int map_size, int max_level);
+MVE_API int mve_visibility_mip(const float* d_texc, const float* d_texc_da, const float* d_rast, int n, int h, int w, int map_size,
+                               int max_level, void* d_workspace, size_t workspace_bytes, float* d_vis, void* stream);
+MVE_API int mve_bake_accumulate_mip(const float* d_tex_rast, const float* d_tex_rast_db, const int32_t* d_f, int F, const float* d_v_img,
+                                    int V, const float* d_img0, const float* d_img_mips, int h, int w, int max_level, const float* d_vis,
+                                    int n, int map_size, float* d_accum, void* stream);
+
 /* Geometry gradients of dr.rasterize / dr.interpolate (nvdiffrast backward as the reference's mesh optimisation uses it through
  * MeshRenderer.forward, base_mesh_renderer.py:240-252):
  *   interpolate_backward_rast: grad_rast[pixel] = (sum_a g_a (a0 - a2), sum_a g_a (a1 - a2), 0, 0)   -- d out / d (u, v)

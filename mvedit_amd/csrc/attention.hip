@@ -451,14 +451,14 @@ __device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
 // takes C = -m_run (16 registers holding the lane's own query's value) instead of 0.  exp2 is then applied to the accumulator as it is:
 // the 32 v_fma per tile of the generic path disappear (rocprofv3: the kernel is VALU-issue bound -- SQ_ACTIVE_INST_VALU 77 % of the
 // SIMD cycles against 38 % MFMA busy).  A growing maximum (rare after the first tiles) subtracts the growth from S and rescales O.
-template <class Tag, bool SEG2, int NW, int NST, int WPS, bool PRE>
+template <class Tag, bool SEG2, int NW, int NST, int WPS, bool PRE, bool PIPE>
 __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p) {
     constexpr int D = 40, KB = 64, QB = 32 * NW;
     constexpr int K_ROW = 80, V_ROW = 96;
     constexpr int K_BYTES = KB * K_ROW, V_BYTES = KB * V_ROW, STAGE = K_BYTES + V_BYTES;
     constexpr int N_DMA = STAGE / 1024, K_DMA = K_BYTES / 1024, DMA_PER_WAVE = (N_DMA + NW - 1) / NW;
     static_assert(STAGE % 1024 == 0 && K_BYTES % 1024 == 0, "stage must split into whole LDS-DMA instructions");
-    static_assert(NST == 2 || NST == 3, "2 or 3 LDS stages");
+    static_assert(NST >= 2 && NST <= 4, "2 to 4 LDS stages");
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
     typedef T T2 __attribute__((ext_vector_type(2)));
@@ -582,49 +582,55 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
-    auto tile = [&](const unsigned char* St, int key0, auto masked_tag, bool first) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        f32x16 s[2], zero16;
+    struct S2 { f32x16 a, b; };                    // S^T of one 64-key tile: key blocks 0-31 and 32-63
+    struct PB { unsigned w[2][2][4]; };            // P^T in the PV operand layout: [key block][16-query group][register]
+
+    // S^T = K Q^T of the tile staged at St (PRE: minus the running maximum through the C operand)
+    auto qk = [&](const unsigned char* St) -> S2 {
+        f32x16 zero16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+        S2 s;
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const V8 ka = *reinterpret_cast<const V8*>(St + (st < 2 ? k_off01 + 32 * st : k_off2) + kb * 32 * K_ROW);
-                s[kb] = Tag::mfma32(ka, qf[st], st == 0 ? (PRE ? negm : zero16) : s[kb]);
-            }
+            const int o = st < 2 ? k_off01 + 32 * st : k_off2;
+            const V8 ka = *reinterpret_cast<const V8*>(St + o);
+            const V8 kb_ = *reinterpret_cast<const V8*>(St + o + 32 * K_ROW);
+            s.a = Tag::mfma32(ka, qf[st], st == 0 ? (PRE ? negm : zero16) : s.a);
+            s.b = Tag::mfma32(kb_, qf[st], st == 0 ? (PRE ? negm : zero16) : s.b);
         }
+        return s;
+    };
+
+    // online softmax of one tile, first half: mask the ragged tail, update m_run where the maximum grows (exact rescale of O; PRE: the
+    // logits already carry -m_run, so growth shows as a positive maximum and is subtracted from S)
+    auto softmax_max = [&](S2& s, int key0, auto masked_tag, bool first) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         if constexpr (MASKED) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Ltot) s[kb][r] = -INFINITY;
+            for (int r = 0; r < 16; ++r) {
+                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Ltot) s.a[r] = -INFINITY;
+                if (key0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Ltot) s.b[r] = -INFINITY;
+            }
         }
-        float mx = fmaxf(s[0][0], s[1][0]);
+        float mx = fmaxf(s.a[0], s.b[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);        // v_max3_f32 (built with -fno-honor-nans: no canonicalising v_max)
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s.a[r]), s.b[r]);          // v_max3_f32 (built with -fno-honor-nans: no canonicalising v_max)
         mx = mve_max_xor32(mx);
+        float a0 = 1.f, a1 = 1.f;
+        bool rescale = false;
         if constexpr (PRE) {
             // s = logit - m_run (m_run = 0 before the first tile): the maximum grows where mx > 0
             if (__builtin_expect(first || __any(mx > 0.f), 0)) {
                 const float delta = first ? mx : fmaxf(mx, 0.f);
                 m_run += delta;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+                for (int r = 0; r < 16; ++r) { s.a[r] -= delta; s.b[r] -= delta; negm[r] = -m_run; }
                 if (!first) {                            // O is still zero on the first tile (and exp2(-delta) may overflow there)
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
                     const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
-                    const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { oacc[i][0][r] *= a0; oacc[i][1][r] *= a1; }
+                    a0 = __uint_as_float(ar[0]); a1 = __uint_as_float(ar[1]);
+                    rescale = true;
                 }
             }
         } else {
@@ -635,27 +641,35 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
                 m_run = m_new;
                 // O^T's lane column is query (lane & 15) of its 16-query group: alpha of lanes {0-15, 32-47} resp. {16-31, 48-63}
                 const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
-                const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { oacc[i][0][r] *= a0; oacc[i][1][r] *= a1; }
+                a0 = __uint_as_float(ar[0]); a1 = __uint_as_float(ar[1]);
+                rescale = true;
             }
         }
+        if (rescale) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { oacc[i][0][r] *= a0; oacc[i][1][r] *= a1; }
+        }
+    };
+
+    // second half (straight-line): P = exp2(S - m), rounded to 16 bit, moved into the PV operand layout
+    auto softmax_exp = [&](const S2& s) -> PB {
         const float nm = -m_run;
-        unsigned pb[2][2][4];
+        PB pb;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            const f32x16& sk = kb ? s.b : s.a;
             unsigned pk[8];
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
                 float e0, e1;
                 if constexpr (PRE) {
-                    e0 = __builtin_amdgcn_exp2f(s[kb][2 * r2]);
-                    e1 = __builtin_amdgcn_exp2f(s[kb][2 * r2 + 1]);
+                    e0 = __builtin_amdgcn_exp2f(sk[2 * r2]);
+                    e1 = __builtin_amdgcn_exp2f(sk[2 * r2 + 1]);
                 } else {
-                    e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][2 * r2], sc, nm));
-                    e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][2 * r2 + 1], sc, nm));
+                    e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sk[2 * r2], sc, nm));
+                    e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sk[2 * r2 + 1], sc, nm));
                 }
                 pk[r2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e0, e1}, T2));
             }
@@ -663,13 +677,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
             for (int v = 0; v < 4; ++v) {
                 const int ai = v < 2 ? v : v + 2;
                 const auto r = __builtin_amdgcn_permlane16_swap(pk[ai], pk[ai + 2], false, false);
-                pb[kb][0][v] = r[0];
-                pb[kb][1][v] = r[1];
+                pb.w[kb][0][v] = r[0];
+                pb.w[kb][1][v] = r[1];
             }
         }
-        // V^T fragments by LDS transpose reads.  Issued from inline asm with their own lgkmcnt wait: hipcc has no memory operand for the
-        // transpose-read builtin and would drain the LDS-DMA of the NEXT tile (s_waitcnt vmcnt(0)) in front of it.  In-order LDS returns make
-        // the extra entries on the counter harmless for the compiler's own counted waits (they can only over-wait).
+        return pb;
+    };
+
+    // O^T += V^T P^T.  V^T fragments by LDS transpose reads, issued from inline asm with their own lgkmcnt wait: hipcc has no memory operand
+    // for the transpose-read builtin.  In-order LDS returns make the extra entries on the counter harmless for the compiler's own counted
+    // waits (they can only over-wait).
+    auto pv = [&](const unsigned char* St, const PB& pb) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             s16x4 lo[3], up[3];
@@ -689,41 +707,92 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
                 const V8 va = __builtin_bit_cast(V8, __builtin_shufflevector(lo[i], up[i], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
-                    const u32x4 pw = {pb[kb][f][0], pb[kb][f][1], pb[kb][f][2], pb[kb][f][3]};
+                    const u32x4 pw = {pb.w[kb][f][0], pb.w[kb][f][1], pb.w[kb][f][2], pb.w[kb][f][3]};
                     oacc[i][f] = Tag::mfma16(va, __builtin_bit_cast(V8, pw), oacc[i][f]);
                 }
             }
         }
     };
 
-    // NST stages, PD = NST - 1 tiles in flight.  Iteration t: issue tile t + PD into the stage tile t - 1 left (every wave is past the
-    // barrier that ended iteration t - 1), compute tile t, wait until only this wave's instructions of the tiles AFTER t + 1 are outstanding
-    // (VMEM returns in order: tile t + 1 has landed), drain the LDS reads, barrier.
-    constexpr int PD = NST - 1;
-    static_assert(DMA_PER_WAVE * (PD - 1) <= 3, "wait_sync covers at most three outstanding instructions");
-    auto wait_sync = [&](int keep) {          // keep: wave-uniform, 0..3
+    auto wait_sync = [&](int keep) {          // s_waitcnt vmcnt(keep) (wave-uniform, 0..3), drain the LDS reads, barrier
         if (keep >= 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
+    auto next_stage = [&](int off) { return off + STAGE == NST * STAGE ? 0 : off + STAGE; };
+
+    if constexpr (!PIPE) {
+        // NST stages, PD = NST - 1 tiles in flight.  Iteration t: issue tile t + PD into the stage tile t - 1 left (every wave is past the
+        // barrier that ended iteration t - 1), compute tile t, wait until only this wave's instructions of the tiles AFTER t + 1 are
+        // outstanding (VMEM returns in order: tile t + 1 has landed), drain the LDS reads, barrier.
+        constexpr int PD = NST - 1;
+        static_assert(DMA_PER_WAVE * (PD - 1) <= 3, "wait_sync covers at most three outstanding instructions");
 #pragma unroll
-    for (int i = 0; i < PD; ++i)
-        if (i < n_tiles) dma(i, i * STAGE);
-    // make hipcc wait for the Q loads HERE: left alone it puts their s_waitcnt vmcnt(0) at the first use inside the tile loop, where it
-    // would drain the in-flight LDS-DMA of every iteration
-    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]));
-    wait_sync(n_mine * ((n_tiles < PD ? n_tiles : PD) - 1));
-    int cur = 0, nxt = PD * STAGE;            // stage offsets of tile t and of tile t + PD
-    for (int t = 0; t < n_full; ++t) {        // full tiles: no key mask
-        if (t + PD < n_tiles) dma(t + PD, nxt);
-        tile(smem + cur, t * KB, std::false_type{}, t == 0);
-        const int last_issued = t + PD < n_tiles ? t + PD : n_tiles - 1;
-        wait_sync(last_issued > t + 1 ? n_mine * (last_issued - (t + 1)) : 0);
-        nxt = cur;
-        cur = cur + STAGE == NST * STAGE ? 0 : cur + STAGE;
+        for (int i = 0; i < PD; ++i)
+            if (i < n_tiles) dma(i, i * STAGE);
+        // make hipcc wait for the Q loads HERE: left alone it puts their s_waitcnt vmcnt(0) at the first use inside the tile loop, where it
+        // would drain the in-flight LDS-DMA of every iteration
+        asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]));
+        wait_sync(n_mine * ((n_tiles < PD ? n_tiles : PD) - 1));
+        int cur = 0, nxt = PD * STAGE;            // stage offsets of tile t and of tile t + PD
+        for (int t = 0; t < n_full; ++t) {        // full tiles: no key mask
+            if (t + PD < n_tiles) dma(t + PD, nxt);
+            S2 s = qk(smem + cur);
+            softmax_max(s, t * KB, std::false_type{}, t == 0);
+            const PB pb = softmax_exp(s);
+            pv(smem + cur, pb);
+            const int last_issued = t + PD < n_tiles ? t + PD : n_tiles - 1;
+            wait_sync(last_issued > t + 1 ? n_mine * (last_issued - (t + 1)) : 0);
+            nxt = cur;
+            cur = next_stage(cur);
+        }
+        if (n_full < n_tiles) {                   // ragged last tile (Lk = 77, ...): already landed
+            S2 s = qk(smem + cur);
+            softmax_max(s, n_full * KB, std::true_type{}, n_full == 0);
+            const PB pb = softmax_exp(s);
+            pv(smem + cur, pb);
+        }
+    } else {
+        // Software pipeline inside the wave: while the VALU runs the exponentials of tile t, the matrix pipe already computes S^T of tile t + 1
+        // (two independent instruction streams in one basic block, after the branchy maximum update so that the new tile's C operand is the
+        // updated maximum; rocprofv3 showed the un-pipelined wave spending 46 % of its cycles
+        // issue-stalled behind its own MFMA -> max -> exp -> MFMA chain with neither pipe saturated).  K of tile t + 1 must therefore be in
+        // LDS during iteration t: tile t + 2 is issued at the top of iteration t and fully waited for at its end (NST = 3: it lands in the
+        // stage tile t - 1 left; NST = 4: tile t + 3 is issued and one tile stays in flight across the barrier).
+        static_assert(NST >= 3, "the pipelined loop needs the next tile's K resident");
+        constexpr int PD = NST - 1;
+        static_assert(DMA_PER_WAVE * (PD - 2) <= 3, "wait_sync covers at most three outstanding instructions");
+#pragma unroll
+        for (int i = 0; i < PD; ++i)
+            if (i < n_tiles) dma(i, i * STAGE);
+        asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]));
+        {   // tiles 0 and 1 landed (the second one only if it exists); later ones may stay in flight
+            const int issued = n_tiles < PD ? n_tiles : PD;
+            wait_sync(issued > 2 ? n_mine * (issued - 2) : 0);
+        }
+        int cur = 0, nx1 = STAGE, nxt = (PD % NST) * STAGE;      // stage offsets of tiles t, t + 1 and t + PD
+        S2 sA = qk(smem), sB;
+        const int n_main = n_tiles - 1;           // tiles that have a successor; all of them are full tiles
+        auto step = [&](S2& sc_, S2& sn_, int t) {
+            if (t + PD < n_tiles) dma(t + PD, nxt);
+            softmax_max(sc_, t * KB, std::false_type{}, t == 0);           // branchy part first: m_run (and PRE's C operand) final for tile t
+            sn_ = qk(smem + nx1);                                          // matrix pipe: S^T of tile t + 1 ...
+            const PB pb = softmax_exp(sc_);                                // ... under the VALU's exponentials of tile t
+            pv(smem + cur, pb);
+            // tiles up to t + 2 must have landed before the next iteration reads K of tile t + 2
+            const int last_issued = t + PD < n_tiles ? t + PD : n_tiles - 1;
+            wait_sync(last_issued > t + 2 ? n_mine * (last_issued - (t + 2)) : 0);
+            nxt = cur; cur = nx1; nx1 = next_stage(nx1);
+        };
+        int t = 0;
+        for (; t + 2 <= n_main; t += 2) { step(sA, sB, t); step(sB, sA, t + 1); }
+        if (t < n_main) { step(sA, sB, t); sA = sB; ++t; }
+        if (n_full < n_tiles) softmax_max(sA, t * KB, std::true_type{}, t == 0);
+        else softmax_max(sA, t * KB, std::false_type{}, t == 0);
+        const PB pb = softmax_exp(sA);
+        pv(smem + cur, pb);
     }
-    if (n_full < n_tiles) tile(smem + cur, n_full * KB, std::true_type{}, n_full == 0);      // ragged last tile (Lk = 77, ...): already landed
 
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -756,14 +825,30 @@ int g_attn_variant = 11;
 template <class Tag, int D>
 int launch(const AttnParams& p, hipStream_t s) {
     if constexpr (D == 40) {
-        if (g_attn_variant >= 8 && g_attn_variant <= 11) {                        // k_attention3: 32x32x16 Q K^T, LDS-transposed V
-            // 8: 4 waves, 2 stages; 9: 8 waves, 2 stages; 10: 4 waves, 3 stages; 11: 8 waves, 3 stages
-            const bool w8 = g_attn_variant == 9 || g_attn_variant == 11, s3 = g_attn_variant >= 10;
+        if (g_attn_variant >= 8 && g_attn_variant <= 15) {                        // k_attention3: 32x32x16 Q K^T, LDS-transposed V
+            // 8: 4 waves, 2 stages; 9: 8 waves, 2 stages; 10: 4 waves, 3 stages; 11: 8 waves, 3 stages;
+            // 12..15: the software-pipelined loop (S^T of tile t + 1 under the softmax of tile t), 3 waves per SIMD:
+            //   12: 4 waves, 3 stages; 13: 4 waves, 4 stages; 14: 8 waves, 3 stages (2 per SIMD); 15: 8 waves, 4 stages
+            const int var = g_attn_variant;
+            const bool w8 = var == 9 || var == 11 || var >= 14;
             const unsigned grid3 = (unsigned)(((p.Lq + (w8 ? 255 : 127)) / (w8 ? 256 : 128)) * p.heads * p.B);
-#define MVE_A3P(SEG, NW_, NST_, PRE_) k_attention3<Tag, SEG, NW_, NST_, 4, PRE_><<<grid3, 64 * NW_, 0, s>>>(p)
-#define MVE_A3(SEG, NW_, NST_) do { if (p.prescaled) MVE_A3P(SEG, NW_, NST_, true); else MVE_A3P(SEG, NW_, NST_, false); } while (0)
-            if (p.Lk2 > 0) { if (w8) { if (s3) MVE_A3(true, 8, 3); else MVE_A3(true, 8, 2); } else { if (s3) MVE_A3(true, 4, 3); else MVE_A3(true, 4, 2); } }
-            else { if (w8) { if (s3) MVE_A3(false, 8, 3); else MVE_A3(false, 8, 2); } else { if (s3) MVE_A3(false, 4, 3); else MVE_A3(false, 4, 2); } }
+#define MVE_A3P(SEG, NW_, NST_, WPS_, PRE_, PIPE_) k_attention3<Tag, SEG, NW_, NST_, WPS_, PRE_, PIPE_><<<grid3, 64 * NW_, 0, s>>>(p)
+            // PRE (maximum subtracted through the MFMA's C operand) is compiled for the un-pipelined variants only: same-box A/B showed no gain
+            // from the 32 fewer v_fma per tile (the loop is bound by its dependency chain, not by VALU issue), and its 16 extra registers
+            // spill in the pipelined loop.  A pre-scaled Q runs the generic path with scale_log2e = 1.
+#define MVE_A3(NW_, NST_, WPS_, PIPE_) do { \
+                if (p.Lk2 > 0) { if (p.prescaled && !PIPE_) MVE_A3P(true, NW_, NST_, WPS_, (!PIPE_), PIPE_); else MVE_A3P(true, NW_, NST_, WPS_, false, PIPE_); } \
+                else { if (p.prescaled && !PIPE_) MVE_A3P(false, NW_, NST_, WPS_, (!PIPE_), PIPE_); else MVE_A3P(false, NW_, NST_, WPS_, false, PIPE_); } } while (0)
+            switch (var) {
+                case 8: MVE_A3(4, 2, 4, false); break;
+                case 9: MVE_A3(8, 2, 4, false); break;
+                case 10: MVE_A3(4, 3, 4, false); break;
+                case 11: MVE_A3(8, 3, 4, false); break;
+                case 12: MVE_A3(4, 3, 3, true); break;
+                case 13: MVE_A3(4, 4, 3, true); break;
+                case 14: MVE_A3(8, 3, 2, true); break;
+                default: MVE_A3(8, 4, 2, true); break;
+            }
 #undef MVE_A3P
 #undef MVE_A3
             MVE_LAUNCH_CHECK();

@@ -180,6 +180,83 @@ def _antialias_raw(color, rast, pos, tri, opp):
     return out
 
 
+def rasterize_db(pos, tri, rast):
+    """The second output of dr.rasterize: barycentric pixel differentials (du/dX, du/dY, dv/dX, dv/dY) [B,h,w,4] of `rast` (no gradient:
+    every reference call site that uses it for textures passes grad_db=False or never differentiates it)."""
+    pos, tri, rast = pos.detach().float().contiguous(), tri.to(torch.int32).contiguous(), rast.detach().contiguous()
+    B, V, _ = pos.shape
+    _, h, w, _ = rast.shape
+    out = torch.empty_like(rast)
+    with torch.cuda.device(pos.device):
+        _lib.call('mve_rasterize_db', _lib.ptr(pos), B, V, _lib.ptr(tri), tri.shape[0], _lib.ptr(rast), h, w, _lib.ptr(out), _lib.stream_ptr(pos.device))
+    return out
+
+
+def interpolate_da(attr, rast, rast_db, tri):
+    """The second output of dr.interpolate(attr, rast, tri, rast_db=rast_db, diff_attrs='all'): [B,h,w,2C] = (dA0/dX, dA0/dY, dA1/dX, ...)."""
+    attr = attr.detach().float().contiguous()
+    if attr.dim() == 2:
+        attr = attr[None]
+    rast, rast_db, tri = rast.detach().contiguous(), rast_db.contiguous(), tri.to(torch.int32).contiguous()
+    B, h, w, _ = rast.shape
+    Ba, V, C = attr.shape
+    out = torch.empty(B, h, w, 2 * C, dtype=torch.float32, device=rast.device)
+    with torch.cuda.device(rast.device):
+        _lib.call('mve_interpolate_da', _lib.ptr(attr), Ba, V, C, _lib.ptr(rast), _lib.ptr(rast_db), B, h * w, _lib.ptr(tri), tri.shape[0],
+                  _lib.ptr(out), _lib.stream_ptr(rast.device))
+    return out
+
+
+def _mip_levels(H, W, max_mip_level=None):
+    full = _lib.raw('mve_mip_levels')(int(H), int(W))
+    return full if max_mip_level is None else min(full, int(max_mip_level))
+
+
+def build_mips(tex, max_mip_level=None):
+    """tex [Bt,H,W,C] fp32 -> (mips [Bt, mip_texels*C], levels): the box-filtered level stack dr.texture builds for the mip-mapped filters."""
+    tex = tex.detach().float().contiguous()
+    Bt, H, W, C = tex.shape
+    lv = _mip_levels(H, W, max_mip_level)
+    mips = torch.empty(Bt, _lib.raw('mve_mip_texels')(H, W, lv) * C, dtype=torch.float32, device=tex.device)
+    with torch.cuda.device(tex.device):
+        _lib.call('mve_mip_build', _lib.ptr(tex), Bt, H, W, C, lv, _lib.ptr(mips), _lib.stream_ptr(tex.device))
+    return mips, lv
+
+
+def _texture_mip_raw(tex, mips, lv, uv, uv_da, rast):
+    n, h, w, _ = uv.shape
+    Bt, H, W, C = tex.shape
+    out = torch.empty(n, h, w, C, dtype=torch.float32, device=uv.device)
+    with torch.cuda.device(uv.device):
+        _lib.call('mve_texture_mip', _lib.ptr(tex), _lib.ptr(mips), Bt, H, W, C, lv, _lib.ptr(uv), _lib.ptr(uv_da),
+                  _lib.ptr(rast) if rast is not None else None, n, h, w, _lib.ptr(out), _lib.stream_ptr(uv.device))
+    return out
+
+
+class _TextureMipFn(torch.autograd.Function):
+    """dr.texture(..., filter_mode='linear-mipmap-linear') with its gradient w.r.t. the texture (through the level stack)."""
+
+    @staticmethod
+    def forward(ctx, tex, uv, uv_da, rast, max_mip_level):
+        mips, lv = build_mips(tex, max_mip_level)
+        ctx.save_for_backward(uv, uv_da, rast)
+        ctx.tex_shape, ctx.lv = tuple(tex.shape), lv
+        return _texture_mip_raw(tex, mips, lv, uv, uv_da, rast)
+
+    @staticmethod
+    def backward(ctx, g):
+        uv, uv_da, rast = ctx.saved_tensors
+        Bt, H, W, C = ctx.tex_shape
+        n, h, w, _ = uv.shape
+        g = g.float().contiguous()
+        g_tex = torch.empty(Bt, H, W, C, dtype=torch.float32, device=uv.device)
+        g_mips = torch.empty(Bt, max(1, _lib.raw('mve_mip_texels')(H, W, ctx.lv) * C), dtype=torch.float32, device=uv.device)
+        with torch.cuda.device(uv.device):
+            _lib.call('mve_texture_mip_backward', _lib.ptr(g), Bt, H, W, C, ctx.lv, _lib.ptr(uv), _lib.ptr(uv_da),
+                      _lib.ptr(rast) if rast is not None else None, n, h, w, _lib.ptr(g_tex), _lib.ptr(g_mips), _lib.stream_ptr(uv.device))
+        return g_tex, None, None, None, None
+
+
 class _TextureFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tex, uv, rast):
@@ -200,9 +277,23 @@ class _TextureFn(torch.autograd.Function):
         return g_tex, None, None
 
 
-def texture(tex, uv, rast=None):
-    """dr.texture(tex [1|n,th,tw,C], uv [n,h,w,2]) with the bilinear filter, wrap addressing; background -> 0 when rast is given.
-    Differentiable w.r.t. tex."""
+def texture(tex, uv, rast=None, uv_da=None, filter_mode='linear', max_mip_level=None):
+    """dr.texture(tex [1|n,th,tw,C], uv [n,h,w,2], uv_da=..., filter_mode=...), wrap addressing; background -> 0 when rast is given.
+    filter_mode 'linear' (bilinear) or 'linear-mipmap-linear' (needs uv_da [n,h,w,4], the attribute differentials of uv).
+    Differentiable w.r.t. tex; uv / uv_da carry no gradient (refused loudly: the reference propagates it through nvdiffrast)."""
+    if torch.is_grad_enabled() and (uv.requires_grad or (uv_da is not None and uv_da.requires_grad)):
+        raise NotImplementedError('texture: no gradient w.r.t. uv / uv_da is built (geometry of a textured mesh is not optimised by the '
+                                  'pipelines); detach them or call under torch.no_grad()')
+    assert filter_mode in ('linear', 'linear-mipmap-linear'), filter_mode
+    if filter_mode == 'linear-mipmap-linear':
+        assert uv_da is not None, "filter_mode='linear-mipmap-linear' needs uv_da (interpolate_da of the texture coordinates)"
+        uvc, dac = uv.detach().float().contiguous(), uv_da.detach().float().contiguous()
+        rc = rast.detach().contiguous() if rast is not None else None
+        if torch.is_grad_enabled() and tex.requires_grad:
+            return _TextureMipFn.apply(tex.float().contiguous(), uvc, dac, rc, max_mip_level)
+        t = tex.detach().float().contiguous()
+        mips, lv = build_mips(t, max_mip_level)
+        return _texture_mip_raw(t, mips, lv, uvc, dac, rc)
     if torch.is_grad_enabled() and tex.requires_grad:
         return _TextureFn.apply(tex.float().contiguous(), uv.detach().float().contiguous(), rast.contiguous() if rast is not None else None)
     return _texture_raw(tex, uv, rast)
@@ -235,11 +326,14 @@ def box_downsample(x, factor):
 
 class MeshRenderer:
     """The reference's MeshRenderer for one mesh (num_scenes = 1, as in every MVEdit pipeline):
-    forward (base_mesh_renderer.py:207-395) and bake_multiview (:507-603).  Texture fetches are bilinear (the reference's
-    default 'linear-mipmap-linear' pyramid is not reproduced); forward is inference-only (no autograd through the kernels)."""
+    forward (base_mesh_renderer.py:207-395), get_cam_weights_uv (:425-505) and bake_multiview (:507-603), with the reference's
+    `texture_filter` ('linear-mipmap-linear' by default, :196: screen-space UV differentials out of rasterize / interpolate, a box-filtered
+    level stack and a trilinear fetch; 'linear' = plain bilinear).  forward is differentiable w.r.t. the texture / vertex colours and,
+    through rasterize / interpolate / antialias, w.r.t. the geometry."""
 
-    def __init__(self, near=0.1, far=10, ssaa=1):
-        self.near, self.far, self.ssaa = near, far, ssaa
+    def __init__(self, near=0.1, far=10, ssaa=1, texture_filter='linear-mipmap-linear'):
+        assert texture_filter in ('linear', 'linear-mipmap-linear')
+        self.near, self.far, self.ssaa, self.texture_filter = near, far, ssaa, texture_filter
 
     def project(self, v, poses, intrinsics, h, w):
         """v [V,3], poses [b,3,4] c2w (OpenCV), intrinsics [b,4] -> (v_cam [b,V,3], v_clip [b,V,4]); :222-237."""
@@ -289,7 +383,10 @@ class MeshRenderer:
         fg = rast[..., 3] > 0
         if getattr(mesh, 'vt', None) is not None and getattr(mesh, 'albedo', None) is not None:
             texc = interpolate(mesh.vt[None], rast, mesh.ft)
-            albedo = texture(mesh.albedo[None, ..., :3], texc, rast)                  # background written as 0 (:262)
+            texc_da = None
+            if self.texture_filter == 'linear-mipmap-linear':                         # :241, :260-261
+                texc_da = interpolate_da(mesh.vt[None], rast, rasterize_db(g['v_clip'], f, rast), mesh.ft)
+            albedo = texture(mesh.albedo[None, ..., :3], texc, rast, uv_da=texc_da, filter_mode=self.texture_filter)   # background 0 (:264)
         elif getattr(mesh, 'vc', None) is not None:
             rgba = interpolate(mesh.vc.float()[None] if mesh.vc.dim() == 2 else mesh.vc.float(), rast, f)
             alpha = alpha * rgba[..., 3:4]
@@ -340,25 +437,37 @@ class MeshRenderer:
 
     def _view_batch(self, v, f, vt, ft, poses, intrinsics, alphas, h, w, map_size, cos_weight_pow):
         """Per-view geometry shared by bake_multiview and get_cam_weights_uv (base_mesh_renderer.py:441-481 == :527-566):
-        -> (visibility u64 fixed point [bs,map,map], eroded cos^pow * alpha weight image [bs,h,w], v_img [bs,V,2])."""
+        -> (visibility fp32 [bs,map,map] = `visibility_grad`, eroded cos^pow * alpha weight image [bs,h,w], v_img [bs,V,2], and for the
+        bilinear filter the visibility in its 2^-32 fixed-point form, which mve_bake_accumulate consumes)."""
         dev = v.device
         bs = poses.shape[0]
         sp = _lib.stream_ptr(dev)
+        mip = self.texture_filter == 'linear-mipmap-linear'
         v_cam, v_clip, _ = self.project(v, poses, intrinsics, h, w)
         rast = rasterize(v_clip, f, (h, w))
         texc = interpolate(vt[None], rast, ft)
         depth = 1 / interpolate(-v_cam[..., 2:3].contiguous(), rast, f)[..., 0]
         depth = depth.masked_fill(~(rast[..., 3] > 0), 0).contiguous()
         v_img = (v_clip[..., :2] / v_clip[..., 3:] * 0.5 + 0.5).contiguous()
-        vis = torch.empty(bs, map_size, map_size, dtype=torch.int64, device=dev)
         tmp = torch.empty(bs, h, w, dtype=torch.float32, device=dev)
         w_img = torch.empty_like(tmp)
         alpha_b, intr_b = alphas.float().contiguous(), intrinsics.float().contiguous()
         with torch.cuda.device(dev):
-            _lib.call('mve_splat_visibility', _lib.ptr(texc), _lib.ptr(rast), bs, h, w, map_size, _lib.ptr(vis), sp)
+            if mip:                 # gradient of the trilinear fetch w.r.t. a texture of ones, through the level stack (:466-475)
+                texc_da = interpolate_da(vt[None], rast, rasterize_db(v_clip, f, rast), ft)
+                lv = _mip_levels(map_size, map_size)
+                nbytes = _lib.raw('mve_visibility_mip_workspace_bytes')(bs, map_size, lv)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                vis, vis64 = torch.empty(bs, map_size, map_size, dtype=torch.float32, device=dev), None
+                _lib.call('mve_visibility_mip', _lib.ptr(texc), _lib.ptr(texc_da), _lib.ptr(rast), bs, h, w, map_size, lv, _lib.ptr(ws), nbytes,
+                          _lib.ptr(vis), sp)
+            else:
+                vis64 = torch.empty(bs, map_size, map_size, dtype=torch.int64, device=dev)
+                _lib.call('mve_splat_visibility', _lib.ptr(texc), _lib.ptr(rast), bs, h, w, map_size, _lib.ptr(vis64), sp)
+                vis = (vis64.double() / 4294967296.0).float()
             _lib.call('mve_view_weight', _lib.ptr(depth), _lib.ptr(alpha_b), _lib.ptr(intr_b), bs, h, w, float(cos_weight_pow),
                       _lib.ptr(tmp), _lib.ptr(w_img), sp)
-        return vis, w_img, v_img
+        return vis, w_img, v_img, vis64
 
     def get_cam_weights_uv(self, meshes, poses, intrinsics, alphas=None, render_size=512, map_size=1024, render_bs=8, cos_weight_pow=1.0):
         """base_mesh_renderer.py:425-505: per-view, per-texel blending weights (cos^pow of the viewing angle, eroded, fetched at the
@@ -379,14 +488,18 @@ class MeshRenderer:
         vt_clip = torch.cat([vt * 2 - 1, vt.new_tensor([[0., 1.]]).expand(vt.size(0), -1)], dim=-1)
         tex_rast = rasterize(vt_clip[None], ft, (map_size, map_size))
         valid = tex_rast[0, ..., 3] > 0
+        mip = self.texture_filter == 'linear-mipmap-linear'
+        tex_rast_db = rasterize_db(vt_clip[None], ft, tex_rast) if mip else None
         out = []
         for i0 in range(0, n, render_bs):
             sl = slice(i0, min(i0 + render_bs, n))
             bs = sl.stop - sl.start
-            vis, w_img, v_img = self._view_batch(v, f, vt, ft, poses[sl], intrinsics[sl], alphas[sl], h, w, map_size, cos_weight_pow)
-            imgc = interpolate(v_img, tex_rast.expand(bs, -1, -1, -1).contiguous(), f)
-            tex = texture(w_img[..., None], imgc)
-            out.append(tex * (vis.double() / 4294967296.0).float()[..., None])
+            vis, w_img, v_img, _ = self._view_batch(v, f, vt, ft, poses[sl], intrinsics[sl], alphas[sl], h, w, map_size, cos_weight_pow)
+            tr = tex_rast.expand(bs, -1, -1, -1).contiguous()
+            imgc = interpolate(v_img, tr, f)
+            imgc_da = interpolate_da(v_img, tr, tex_rast_db.expand(bs, -1, -1, -1).contiguous(), f) if mip else None      # :496-497
+            tex = texture(w_img[..., None], imgc, uv_da=imgc_da, filter_mode=self.texture_filter)
+            out.append(tex * vis[..., None])
         return torch.cat(out, dim=0)[None], valid[None]
 
     def bake_multiview(self, meshes, images, alphas, poses, intrinsics, map_size=1024, cos_weight_pow=8.0, base_weight=0.0,
@@ -395,7 +508,7 @@ class MeshRenderer:
 
         meshes: a list with ONE object exposing v [V,3], f [F,3], vt [Vt,2], ft [F,3] (and optionally albedo [h,w,3|4]);
         images [1,n,h,w,3], alphas [1,n,h,w,1], poses [1,n,3|4,4], intrinsics [1,n,4].  Sets mesh.albedo [map,map,4] and
-        mesh.textureless = False, returns [mesh].  Bilinear (not mip-mapped) filtering -- see csrc/raster.hip."""
+        mesh.textureless = False, returns [mesh].  Filtering follows self.texture_filter (csrc/texture_mip.hip / csrc/raster.hip)."""
         assert len(meshes) == 1, 'only support one mesh'
         mesh = meshes[0]
         images, alphas = images[0].float().contiguous(), alphas[0].float().contiguous()
@@ -410,28 +523,25 @@ class MeshRenderer:
         vt_clip = torch.cat([vt * 2 - 1, vt.new_tensor([[0., 1.]]).expand(vt.size(0), -1)], dim=-1)
         tex_rast = rasterize(vt_clip[None], ft, (map_size, map_size))[0].contiguous()
         valid = tex_rast[..., 3] > 0
+        mip = self.texture_filter == 'linear-mipmap-linear'
+        tex_rast_db = rasterize_db(vt_clip[None], ft, tex_rast[None])[0].contiguous() if mip else None          # :521
         accum = torch.zeros(map_size, map_size, 4, dtype=torch.float32, device=dev)
         debug = dict(vis=[], wimg=[], tex_rast=tex_rast)
 
         for i0 in range(0, n, render_bs):
             sl = slice(i0, min(i0 + render_bs, n))
             bs = sl.stop - sl.start
-            v_cam, v_clip, _ = self.project(v, poses[sl], intrinsics[sl], h, w)
-            rast = rasterize(v_clip, f, (h, w))
-            texc = interpolate(vt[None], rast, ft)
-            depth = 1 / interpolate(-v_cam[..., 2:3].contiguous(), rast, f)[..., 0]
-            depth = depth.masked_fill(~(rast[..., 3] > 0), 0).contiguous()
-            v_img = (v_clip[..., :2] / v_clip[..., 3:] * 0.5 + 0.5).contiguous()
-            vis = torch.empty(bs, map_size, map_size, dtype=torch.int64, device=dev)
-            tmp = torch.empty(bs, h, w, dtype=torch.float32, device=dev)
-            w_img = torch.empty_like(tmp)
-            img_b, alpha_b, intr_b = images[sl].contiguous(), alphas[sl].contiguous(), intrinsics[sl].contiguous()
+            vis, w_img, v_img, vis64 = self._view_batch(v, f, vt, ft, poses[sl], intrinsics[sl], alphas[sl], h, w, map_size, cos_weight_pow)
+            img_b = images[sl].contiguous()
             with torch.cuda.device(dev):
-                _lib.call('mve_splat_visibility', _lib.ptr(texc), _lib.ptr(rast), bs, h, w, map_size, _lib.ptr(vis), sp)
-                _lib.call('mve_view_weight', _lib.ptr(depth), _lib.ptr(alpha_b), _lib.ptr(intr_b), bs, h, w, float(cos_weight_pow),
-                          _lib.ptr(tmp), _lib.ptr(w_img), sp)
-                _lib.call('mve_bake_accumulate', _lib.ptr(tex_rast), _lib.ptr(f), f.shape[0], _lib.ptr(v_img), v_img.shape[1],
-                          _lib.ptr(img_b), _lib.ptr(w_img), _lib.ptr(vis), bs, h, w, map_size, _lib.ptr(accum), sp)
+                if mip:             # dr.texture(cat([images, img_space_weight]), imgc, uv_da=imgc_db) per texel and view (:573-577)
+                    img4 = torch.cat([img_b, w_img[..., None]], dim=-1).contiguous()
+                    mips, lv = build_mips(img4)
+                    _lib.call('mve_bake_accumulate_mip', _lib.ptr(tex_rast), _lib.ptr(tex_rast_db), _lib.ptr(f), f.shape[0], _lib.ptr(v_img),
+                              v_img.shape[1], _lib.ptr(img4), _lib.ptr(mips), h, w, lv, _lib.ptr(vis), bs, map_size, _lib.ptr(accum), sp)
+                else:
+                    _lib.call('mve_bake_accumulate', _lib.ptr(tex_rast), _lib.ptr(f), f.shape[0], _lib.ptr(v_img), v_img.shape[1],
+                              _lib.ptr(img_b), _lib.ptr(w_img), _lib.ptr(vis64), bs, h, w, map_size, _lib.ptr(accum), sp)
             if return_debug:
                 debug['vis'].append(vis)
                 debug['wimg'].append(w_img)

@@ -4,7 +4,8 @@
 PARITY UNPINNED: the reference's rasterisation, interpolation and texture fetches are nvdiffrast calls (requirements.txt:3,
 not available here).  This file restates the reference's data flow line by line on top of oracle/raster.py, with
   * dr.texture(..., filter_mode) restated as a plain bilinear fetch with wrap addressing (nvdiffrast's default boundary
-    mode); the mip pyramid of the reference's default 'linear-mipmap-linear' is NOT reproduced;
+    mode) for texture_filter='linear', and as the mip-mapped trilinear fetch of oracle/texture_mip_oracle.py for the reference's
+    default 'linear-mipmap-linear';
   * the visibility term d sum(dr.texture(ones, texc)) / d ones  (:547-552) restated as what that gradient is for the
     bilinear filter: the scatter-add of each foreground pixel's four bilinear weights.
 The geometry helpers it calls (get_ray_directions, depth_to_normal) ARE pinned against reference-executed golden vectors
@@ -61,6 +62,36 @@ def texture_bilinear(tex, uv):
     return out
 
 
+def texture_mip(tex, uv, pos, tri, rast, attr, attr_tri, tex_attr_batch=None):
+    """dr.texture(tex [Bt,H,W,C], uv [n,h,w,2], uv_da, 'linear-mipmap-linear') with uv_da = the pixel differentials of `attr` (the
+    attribute uv was interpolated from: [V,2] or [n,V,2]) over the rasterisation (pos [n,V,4], tri, rast) -- numpy in, numpy out, through
+    oracle/texture_mip_oracle.py."""
+    import torch
+    from . import texture_mip_oracle as T
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    rast_t = t(rast.astype(f32))
+    db = T.rasterize_db(t(pos.astype(f32)), t(np.asarray(tri)), rast_t)
+    da = T.interpolate_da(t(np.asarray(attr, f32)), rast_t, db, t(np.asarray(attr_tri)))
+    return T.texture(t(tex.astype(f32)), t(uv.astype(f32)), da).numpy()
+
+
+def visibility_mip(texc, pos, tri, rast, vt, ft, map_size):
+    """`visibility_grad` with the mip-mapped filter (:466-475, :547-552): gradient of sum(dr.texture(ones, texc, uv_da)) w.r.t. the ones,
+    over the covered pixels (the background pixels' uv = 0 splat onto the atlas corner is left out, as in splat_visibility)."""
+    import torch
+    from . import texture_mip_oracle as T
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    rast_t = t(rast.astype(f32))
+    db = T.rasterize_db(t(pos.astype(f32)), t(np.asarray(tri)), rast_t)
+    da = T.interpolate_da(t(np.asarray(vt, f32)), rast_t, db, t(np.asarray(ft)))
+    n = rast.shape[0]
+    ones = torch.ones(n, map_size, map_size, 1, dtype=torch.float64, requires_grad=True)
+    out = T.texture(ones, t(texc.astype(f32)).double(), da.double())
+    fg = (rast_t[..., 3] > 0)[..., None]
+    g, = torch.autograd.grad((out * fg).sum(), ones)
+    return g[..., 0].numpy()
+
+
 def splat_visibility(texc, fg, map_size):
     """sum of bilinear footprint weights per texel; texc [h,w,2], fg [h,w] -> [map,map] float64."""
     ix, iy, wx, wy = _taps(texc[fg][:, 0], texc[fg][:, 1], map_size, map_size)
@@ -88,7 +119,7 @@ def view_weight(depth, alpha, intrinsics, cos_weight_pow):
 
 
 def bake_multiview(v, f, vt, ft, images, alphas, poses, intrinsics, map_size, cos_weight_pow=8.0, near=0.1, far=10.0,
-                   projected=None, dilate=None):
+                   projected=None, dilate=None, texture_filter='linear'):
     """Returns (albedo [map,map,3] before dilation/clamp, accum [map,map,4], valid [map,map], per-view debug dict)."""
     n, h, w, _ = images.shape
     vt = np.asarray(vt, f32)
@@ -106,11 +137,17 @@ def bake_multiview(v, f, vt, ft, images, alphas, poses, intrinsics, map_size, co
     v_img = (v_clip[..., :2] / v_clip[..., 3:] * f32(0.5) + f32(0.5)).astype(f32)
     accum = np.zeros((map_size, map_size, 4), f32)
     vis_all = []
+    mip = texture_filter == 'linear-mipmap-linear'
+    vis_mip = visibility_mip(texc, v_clip, f, rast, vt, ft, map_size) if mip else None
     for i in range(n):
-        vis = splat_visibility(texc[i], fg[i], map_size)
+        vis = vis_mip[i] if mip else splat_visibility(texc[i], fg[i], map_size)
         vis_all.append(vis)
         imgc = OR.interpolate(v_img[i:i + 1], tex_rast[None], f)[0]
-        tex = texture_bilinear(np.concatenate([images[i], wimg[i][..., None]], axis=-1).astype(f32), imgc)
+        img4 = np.concatenate([images[i], wimg[i][..., None]], axis=-1).astype(f32)
+        if mip:       # :573-577: image-space coordinates and their differentials over the ATLAS rasterisation
+            tex = texture_mip(img4[None], imgc[None], vt_clip, ft, tex_rast[None], v_img[i], f)[0]
+        else:
+            tex = texture_bilinear(img4, imgc)
         weight = (tex[..., 3] * vis.astype(f32)).astype(f32)
         accum[..., :3] = accum[..., :3] + tex[..., :3] * weight[..., None]
         accum[..., 3] = accum[..., 3] + weight

@@ -2,7 +2,7 @@
 
 Restatement of `MeshRenderer.forward`, single-scene branch (lib/models/decoders/mesh_renderer/base_mesh_renderer.py:207-395) on top of
 the raster oracle: depth = 1 / interpolate(-z_cam), normals rotated into the camera frame and mapped to [0, 1], albedo from the texture
-(bilinear) or the vertex colours, optional edge dilation, antialias over the packed (rgba, depth, normal) image, SSAA box filter.
+(bilinear, or mip-mapped with texture_filter='linear-mipmap-linear') or the vertex colours, optional edge dilation, antialias over the packed (rgba, depth, normal) image, SSAA box filter.
 
 PINNED (orchestration): tests/test_mesh_forward_ref.py compares it with the reference's own `forward` executed over a stand-in `dr`
 module (tests/golden/make_mesh_forward_golden.py).  The raster / antialias / filter primitives stay this repo's specification
@@ -16,7 +16,7 @@ f32 = np.float32
 
 
 def mesh_forward(v, f, vn, fn, projected, r_c2w, h, w, vt=None, ft=None, albedo=None, vc=None, normal_bg=(0.5, 0.5, 1.0), aa=True, ssaa=1,
-                 shading_fun=None, dilate=None):
+                 shading_fun=None, dilate=None, texture_filter='linear'):
     """projected = (v_cam [n,V,3], v_clip [n,V,4]) at the SSAA resolution; r_c2w [n,3,3] (OpenGL camera-to-world rotation).
     -> rgba [n,h,w,4], depth [n,h,w], normal [n,h,w,3] at the output resolution."""
     v_cam, v_clip = projected
@@ -34,7 +34,10 @@ def mesh_forward(v, f, vn, fn, projected, r_c2w, h, w, vt=None, ft=None, albedo=
     alpha = fg[..., None].astype(f32)
     if vt is not None and albedo is not None:
         texc = OR.interpolate(vt[None], rast, ft)
-        alb = np.stack([BO.texture_bilinear(albedo[..., :3], texc[i]) for i in range(n)])
+        if texture_filter == 'linear-mipmap-linear':          # :241, :260-264 (oracle/texture_mip_oracle.py)
+            alb = BO.texture_mip(albedo[..., :3][None], texc, v_clip, f, rast, vt, ft)
+        else:
+            alb = np.stack([BO.texture_bilinear(albedo[..., :3], texc[i]) for i in range(n)])
         alb[~fg] = 0
     elif vc is not None:
         rgba_v = OR.interpolate(vc[None], rast, f)

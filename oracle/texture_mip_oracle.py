@@ -64,7 +64,9 @@ def interpolate_da(attr, rast, rast_db, tri):
     """attr [V,C] or [B,V,C] -> attribute pixel differentials [B,H,W,2C] (dA0/dX, dA0/dY, dA1/dX, ...); zeros on empty pixels."""
     B, H, W, _ = rast.shape
     if attr.dim() == 2:
-        attr = attr[None].expand(B, -1, -1)
+        attr = attr[None]
+    if attr.shape[0] == 1:
+        attr = attr.expand(B, -1, -1)
     idx = rast[..., 3].long() - 1
     fg = idx >= 0
     t = tri.long()[idx.clamp(min=0)]

@@ -24,6 +24,7 @@ from scene import face_atlas, icosphere  # noqa: E402
 
 REF = '/root/reference'
 OUT = os.path.join(HERE, 'bake_ref.npz')
+MIP_MAP = 128          # atlas size of the mip-mapped case (64^2 views of a small object: minified fetches on both sides)
 
 
 def _fn(path, name, ns, cls=None):
@@ -51,26 +52,33 @@ def texture_torch(tex, uv):
     return out
 
 
-def dr_module():
+def dr_module(mip=False):
+    """mip=True: rasterize / interpolate also return the pixel differentials and dr.texture honours filter_mode / uv_da through
+    oracle/texture_mip_oracle.py (nvdiffrast's algorithm restated in torch, differentiable w.r.t. the texture)."""
+    from oracle import texture_mip_oracle as TM
     dr = types.SimpleNamespace()
 
     def rasterize(glctx, pos, tri, resolution, grad_db=False):
         rast = torch.from_numpy(np.asarray(RO.rasterize(pos.detach().numpy(), tri.numpy(), tuple(resolution))))
-        return rast, torch.zeros_like(rast)
+        return rast, (TM.rasterize_db(pos.detach().float(), tri, rast) if mip else torch.zeros_like(rast))
 
     def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
-        if attr.dim() == 2:                 # [V, A]: shared by all views
-            attr = attr[None]
-        out = torch.from_numpy(np.asarray(RO.interpolate(attr.detach().numpy(), rast.numpy(), tri.numpy())))
+        shared = attr.dim() == 2            # [V, A]: shared by all views
+        a3 = attr[None] if shared else attr
+        out = torch.from_numpy(np.asarray(RO.interpolate(a3.detach().numpy(), rast.numpy(), tri.numpy())))
+        if mip and rast_db is not None and diff_attrs is not None:
+            return out, TM.interpolate_da(attr.detach().float(), rast, rast_db, tri)
         return out, torch.zeros(*out.shape[:-1], 2 * out.shape[-1])
 
     def texture(tex, uv, uv_da=None, filter_mode=None):
+        if mip and filter_mode == 'linear-mipmap-linear':
+            return TM.texture(tex, uv, uv_da, filter_mode)
         return texture_torch(tex, uv)
     dr.rasterize, dr.interpolate, dr.texture = rasterize, interpolate, texture
     return dr
 
 
-def scene(S=48, n_views=4, map_size=64):
+def scene(S=64, n_views=4, map_size=64):
     v, f = icosphere(2, 0.6)
     v = (v * (1 + 0.15 * np.sin(5 * v[:, :1]))).astype(np.float32)
     vt, ft = face_atlas(f)
@@ -116,8 +124,18 @@ def main():
     alphas = np.stack(alphas)
     (mesh,) = bake(r, [mesh], t(images)[None], t(alphas)[None], t(poses)[None], t(intr)[None], map_size=map_size, cos_weight_pow=8.0,
                    render_bs=3)
-    np.savez_compressed(OUT, alphas=alphas, albedo=mesh.albedo.numpy())
-    print('wrote', OUT, os.path.getsize(OUT), mesh.albedo.shape, float(mesh.albedo[..., :3].mean()))
+    albedo_linear = mesh.albedo.numpy()
+    # the reference's DEFAULT filter: the same method over the mip-mapped stand-in (atlas twice as fine as the views can resolve, so that
+    # both the visibility footprints and the image fetches really leave level 0)
+    ns['dr'] = dr_module(mip=True)
+    bake = _fn(os.path.join(REF, 'lib/models/decoders/mesh_renderer/base_mesh_renderer.py'), 'bake_multiview', ns, cls='MeshRenderer')
+    r.texture_filter = 'linear-mipmap-linear'
+    mesh2 = types.SimpleNamespace(v=t(v), f=t(f), vt=t(vt), ft=t(ft), albedo=None, vc=None, textureless=True)
+    (mesh2,) = bake(r, [mesh2], t(images)[None], t(alphas)[None], t(poses)[None], t(intr)[None], map_size=MIP_MAP, cos_weight_pow=8.0,
+                    render_bs=3)
+    np.savez_compressed(OUT, alphas=alphas, albedo=albedo_linear, albedo_mip=mesh2.albedo.numpy())
+    print('wrote', OUT, os.path.getsize(OUT), mesh.albedo.shape, float(mesh.albedo[..., :3].mean()), mesh2.albedo.shape,
+          float(mesh2.albedo[..., :3].mean()))
 
 
 if __name__ == '__main__':

@@ -64,14 +64,33 @@ def main():
     forward = B._fn(path, 'forward', ns, cls='MeshRenderer')
     t = torch.from_numpy
     out = {}
-    for tag, ssaa, kw in (('tex_aa', 1, {}), ('tex_aa_ssaa2', 2, {}), ('vc_shade_dilate', 1, dict(shading_fun=shade, dilate_edges=1, aa=False))):
-        r = types.SimpleNamespace(glctx=None, near=0.01, far=100.0, texture_filter='linear', ssaa=ssaa)
-        if tag.startswith('tex'):
+    tex_big = np.random.default_rng(5).random((256, 256, 4)).astype(np.float32)     # 256^2 atlas seen at 64^2: minified 2-4x
+    out['tex_big'] = tex_big
+    for tag, ssaa, kw in (('tex_aa', 1, {}), ('tex_aa_ssaa2', 2, {}), ('vc_shade_dilate', 1, dict(shading_fun=shade, dilate_edges=1, aa=False)),
+                          ('texmip_aa', 1, {}), ('texmip_aa_ssaa2', 2, {})):
+        mip = tag.startswith('texmip')
+        if mip:             # the reference's default filter over the mip-mapped stand-in (make_bake_golden.dr_module(mip=True))
+            dr2 = B.dr_module(mip=True)
+            base2 = dr2.rasterize
+
+            def rasterize2(glctx, pos, tri, resolution, grad_db=False, _b=base2):
+                recorded['v_clip'] = pos.detach().numpy().copy()
+                return _b(glctx, pos, tri, resolution, grad_db)
+            dr2.rasterize, dr2.antialias = rasterize2, antialias
+            ns2 = dict(torch=torch, F=F, dr=dr2, edge_dilation=ed.edge_dilation)
+            B._fn(path, 'interpolate_hwc', ns2)
+            forward_fn = B._fn(path, 'forward', ns2, cls='MeshRenderer')
+        else:
+            forward_fn = forward
+        r = types.SimpleNamespace(glctx=None, near=0.01, far=100.0, texture_filter='linear-mipmap-linear' if mip else 'linear', ssaa=ssaa)
+        if mip:
+            mesh = types.SimpleNamespace(v=t(v), f=t(f), vn=t(vn), fn=t(f), vt=t(vt), ft=t(ft), albedo=t(tex_big), vc=None)
+        elif tag.startswith('tex'):
             mesh = types.SimpleNamespace(v=t(v), f=t(f), vn=t(vn), fn=t(f), vt=t(vt), ft=t(ft), albedo=t(tex), vc=None)
         else:
             mesh = types.SimpleNamespace(v=t(v), f=t(f), vn=t(vn), fn=t(f), vt=None, ft=None, albedo=None, vc=t(vcol))
         with torch.no_grad():
-            res = forward(r, [mesh], t(poses)[None], t(intr)[None], S, S, **kw)
+            res = forward_fn(r, [mesh], t(poses)[None], t(intr)[None], S, S, **kw)
         out[f'{tag}_rgba'], out[f'{tag}_depth'], out[f'{tag}_normal'] = (res[k][0].detach().numpy() for k in ('rgba', 'depth', 'normal'))
         out[f'{tag}_v_clip'] = recorded['v_clip']
     np.savez_compressed(OUT, **out)

@@ -29,17 +29,22 @@ def test_edge_dilation_restatement_is_bit_exact():
     assert np.array_equal(MF.edge_dilation(g['dil_img'], g['dil_mask'], 1, 2), g['dil_out_r1_i2'])
 
 
-@pytest.mark.parametrize('tag,ssaa', [('tex_aa', 1), ('tex_aa_ssaa2', 2), ('vc_shade_dilate', 1)])
+@pytest.mark.parametrize('tag,ssaa', [('tex_aa', 1), ('tex_aa_ssaa2', 2), ('vc_shade_dilate', 1), ('texmip_aa', 1), ('texmip_aa_ssaa2', 2)])
 def test_mesh_forward_restatement_equals_reference_output(tag, ssaa):
+    """texmip_*: the reference's default texture_filter 'linear-mipmap-linear' (a 256^2 atlas seen at 64^2 / 128^2)."""
     mod = _mod()
     v, f, vn, vt, ft, tex, vcol, poses, intr, S = mod.scene()
     v_cam, _ = BO.project(v, poses, intr * ssaa, S * ssaa, S * ssaa, 0.01, 100.0)
     r_c2w = np.concatenate([poses[:, :3, :1], -poses[:, :3, 1:3]], -1)
-    kw = dict(vt=vt, ft=ft, albedo=tex) if tag.startswith('tex') else dict(
+    kw = dict(vt=vt, ft=ft, albedo=G['tex_big'], texture_filter='linear-mipmap-linear') if tag.startswith('texmip') else dict(
+        vt=vt, ft=ft, albedo=tex) if tag.startswith('tex') else dict(
         vc=vcol, shading_fun=mod.shade, aa=False,
         dilate=lambda rgba: MF.edge_dilation(rgba.transpose(0, 3, 1, 2), rgba.transpose(0, 3, 1, 2)[:, 3:], 1).transpose(0, 2, 3, 1))
     rgba, depth, normal = MF.mesh_forward(v, f, vn, f, (v_cam, G[f'{tag}_v_clip']), r_c2w, S, S, ssaa=ssaa, **kw)
     assert ((rgba[..., 3] > 0) & (rgba[..., 3] < 1)).mean() > 0.001 or tag == 'vc_shade_dilate'       # antialiased silhouettes exist
+    if tag.startswith('texmip'):       # the filter matters: the bilinear fetch of the same atlas is far from the mip-mapped reference output
+        lin = MF.mesh_forward(v, f, vn, f, (v_cam, G[f'{tag}_v_clip']), r_c2w, S, S, ssaa=ssaa, vt=vt, ft=ft, albedo=G['tex_big'])[0]
+        assert np.abs(lin - G[f'{tag}_rgba']).max() > 0.1
     np.testing.assert_allclose(rgba, G[f'{tag}_rgba'], rtol=0, atol=2e-6)
     np.testing.assert_allclose(depth, G[f'{tag}_depth'], rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(normal, G[f'{tag}_normal'], rtol=0, atol=3e-6)

@@ -218,10 +218,11 @@ def test_attention_packed_qkv_spike_and_segments(lib):
           attn_ref(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B // 2, 2 * L, 2 * L, heads, d), dtype)
 
 
-@pytest.mark.parametrize('variant', [0, 8, 9, 10, 11])
+@pytest.mark.parametrize('variant', [0, 8, 9, 10, 11, 12, 13, 14, 15])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 def test_attention_d40_transposed_v_kernel(lib, dtype, variant):
-    """k_attention3 (mve_attention_tune(8..11): 4 or 8 waves per block, 2 or 3 LDS stages; 32x32x16 Q K^T, V staged row-major by LDS-DMA and read through ds_read_b64_tr_b16, P moved
+    """k_attention3 (mve_attention_tune(8..15): 4 or 8 waves per block, 2 to 4 LDS stages, 12..15 with the software-pipelined tile loop;
+    32x32x16 Q K^T, V staged row-major by LDS-DMA and read through ds_read_b64_tr_b16, P moved
     into its operand layout with v_permlane16_swap) on every d = 40 situation the UNet produces: full tiles, a ragged last key tile
     (Lk = 77 / 93 / 16 / 300), query counts that do not fill the 128-row block, the rescale path (a key dominating a late tile), strided
     packed-QKV views, two KV segments, cross-image pairing -- against fp32 torch with the per-kernel bar of test_attention."""
@@ -253,11 +254,11 @@ def test_attention_d40_transposed_v_kernel(lib, dtype, variant):
         check('variant cross-image', out, attn_ref(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B // 2, 2 * L, 2 * L, heads, d), dtype)
         # Q carrying softmax_scale * log2(e) (how the executors call the kernel): the maximum is subtracted by the MFMA's C operand
         c = d ** -0.5 * math.log2(math.e)
-        for B, Lq, Lk in [(2, 256, 256), (1, 2048, 2048), (2, 1000, 77), (1, 128, 16), (3, 576, 93)]:
-            q, k, v = rnd((B * Lq, C), dtype, 11), rnd((B * Lk, C), dtype, 12), rnd((B * Lk, C), dtype, 13)
+        for Bp, Lqp, Lkp in [(2, 256, 256), (1, 2048, 2048), (2, 1000, 77), (1, 128, 16), (3, 576, 93)]:
+            q, k, v = rnd((Bp * Lqp, C), dtype, 11), rnd((Bp * Lkp, C), dtype, 12), rnd((Bp * Lkp, C), dtype, 13)
             qp = (q.float() * c).to(dtype)
-            out = ops.attention(qp.cuda(), k.cuda(), v.cuda(), B, Lq, Lk, heads, d, prescaled=True)
-            check(f'attention variant {variant} prescaled', out, attn_ref(qp.float() / c, k, v, B, Lq, Lk, heads, d), dtype, f'{(B, Lq, Lk)}')
+            out = ops.attention(qp.cuda(), k.cuda(), v.cuda(), Bp, Lqp, Lkp, heads, d, prescaled=True)
+            check(f'attention variant {variant} prescaled', out, attn_ref(qp.float() / c, k, v, Bp, Lqp, Lkp, heads, d), dtype, f'{(Bp, Lqp, Lkp)}')
         qp = (qkv[:, :C].float() * c).to(dtype)          # the spike row: rescale path of the prescaled kernel; second KV segment
         out = ops.attention(qp.cuda(), g[:, C:2 * C], g[:, 2 * C:], B, L, L, heads, d, k2=k2.cuda(), v2=v2.cuda(), Lk2=L2, prescaled=True)
         check('variant prescaled spike + 2 segments', out, attn_ref(qp.float() / c, kc, vc, B, L, L + L2, heads, d), dtype)
