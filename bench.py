@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the NeRF / raster / back-projection figures')
     ap.add_argument('--no-op-timing', action='store_true', help='time the steps without per-op HIP events')
+    ap.add_argument('--secondary-only', action='store_true', help='run only the render / reconstruct / VAE figures (the workload of the '
+                    'rocprofv3 passes behind profiles/rNN_rocprof_render_*.txt) and print them')
     return ap.parse_args()
 
 
@@ -230,6 +232,9 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists for the HIP path)'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    if args.secondary_only:
+        print(json.dumps({'secondary': secondary(dev)}), flush=True)
+        return
 
     from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG
     from mvedit_amd import ops
@@ -322,7 +327,9 @@ def main():
         roof = dict(bound='mfma', kernel={'conv3x3': 'k_gemm_big<MODE=1> implicit-GEMM conv3x3 (256x320 tile)', 'linear': 'k_gemm_big<MODE=0> (256x320 tile)',
                                           'attention': 'k_attention'}[dom],
                     achieved=round(achieved, 1), peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(achieved / PEAK_TFLOPS_F16, 4),
-                    traffic=pmc_traffic(dom), launches_per_step=b['launches'], flops_per_step=b['flops'],
+                    traffic=pmc_traffic(dom), traffic_source='static: read from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                    'passes of this command, 2 x FETCH + WRITE per launch), not measured in this run',
+                    launches_per_step=b['launches'], flops_per_step=b['flops'],
                     avg_launch_ms=round(b['ms'] / b['launches'], 4),
                     per_class_ms={k: round(v['ms'], 3) for k, v in breakdown.items()},
                     per_class_tflops={k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) for k, v in breakdown.items() if v['flops'] > 0})
@@ -340,6 +347,7 @@ def main():
                        'parallelism': f'views/{world}' + (' + all_gather(RGBD/normal maps, 4 MiB per view)' if world > 1 else '')},
             'model_tflops_per_s': round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
             'model_flops_frac_of_peak': round(total_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_TFLOPS_F16 * world), 4),
+            'rccl_world': dist.get_world_size() if use_dist else 1,
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -709,6 +709,39 @@ MVE_API int mve_texture_bilinear_backward(const float* d_grad_out, int Bt, int t
 MVE_API int mve_antialias_backward(const float* d_grad_out, int B, int H, int W, int C, const float* d_rast, const float* d_pos, int V,
                                    const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_color, void* stream);
 
+/* Tri-plane radiance decoders: `TriPlaneDecoder.point_decode` (lib/models/decoders/triplane_decoder.py:135-199)
+ * and `TriPlaneiNGPDecoder.point_decode` (lib/models/decoders/triplane_ingp_decoder.py:142-212) for one scene, forward only:
+ *   feature k = c * 3 + p of a point = bilinear F.grid_sample(padding_mode='border', align_corners=False) of channel c of plane p at the
+ *   point's two coordinates for that plane (plane_cfg; flip_z negates z);  base_x = base_net(features) [+ ingp_base_net(hash-grid encoding
+ *   of (xyz + bound) / (2 bound), tiny-cuda-nn HashGrid with Smoothstep interpolation)];  sigma = sigma_activation(density_net(act(base_x)));
+ *   rgb = sigmoid(color_net(cat[act(base_x), SH_4(dir)])) * (1 + 2 s) - s.
+ * Supported topology (the classes' defaults): base_net = one Linear(3C -> hidden), density_net = Linear(hidden -> 1), color_net =
+ * Linear(hidden + 16 -> hidden2), act, Linear(hidden2 -> 3); hidden, hidden2 in {64, 128}; dir_layers = None; ingp_base_layers = 1.
+ * Weight matrices are passed TRANSPOSED ([in][out], fp32) so that a wave reads an input's fan-out as one contiguous scalar load.
+ * code is channels-last [3][h][w][C].  activation: 0 relu, 1 silu, 2 softplus; sigma_activation: the same, 3 = trunc_exp (exp). */
+typedef struct MveTriplaneDesc {
+    const float *d_xyz, *d_dirs;                     /* [N,3]; d_dirs NULL: density only (point_density_decode) */
+    const float *d_code;                             /* [3][h][w][C] */
+    int32_t N, C, h, w;
+    int32_t axes[6];                                 /* plane p reads (xyz[axes[2p]], xyz[axes[2p+1]]) */
+    int32_t flip_z;
+    const float *d_base_wT, *d_base_b;               /* [3C][hidden], [hidden] */
+    int32_t hidden, hidden2;
+    const float *d_ingp_wT, *d_ingp_b;               /* [2 n_levels][hidden], [hidden]; NULL for TriPlaneDecoder */
+    const float *d_table;                            /* hash table [rows][2] */
+    int32_t n_levels;
+    float bound;
+    const float *level_scale;                        /* HOST arrays [n_levels] (as mve_hashgrid_mlp_decode takes them) */
+    const uint32_t *level_res, *level_offset, *level_size;
+    const float *d_dens_w, *d_dens_b;                /* [hidden], [1] */
+    const float *d_col1_wT, *d_col1_b;               /* [hidden + 16][hidden2], [hidden2] */
+    const float *d_col2_w, *d_col2_b;                /* [3][hidden2], [3] */
+    int32_t activation, sigma_activation;
+    float sigmoid_saturation;
+    float *d_sigmas, *d_rgbs;                        /* [N], [N,3] (d_rgbs unused when d_dirs is NULL) */
+} MveTriplaneDesc;
+MVE_API int mve_triplane_decode(const MveTriplaneDesc* desc, void* stream);
+
 /* Mip-mapped texture path: what the reference gets from nvdiffrast with MeshRenderer(texture_filter='linear-mipmap-linear') -- its default
  * (lib/models/decoders/mesh_renderer/base_mesh_renderer.py:196) -- in forward (:241, :260-264, :357-361), get_cam_weights_uv (:442, :466-475,
  * :496-500) and bake_multiview (:521, :543-552, :573-577).  nvdiffrast is not vendored: algorithm restated in oracle/texture_mip_oracle.py.

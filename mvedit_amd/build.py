@@ -39,6 +39,7 @@ EXTRA_FLAGS = {
     'mesh_reg.hip': ['-ffp-contract=off'],
     'blur.hip': ['-ffp-contract=off'],
     'sh.hip': ['-ffp-contract=off'],
+    'triplane.hip': ['-ffp-contract=off'],
 }
 
 

@@ -578,7 +578,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
     float m_run = PRE ? 0.f : -INFINITY;
     const float sc = p.scale_log2e;
 
-    f32x16 negm;                                   // PRE: -m_run in all 16 accumulator registers (C operand of the first d-step)
+    // PRE: -m_run in all 16 accumulator registers (C operand of the first d-step)
+    f32x16 negm;
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
@@ -596,8 +597,21 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
             const int o = st < 2 ? k_off01 + 32 * st : k_off2;
             const V8 ka = *reinterpret_cast<const V8*>(St + o);
             const V8 kb_ = *reinterpret_cast<const V8*>(St + o + 32 * K_ROW);
-            s.a = Tag::mfma32(ka, qf[st], st == 0 ? (PRE ? negm : zero16) : s.a);
-            s.b = Tag::mfma32(kb_, qf[st], st == 0 ? (PRE ? negm : zero16) : s.b);
+            if (PRE && st == 0) {
+                // D != C written out by hand: for a C operand that stays live hipcc copies it into the accumulator first (8 v_mov_b64 per
+                // chain and tile -- what the saved v_fma bought).  Operands come from waited-for loads / old VALU results; the only
+                // consumer of D is the next MFMA of the chain taking it whole as C: no wait states needed on either side.
+                if constexpr (std::is_same<T, f16>::value) {
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s.a) : "v"(ka), "v"(qf[0]), "v"(negm));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s.b) : "v"(kb_), "v"(qf[0]), "v"(negm));
+                } else {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s.a) : "v"(ka), "v"(qf[0]), "v"(negm));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s.b) : "v"(kb_), "v"(qf[0]), "v"(negm));
+                }
+            } else {
+                s.a = Tag::mfma32(ka, qf[st], st == 0 ? zero16 : s.a);
+                s.b = Tag::mfma32(kb_, qf[st], st == 0 ? zero16 : s.b);
+            }
         }
         return s;
     };
@@ -820,7 +834,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
 // 1 (d = 40 only, single KV segment): 16 query rows per wave, 64-key fills, 3 blocks per CU --
 // an experiment for the VALU-bound d = 40 case (mve_attention_tune; results are NOT bit-identical across variants: the online-softmax
 // rescale points move with the fill size).
-int g_attn_variant = 11;
+int g_attn_variant = 9;
 
 template <class Tag, int D>
 int launch(const AttnParams& p, hipStream_t s) {
@@ -863,15 +877,18 @@ int launch(const AttnParams& p, hipStream_t s) {
     }
     constexpr int QB = 128;
     const unsigned grid = (unsigned)(((p.Lq + QB - 1) / QB) * p.heads * p.B);
+    // the default family (variants >= 8) uses, for the other head dims, the LDS layouts that the same-box A/B measured fastest and the GPU
+    // tests showed bit-identical to variant 0: K + V^T swizzles for d = 80 / 160 (+5 %), the V^T store swizzle for d = 64 (+12 %)
+    const int var = g_attn_variant >= 8 ? ((D == 80 || D == 160) ? 6 : 4) : g_attn_variant;
     if constexpr (D == 80 || D == 160) {
-        if ((g_attn_variant == 2 || g_attn_variant == 6) && p.Lk2 == 0) {          // conflict-free K swizzle (see k_perm)
-            if (g_attn_variant == 6) k_attention2<Tag, D, false, 2, 0, 0, true, true><<<grid, NT, 0, s>>>(p);
+        if ((var == 2 || var == 6) && p.Lk2 == 0) {          // conflict-free K swizzle (see k_perm)
+            if (var == 6) k_attention2<Tag, D, false, 2, 0, 0, true, true><<<grid, NT, 0, s>>>(p);
             else k_attention2<Tag, D, false, 2, 0, 0, true><<<grid, NT, 0, s>>>(p);
             MVE_LAUNCH_CHECK();
             return MVE_OK;
         }
     }
-    if ((g_attn_variant == 4 || g_attn_variant == 6) && p.Lk2 == 0) {              // V^T store swizzle (see v_swz2)
+    if ((var == 4 || var == 6) && p.Lk2 == 0) {              // V^T store swizzle (see v_swz2)
         k_attention2<Tag, D, false, 2, 0, 0, false, true><<<grid, NT, 0, s>>>(p);
         MVE_LAUNCH_CHECK();
         return MVE_OK;

@@ -454,7 +454,9 @@ __global__ __launch_bounds__(kBlock) void k_grid_points(const int32_t* __restric
 __global__ __launch_bounds__(kBlock) void k_grid_scatter(const float* __restrict__ sigmas, const int32_t* __restrict__ indices, uint32_t N,
                                                          float* __restrict__ tmp_grid) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < N) tmp_grid[indices[i]] = fminf(sigmas[i], 3.4028234663852886e38f);
+    // sigmas.clamp(max=finfo.max) of the reference (base_volume_renderer.py:166): +inf becomes FLT_MAX, a NaN stays a NaN -- its
+    // (tmp >= 0) test then fails and the cell keeps its old density, where fminf would have marked it occupied at maximum density
+    if (i < N) { const float sg = sigmas[i]; tmp_grid[indices[i]] = sg != sg ? sg : fminf(sg, 3.4028234663852886e38f); }
 }
 // grid = where(grid >= 0 & tmp >= 0, max(grid * decay, tmp), grid); per-block partial sums of clamp(grid, 0) in fp64
 __global__ __launch_bounds__(kBlock) void k_grid_ema(float* __restrict__ grid, const float* __restrict__ tmp, uint32_t n, float decay,

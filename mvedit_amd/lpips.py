@@ -25,18 +25,23 @@ class _LPIPSFn(torch.autograd.Function):
         with torch.cuda.device(eng.device):
             _lib.call('mve_lpips_forward', eng._h, _lib.ptr(p), _lib.ptr(t), _dt(io), B, H, W, _lib.ptr(loss), _lib.ptr(ws), ws.numel(),
                       _lib.stream_ptr(eng.device))
-        ctx.eng, ctx.ws, ctx.shape, ctx.io, ctx.in_dtype = eng, ws, (B, H, W), io, pred.dtype
+        ctx.save_for_backward(ws)                  # the activations of this call: backward reads them (and overwrites them: one backward only)
+        ctx.eng, ctx.shape, ctx.io, ctx.in_dtype, ctx.done = eng, (B, H, W), io, pred.dtype, False
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         eng, (B, H, W) = ctx.eng, ctx.shape
+        if ctx.done:
+            raise RuntimeError('LPIPSEngine: a second backward through the same forward is not supported (the backward pass overwrites '
+                               'the saved activations); run the forward again')
+        ws, = ctx.saved_tensors
+        ctx.done = True
         g = grad_loss.to(device=eng.device, dtype=torch.float32).contiguous()
         out = torch.empty(B, 3, H, W, dtype=ctx.io, device=eng.device)
         with torch.cuda.device(eng.device):
-            _lib.call('mve_lpips_backward', eng._h, _lib.ptr(g), _dt(ctx.io), B, H, W, _lib.ptr(out), _lib.ptr(ctx.ws), ctx.ws.numel(),
+            _lib.call('mve_lpips_backward', eng._h, _lib.ptr(g), _dt(ctx.io), B, H, W, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                       _lib.stream_ptr(eng.device))
-        ctx.ws = None
         return out.to(ctx.in_dtype), None, None
 
 

@@ -579,12 +579,13 @@ class _AutoNormalFn(torch.autograd.Function):
         vs, vn = torch.empty_like(v), torch.empty_like(v)
         with torch.cuda.device(v.device):
             _lib.call('mve_mesh_normals_forward', _lib.ptr(v), V, _lib.ptr(f), F, _lib.ptr(fn), _lib.ptr(vs), _lib.ptr(vn), _lib.stream_ptr(v.device))
-        ctx.keep, ctx.dtype = (v, f, vs), verts.dtype
+        ctx.save_for_backward(v, f, vs)
+        ctx.dtype = verts.dtype
         return vn.to(verts.dtype), fn.to(verts.dtype)
 
     @staticmethod
     def backward(ctx, g_vn, g_fn):
-        v, f, vs = ctx.keep
+        v, f, vs = ctx.saved_tensors
         g_vn = None if g_vn is None else g_vn.detach().to(torch.float32).contiguous()
         g_fn = None if g_fn is None else g_fn.detach().to(torch.float32).contiguous()
         scratch, g_v = torch.empty_like(v), torch.empty_like(v)
@@ -690,12 +691,13 @@ class _MeshRegFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.call('mve_mesh_reg_forward', _lib.ptr(v), V, _lib.ptr(f), F, _lib.ptr(fn), _lib.ptr(ws), ws.numel(), _lib.ptr(losses),
                       _lib.stream_ptr(dev))
-        ctx.keep, ctx.dtypes = (v, f, fn, ws), (verts.dtype, face_normals.dtype)
+        ctx.save_for_backward(v, f, fn, ws)
+        ctx.dtypes = (verts.dtype, face_normals.dtype)
         return losses[0].clone(), losses[1].clone()
 
     @staticmethod
     def backward(ctx, g_lap, g_nc):
-        v, f, fn, ws = ctx.keep
+        v, f, fn, ws = ctx.saved_tensors
         dev = v.device
         zero = torch.zeros((), dtype=torch.float32, device=dev)
         gl = torch.stack([zero if g_lap is None else g_lap.detach().float().reshape(()), zero if g_nc is None else g_nc.detach().float().reshape(())])

@@ -21,6 +21,10 @@ def partition_views(num_views, world_size, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
+
+
 def partition_sizes(num_views, world_size):
     return [partition_views(num_views, world_size, r)[1] - partition_views(num_views, world_size, r)[0]
             for r in range(world_size)]
@@ -58,8 +62,8 @@ def repartition(per_view, old_num, keep_ids, group=None):
     all-gather + local slice: per-view state is small (latents 32 KiB/view) next to one UNet step."""
     full = all_gather_views(per_view, old_num, group)
     kept = full[torch.as_tensor(keep_ids, device=full.device, dtype=torch.long)]
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if _dist_on() else 1
+    rank = dist.get_rank(group) if _dist_on() else 0
     lo, hi = partition_views(len(keep_ids), world, rank)
     return kept[lo:hi].contiguous()
 
@@ -73,14 +77,16 @@ def sync_scene(tensors, src=0, group=None):
     broadcast per outer step of the whole scene (about 52 MiB for the hash grid + 4 MiB of density grid: well under a millisecond over
     xGMI) removes the drift at its source.  ONE collective per dtype: the tensors are coalesced into a flat buffer and copied back in place.
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _dist_on() or dist.get_world_size(group) == 1:
         return tensors
+    # `src` is a rank of `group`; dist.broadcast wants the global rank
+    src_global = dist.get_global_rank(group, src) if group is not None else src
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault((t.dtype, t.device), []).append(t)
     for (dtype, device), ts in by_dtype.items():
         flat = torch.cat([t.detach().reshape(-1) for t in ts])
-        dist.broadcast(flat, src=src, group=group)
+        dist.broadcast(flat, src=src_global, group=group)
         off = 0
         with torch.no_grad():
             for t in ts:

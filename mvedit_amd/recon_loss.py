@@ -62,7 +62,10 @@ class _ReconLossFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.call('mve_recon_loss_forward', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.ptr(losses), _lib.ptr(out_rgbs), _lib.ptr(out_normals),
                       _lib.stream_ptr(dev))
-        ctx.desc, ctx.keep, ctx.ws, ctx.dims = d, keep, ws, (N, M)
+        # the descriptor holds raw device pointers into `keep` and `ws`: saved (alive + version-checked: an in-place change before backward
+        # raises instead of silently giving wrong gradients) and re-read in backward before the pointers are used
+        ctx.save_for_backward(ws, *[t for t in keep.values() if t is not None])
+        ctx.desc, ctx.dims = d, (N, M)
         ctx.in_shapes = (image.shape, weights_sum.shape, depth.shape, weights.shape)
         ctx.in_dtypes = (image.dtype, weights_sum.dtype, depth.dtype, weights.dtype)
         ctx.mark_non_differentiable(losses)
@@ -71,7 +74,8 @@ class _ReconLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_rgbs, g_normals, _unused):
         N, M = ctx.dims
-        dev = ctx.ws.device
+        ws = ctx.saved_tensors[0]
+        dev = ws.device
         gl = _f32(g_loss, dev)              # stays on the device: the kernels read it (None = 1)
         g_rgbs, g_normals = _f32(g_rgbs, dev), _f32(g_normals, dev)
         g_image = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -79,7 +83,7 @@ class _ReconLossFn(torch.autograd.Function):
         g_depth = torch.empty(N, dtype=torch.float32, device=dev)
         g_weights = torch.empty(M, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.call('mve_recon_loss_backward', ctypes.byref(ctx.desc), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.ptr(g_rgbs), _lib.ptr(g_normals), _lib.ptr(gl),
+            _lib.call('mve_recon_loss_backward', ctypes.byref(ctx.desc), _lib.ptr(ws), ws.numel(), _lib.ptr(g_rgbs), _lib.ptr(g_normals), _lib.ptr(gl),
                       _lib.ptr(g_image), _lib.ptr(g_ws), _lib.ptr(g_depth), _lib.ptr(g_weights), _lib.stream_ptr(dev))
         outs = [g.reshape(s).to(t) for g, s, t in zip((g_image, g_ws, g_depth, g_weights), ctx.in_shapes, ctx.in_dtypes)]
         return (*outs, None, None)
@@ -135,19 +139,21 @@ class _MeshLossFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.call('mve_mesh_loss_forward', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.ptr(losses), _lib.ptr(out_rgbs), _lib.ptr(out_normals),
                       _lib.stream_ptr(dev))
-        ctx.desc, ctx.keep, ctx.ws, ctx.N = d, keep, ws, N
+        ctx.save_for_backward(ws, *[t for t in keep.values() if t is not None])
+        ctx.desc, ctx.N = d, N
         ctx.in_shapes, ctx.in_dtypes = (rgba.shape, normal.shape), (rgba.dtype, normal.dtype)
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), out_rgbs, out_normals, losses
 
     @staticmethod
     def backward(ctx, g_loss, g_rgbs, g_normals, _unused):
-        dev = ctx.ws.device
+        ws = ctx.saved_tensors[0]
+        dev = ws.device
         gl, g_rgbs, g_normals = _f32(g_loss, dev), _f32(g_rgbs, dev), _f32(g_normals, dev)
         g_rgba = torch.empty(ctx.N, 4, dtype=torch.float32, device=dev)
         g_normal = torch.empty(ctx.N, 3, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.call('mve_mesh_loss_backward', ctypes.byref(ctx.desc), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.ptr(g_rgbs), _lib.ptr(g_normals),
+            _lib.call('mve_mesh_loss_backward', ctypes.byref(ctx.desc), _lib.ptr(ws), ws.numel(), _lib.ptr(g_rgbs), _lib.ptr(g_normals),
                       _lib.ptr(gl), _lib.ptr(g_rgba), _lib.ptr(g_normal), _lib.stream_ptr(dev))
         return g_rgba.reshape(ctx.in_shapes[0]).to(ctx.in_dtypes[0]), g_normal.reshape(ctx.in_shapes[1]).to(ctx.in_dtypes[1]), None, None
 

@@ -103,12 +103,13 @@ class _ShadePointsFn(torch.autograd.Function):
         with torch.cuda.device(a.device):
             _lib.call('mve_shade_points', _lib.ptr(a), _lib.ptr(n), _lib.ptr(l), a.shape[0], float(ambient), _lib.ptr(lut_x), _lib.ptr(lut_y),
                       0 if lut_x is None else lut_x.numel(), _lib.ptr(out), None, None, None, _lib.stream_ptr(a.device))
-        ctx.keep, ctx.ambient, ctx.dtypes = (a, n, l, lut_x, lut_y), float(ambient), (albedo.dtype, normal.dtype)
+        ctx.save_for_backward(a, n, l, lut_x, lut_y)        # version-checked: an in-place change before backward raises instead of giving wrong gradients
+        ctx.ambient, ctx.dtypes = float(ambient), (albedo.dtype, normal.dtype)
         return out.to(albedo.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        a, n, l, lut_x, lut_y = ctx.keep
+        a, n, l, lut_x, lut_y = ctx.saved_tensors
         g = g.detach().to(torch.float32).contiguous()
         ga, gn = torch.empty_like(a), torch.empty_like(a)
         with torch.cuda.device(a.device):

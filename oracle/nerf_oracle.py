@@ -65,11 +65,11 @@ def make_nerf_params(n_levels=12, max_resolution=320, hidden=64, seed=7, table_s
                 w2=xavier(4, hidden), b2=np.zeros(4, np.float32), n_levels=n_levels, max_resolution=max_resolution)
 
 
-def hashgrid_encode(x01, table, n_levels=12, max_resolution=320, bound=1.0):
+def hashgrid_encode(x01, table, n_levels=12, max_resolution=320, bound=1.0, log2_hashmap_size=19):
     """x01: [M,3] float32 in [0,1] -> [M, 2*n_levels] float32."""
     x01 = np.ascontiguousarray(x01, dtype=np.float32)
     M = x01.shape[0]
-    meta, _ = grid_meta(n_levels, 16, max_resolution, bound)
+    meta, _ = grid_meta(n_levels, 16, max_resolution, bound, log2_hashmap_size)
     out = np.zeros((M, 2 * n_levels), np.float32)
     for lvl, (scale, res, off, size) in enumerate(meta):
         pos = (scale * x01 + np.float32(0.5)).astype(np.float32)

@@ -22,14 +22,6 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-# GPU tests written after the round's GPU budget was spent have never run on hardware.  They are skipped unless MVE_RUN_PENDING=1
-# so that an unexpected device fault in unverified code cannot take the verified suite down with it (`pytest -x`, or a fault that
-# kills the process).  First thing next round: MVE_RUN_PENDING=1 python -m pytest tests -m gpu (tools/gpu_pending.sh runs them one file per process); then drop the mark.
-pending_first_gpu_run = pytest.mark.skipif(os.environ.get('MVE_RUN_PENDING') != '1',
-                                           reason='written after the round-1 GPU budget was exhausted: not yet run on an MI355X '
-                                                  '(set MVE_RUN_PENDING=1 to run)')
-
-
 @pytest.fixture(scope='session')
 def lib():
     """The C-ABI library, built in-tree if needed (hipcc cross-compiles without a GPU)."""

@@ -6,7 +6,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import pending_first_gpu_run
 from oracle import blur_oracle as B
 
 
@@ -54,7 +53,6 @@ def test_highpass_host_build_vs_oracle_and_its_autograd():
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_blur_and_highpass_vs_oracle(lib):
     from mvedit_amd.pipelines.utils import gaussian_blur, highpass
     g = torch.Generator().manual_seed(2)

@@ -5,7 +5,6 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import pending_first_gpu_run
 from oracle import lpips_oracle as L
 
 
@@ -56,7 +55,6 @@ def _case(B=3, S=32, seed=2):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_forward_and_gradient_vs_oracle(lib):
     """bf16, the reference's configuration (lpips_loss.py:31).  Bar: PyTorch's own bf16 module + autograd sits 5e-3 (loss) / 6.6e-2
     rel-L2 (gradient, cosine 0.998) away from fp32 on this case (measured on the CPU, recomputed below); the engine must be at least
@@ -89,7 +87,6 @@ def test_forward_and_gradient_vs_oracle(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_fp16_forward_and_patch_size(lib):
     """fp16 engine, forward only (fp16 autograd underflows in the reference's stack as well: 19 % off fp32), at the production patch
     size 8 x 128 x 128; batch invariance of the per-pair values."""
@@ -106,7 +103,6 @@ def test_fp16_forward_and_patch_size(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_lpips_building_blocks(lib):
     """max pooling (+ backward with torch's first-arg-max rule), ReLU backward and one layer's distance + gradient, each against torch."""
     import ctypes

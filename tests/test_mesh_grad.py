@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import pending_first_gpu_run
 from oracle import raster as RO
 from oracle import raster_grad_oracle as R
 from scene import icosphere
@@ -112,7 +111,6 @@ def test_device_source_on_host_equals_closed_forms():
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_rasterize_and_interpolate_geometry_gradient_vs_oracle(lib):
     from mvedit_amd.mesh_ops import interpolate, rasterize
     P, tri, H, W = _scene()
@@ -133,7 +131,6 @@ def test_rasterize_and_interpolate_geometry_gradient_vs_oracle(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_vertex_fit_through_depth_converges(lib):
     """Recover a per-vertex radial scale from a target z/w image by gradient descent through rasterize (interior gradients only:
     the silhouette term of antialias is not part of this round)."""
@@ -157,7 +154,6 @@ def test_vertex_fit_through_depth_converges(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_antialias_position_gradient_vs_oracle(lib):
     from mvedit_amd.mesh_ops import antialias
     Pn, tri, rast, opp, color, G = _aa_case()

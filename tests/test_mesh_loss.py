@@ -10,7 +10,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import pending_first_gpu_run
 from oracle import recon_loss_oracle as R
 
 G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mesh_loss_ref.npz'))
@@ -75,7 +74,6 @@ def test_descriptor_layout_matches_the_header(tmp_path):
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pending_first_gpu_run
 @pytest.mark.parametrize('i', range(NC))
 def test_hip_vs_reference(lib, i):
     from mvedit_amd.recon_loss import mesh_optim_loss
@@ -94,7 +92,6 @@ def test_hip_vs_reference(lib, i):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_full_size_views_and_timing(lib):
     """render_bs x 512^2 views as mesh_optim renders them; vs the torch restatement in float64; prints native vs torch-statement time"""
     import time
@@ -145,7 +142,6 @@ def test_hip_full_size_views_and_timing(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_mesh_optim_iteration_on_native_kernels_only(lib):
     """The mesh half of the reconstruct step wired together the way `mesh_optim` wires it (mvedit_3d_pipeline.py:716-847), every stage
     native: Mesh.auto_normal -> MeshRenderer.forward (rasterise / interpolate / antialias with their geometry gradients) ->

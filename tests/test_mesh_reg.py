@@ -9,7 +9,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import pending_first_gpu_run
 from oracle import mesh_reg_oracle as M
 
 G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mesh_reg_ref.npz'))
@@ -68,7 +67,6 @@ def test_host_build_is_independent_of_face_order():
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pending_first_gpu_run
 @pytest.mark.parametrize('i', range(NC))
 def test_hip_vs_reference(lib, i):
     from mvedit_amd.mesh_ops import mesh_regularizers, laplacian_smooth_loss, normal_consistency
@@ -86,7 +84,6 @@ def test_hip_vs_reference(lib, i):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_large_mesh_vs_oracle(lib):
     """a DMTet-sized mesh (~80 k faces): values vs the torch restatement's sparse path, gradients vs its autograd"""
     from mvedit_amd.mesh_ops import mesh_regularizers
@@ -128,7 +125,6 @@ def test_hip_large_mesh_vs_oracle(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_timing_against_the_torch_functions_on_the_same_gpu(lib):
     """not a parity test: prints what the two regularisers cost per iteration natively and as the reference's torch formulation
     (two torch.unique calls + index_add / gathers, on the GPU)"""
@@ -181,7 +177,6 @@ def test_auto_normal_host_build_vs_reference_method(i):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 @pytest.mark.parametrize('i', range(int(GN['n_cases'])))
 def test_hip_auto_normal_vs_reference_method(lib, i):
     from mvedit_amd.mesh_ops import Mesh
@@ -192,7 +187,7 @@ def test_hip_auto_normal_vs_reference_method(lib, i):
     assert rel(m.vn.detach().cpu().numpy(), c('vn')) < 1e-6 and rel(m.face_normals.detach().cpu().numpy(), c('face_normals')) < 1e-6
     assert m.fn.dtype == torch.int32 and np.array_equal(m.fn.cpu().numpy(), c('fn'))
     g_v, = torch.autograd.grad((m.vn * torch.from_numpy(c('g_vn')).float().cuda()).sum()
-                               + (m.face_normals * torch.from_numpy(c('g_fn')).float().cuda()).sum(), v)
+                               + (m.face_normals * torch.from_numpy(c('g_fn')).float().cuda()).sum(), v, retain_graph=True)
     assert rel(g_v.cpu().numpy(), c('g_verts')) < 3e-6
     # chained with the regularisers the way mesh_optim uses them: d normal_consistency / d verts flows through face_normals
     from mvedit_amd.mesh_ops import mesh_regularizers

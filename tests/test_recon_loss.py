@@ -16,7 +16,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import pending_first_gpu_run
 from oracle import recon_loss_oracle as R
 
 G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'recon_loss_ref.npz'))
@@ -156,7 +155,6 @@ def _gpu_run(args, kw, luts, ext=None, gl=None):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 @pytest.mark.parametrize('i', range(NC))
 def test_hip_vs_reference_and_host_build(lib, i):
     args, kw, luts, c = case(i)
@@ -178,7 +176,6 @@ def test_hip_vs_reference_and_host_build(lib, i):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_external_gradients_scale_and_determinism(lib):
     args, kw, luts, c = case(0)
     g = torch.Generator().manual_seed(5)
@@ -195,7 +192,6 @@ def test_hip_external_gradients_scale_and_determinism(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_full_size_iteration(lib):
     """the reference's working size: 8 patches of 128 x 128 rays (n_inverse_rays = 2^17, lib/pipelines/utils.py:233), ~8 samples per ray"""
     P, ps = 8, 128
@@ -227,7 +223,6 @@ def test_hip_full_size_iteration(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_timing_against_the_torch_statements_on_the_same_gpu(lib):
     """not a parity test: prints what one iteration's image-space loss costs natively and as the reference's torch statements (the
     restatement, on the GPU) -- the number DESIGN.md section 4.8 quotes comes from here"""
@@ -267,7 +262,6 @@ def test_hip_timing_against_the_torch_statements_on_the_same_gpu(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_nerf_optim_iteration_on_native_kernels_only(lib):
     """The NeRF half of the reconstruct step wired together the way `nerf_optim` wires it (mvedit_3d_pipeline.py:507-633), every stage
     native: VolumeRenderer training forward (march -> cull -> decode -> composite) -> nerf_optim_loss (shading, tone mapping, L1, TV,

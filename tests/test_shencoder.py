@@ -7,7 +7,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import pending_first_gpu_run
 from oracle import sh_oracle as S
 
 
@@ -54,7 +53,6 @@ def test_host_build_of_kernel_source_vs_oracle(degree):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 @pytest.mark.parametrize('degree', (1, 4, 8))
 def test_hip_vs_oracle_and_reference_kernel(lib, degree):
     from mvedit_amd.shencoder import SHEncoder, sh_encode

@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import pending_first_gpu_run
 from oracle import tonemap_oracle as T
 
 G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tonemap_ref.npz'))
@@ -54,7 +53,6 @@ def test_device_source_on_host_matches_reference_output():
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_lut_and_inverse_vs_reference_output(lib):
     from mvedit_amd.tonemapping import Tonemapping
     tm = Tonemapping()
@@ -67,7 +65,6 @@ def test_lut_and_inverse_vs_reference_output(lib):
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_shade_views_vs_reference_output(lib):
     from mvedit_amd.tonemapping import Tonemapping, shade_views
     rgba, nf, lights = t('rgba').cuda(), t('normal_fg').cuda(), t('cam_lights').cuda()
@@ -96,7 +93,6 @@ def test_lut_gradient_host_build_vs_reference_autograd():
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_lut_is_differentiable_like_the_reference():
     from mvedit_amd.tonemapping import Tonemapping
     tm = Tonemapping(device='cuda')
@@ -139,7 +135,6 @@ def test_shade_points_host_build_vs_reference_shading_funs():
 
 
 @pytest.mark.gpu
-@pending_first_gpu_run
 def test_hip_shading_funs_vs_reference():
     from mvedit_amd.tonemapping import Tonemapping, make_nerf_albedo_shading_fun, make_nerf_shading_fun, make_shading_fun
     cu = lambda k: torch.from_numpy(GS[k]).float().cuda()

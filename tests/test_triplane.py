@@ -1,0 +1,105 @@
+"""Tri-plane decoders (csrc/triplane.hip behind mvedit_amd.triplane) vs the reference's own `TriPlaneDecoder.point_decode` /
+`TriPlaneiNGPDecoder.point_decode` EXECUTED (tests/golden/triplane_ref.npz, tests/golden/make_triplane_golden.py).
+Bars: fp32 MLPs of width 128 over O(1) activations -> 2e-5 relative on sigma (an exponential), 2e-5 absolute on rgb."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import triplane_oracle as TO
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'triplane_ref.npz'))
+CASES = {'plain': dict(plane_cfg=('xy', 'xz', 'yz'), flip_z=False, activation='silu', ingp=False),
+         'flip': dict(plane_cfg=('xy', 'yz', 'xz'), flip_z=True, activation='relu', ingp=False),
+         'ingp': dict(plane_cfg=('xy', 'xz', 'yz'), flip_z=False, activation='silu', ingp=True)}
+HASH = dict(n_levels=12, max_resolution=320, log2_hashmap_size=12, bound=1.0)
+
+
+def weights(tag, dtype=torch.float32):
+    keys = ['base_w', 'base_b', 'dens_w', 'dens_b', 'col1_w', 'col1_b', 'col2_w', 'col2_b'] + (['ingp_w', 'ingp_b'] if CASES[tag]['ingp'] else [])
+    return {k: torch.from_numpy(G[f'{tag}_{k}']).to(dtype) for k in keys}
+
+
+@pytest.mark.parametrize('tag', list(CASES))
+def test_oracle_restatement_equals_reference_output(tag):
+    c = CASES[tag]
+    hash_ = dict(HASH, table=G[f'{tag}_table']) if c['ingp'] else None
+    t = lambda k: torch.from_numpy(G[f'{tag}_{k}'])
+    sig, rgb = TO.point_decode(t('xyz'), t('dirs'), t('code')[0], weights(tag), c['plane_cfg'], c['flip_z'], c['activation'], hash=hash_)
+    np.testing.assert_allclose(sig.numpy(), G[f'{tag}_sigmas'], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(rgb.numpy(), G[f'{tag}_rgbs'], rtol=0, atol=2e-6)
+    assert G[f'{tag}_sigmas'].std() > 0.05 and G[f'{tag}_rgbs'].std() > 0.02
+    assert (np.abs(G[f'{tag}_xyz']) > 1).any(), 'border padding must be exercised'
+
+
+def test_descriptor_layout_matches_the_header(tmp_path):
+    pytest.importorskip('mvedit_amd._lib')
+    from mvedit_amd.triplane import _Desc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f[0] for f in _Desc._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mvedit_amd.h"\nint main(void) {\n  printf("%zu", sizeof(MveTriplaneDesc));\n'
+                   + ''.join(f'  printf(" %zu", offsetof(MveTriplaneDesc, {f}));\n' for f in fields) + '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)], check=True)
+    nums = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert nums[0] == ctypes.sizeof(_Desc) and nums[1:] == [getattr(_Desc, f).offset for f in fields]
+
+
+def _engine(tag):
+    from mvedit_amd.triplane import TriPlaneDecoder, TriPlaneiNGPDecoder
+    c = CASES[tag]
+    kw = dict(plane_cfg=c['plane_cfg'], activation=c['activation'], flip_z=c['flip_z'])
+    eng = TriPlaneiNGPDecoder(n_levels=12, max_resolution=320, log2_hashmap_size=12, **kw) if c['ingp'] else TriPlaneDecoder(**kw)
+    sd = {'base_net.0.weight': G[f'{tag}_base_w'], 'base_net.0.bias': G[f'{tag}_base_b'], 'density_net.0.weight': G[f'{tag}_dens_w'],
+          'density_net.0.bias': G[f'{tag}_dens_b'], 'color_net.0.weight': G[f'{tag}_col1_w'], 'color_net.0.bias': G[f'{tag}_col1_b'],
+          'color_net.2.weight': G[f'{tag}_col2_w'], 'color_net.2.bias': G[f'{tag}_col2_b']}
+    if c['ingp']:
+        sd.update({'ingp_base_net.0.weight': G[f'{tag}_ingp_w'], 'ingp_base_net.0.bias': G[f'{tag}_ingp_b'], 'encoder.params': G[f'{tag}_table'].reshape(-1)})
+    return eng.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', list(CASES))
+def test_hip_vs_reference_output(lib, tag):
+    eng = _engine(tag)
+    t = lambda k: torch.from_numpy(G[f'{tag}_{k}']).cuda()
+    sig, rgb, n = eng.point_decode([t('xyz')], [t('dirs')], t('code'))
+    assert n == [G[f'{tag}_xyz'].shape[0]]
+    np.testing.assert_allclose(sig.cpu().numpy(), G[f'{tag}_sigmas'], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(rgb.cpu().numpy(), G[f'{tag}_rgbs'], rtol=0, atol=2e-5)
+    sig2, n2 = eng.point_density_decode([t('xyz')], t('code'))
+    assert torch.equal(sig2, sig) and n2 == n
+    with pytest.raises(NotImplementedError):
+        eng.point_decode([t('xyz').requires_grad_(True)], [t('dirs')], t('code'))
+
+
+@pytest.mark.gpu
+def test_hip_large_batch_vs_oracle_and_timing(lib):
+    """2^18 points of a 128^2 x 32-channel tri-plane (the SSDNeRF code size): vs the float64 oracle; prints points/s."""
+    tag = 'plain'
+    eng = _engine(tag)
+    g = torch.Generator().manual_seed(5)
+    N = 1 << 18
+    xyz = torch.rand(N, 3, generator=g) * 2.2 - 1.1
+    dirs = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    code = torch.randn(1, 3, 32, 128, 128, generator=g)
+    sig, rgb, _ = eng.point_decode([xyz.cuda()], [dirs.cuda()], code.cuda())
+    idx = torch.randperm(N, generator=g)[:4096]
+    c = CASES[tag]
+    so, ro = TO.point_decode(xyz[idx].double(), dirs[idx].double(), code[0].double(), weights(tag, torch.float64), c['plane_cfg'], c['flip_z'], c['activation'])
+    np.testing.assert_allclose(sig.cpu()[idx].numpy(), so.numpy(), rtol=3e-5, atol=1e-7)
+    np.testing.assert_allclose(rgb.cpu()[idx].numpy(), ro.numpy(), rtol=0, atol=2e-5)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    xg, dg, cg = xyz.cuda(), dirs.cuda(), code.cuda()
+    eng.point_decode([xg], [dg], cg)
+    a.record()
+    for _ in range(5):
+        eng.point_decode([xg], [dg], cg)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    print(f'tri-plane decode: {N} points in {ms:.3f} ms = {N / ms / 1e6:.2f} G points/s, {N * 31.2e3 * 2 / ms / 1e9:.1f} TFLOP/s fp32')

@@ -444,10 +444,7 @@ def test_engine_sd15_full_size_properties(lib):
 def test_engine_graph_replay_equals_eager(lib):
     """mve_unet_graph (opt-in): the forward is captured on the second call with identical plan + tensor addresses and replayed afterwards.
     Replay must be bitwise equal to the eager result, must follow in-place changes of the inputs, and capture must refuse the legacy
-    default stream with a clear message.  Not yet run on hardware: opt in with MVE_RUN_PENDING=1."""
-    import os
-    if os.environ.get('MVE_RUN_PENDING') != '1':
-        pytest.skip('hipGraph replay not yet run on an MI355X (set MVE_RUN_PENDING=1)')
+    default stream with a clear message."""
     from mvedit_amd import _lib
     eng, out_eager, (x, ctx, down, mid) = _parity(U.TINY, 2, 16, torch.float16)
     t = torch.full((2,), 999.0, device='cuda')

@@ -503,10 +503,6 @@ def test_gemm_256_wide_tile_matches_small_kernel(lib):
 def test_attention_experimental_variant_matches_default(lib):
     """mve_attention_tune(1): 16 query rows per wave / 64-key fills for head dim 40 (an A/B candidate, tools/ab_attention.py).  Same
     function, different rescale points: agreement to rounding with the default and with the reference softmax."""
-    from conftest import pending_first_gpu_run  # noqa: F401  (the variant has not run on hardware yet: opt in with MVE_RUN_PENDING=1)
-    import os
-    if os.environ.get('MVE_RUN_PENDING') != '1':
-        pytest.skip('attention variant 1 not yet run on an MI355X (set MVE_RUN_PENDING=1)')
     from mvedit_amd import ops, _lib
     dtype = torch.float16
     B, L, heads, d = 2, 333, 8, 40
@@ -531,9 +527,6 @@ def test_attention_experimental_variant_matches_default(lib):
 def test_attention_conflict_free_k_swizzle_is_bit_identical(lib):
     """mve_attention_tune(2): the K tile of head dims 80 / 160 stored under a chunk permutation whose fragment reads have no LDS bank
     conflicts (derived analytically from the ds_read_b128 lane groups; tools/lds_conflicts.py).  Pure data-layout change: bitwise equal."""
-    import os
-    if os.environ.get('MVE_RUN_PENDING') != '1':
-        pytest.skip('attention variant 2 not yet run on an MI355X (set MVE_RUN_PENDING=1)')
     from mvedit_amd import ops, _lib
     tune = _lib.raw('mve_attention_tune')
     old = tune(-1)
@@ -554,9 +547,6 @@ def test_attention_conflict_free_k_swizzle_is_bit_identical(lib):
 def test_attention_vt_store_swizzle_is_bit_identical(lib):
     """mve_attention_tune(4) / (6): the V^T tile under a swizzle that also spreads the transposing ds_write_b32 stores over the banks
     (tools/lds_conflicts.py: 5- to 10-way -> 2- to 4-way, reads still conflict-free).  Pure data-layout change: bitwise equal."""
-    import os
-    if os.environ.get('MVE_RUN_PENDING') != '1':
-        pytest.skip('attention variants 4 / 6 not yet run on an MI355X (set MVE_RUN_PENDING=1)')
     from mvedit_amd import ops, _lib
     tune = _lib.raw('mve_attention_tune')
     old = tune(-1)
