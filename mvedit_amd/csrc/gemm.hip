@@ -43,6 +43,7 @@ constexpr int BM = 128;
 // defined in gemm_big.hip (256 x 320 tiles, bit-identical results)
 long long mve_gemm_big_blocks(int M, int N, int splitk);
 int mve_gemm_big_launch(int dtype, int mode, const void* params, void* stream);
+int mve_gemm_pp_launch(int dtype, int mode, const void* params, void* stream);      // gemm_pp.hip; 1 = not eligible
 namespace {
 
 template <class Tag, int BN, int MODE>   // MODE 0: dense A, 1: conv3x3 gather
@@ -350,6 +351,21 @@ int gemm_big_min_blocks() {
 // The big-tile kernel exists 320 columns wide (every UNet width) and 256 wide (the VAE's 256 / 512-channel convs; no split-K
 // variants).  Any other N -- 128 at image resolution, 8 for conv_out -- would leave most of a big tile dead and takes the
 // 128 x {64,128,160} kernel, whose results are bit-identical.
+// The 256-row tile has two main loops with bit-identical results: the ping-pong schedule (gemm_pp.hip) wherever it is eligible,
+// else the two-stage loop (gemm_big.hip).  mve_gemm_tune bit 27 / MVE_GEMM_PP=0 turn the former off (A/B).
+int g_gemm_pp = -1;
+int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
+    if (g_gemm_pp < 0) {
+        const char* e = getenv("MVE_GEMM_PP");
+        g_gemm_pp = e ? atoi(e) : 1;
+    }
+    if (g_gemm_pp) {
+        const int rc = mve_gemm_pp_launch(dtype, mode, q, s);
+        if (rc <= 0) return rc;
+    }
+    return mve_gemm_big_launch(dtype, mode, q, s);
+}
+
 bool big_tile_fits(int N, int splitk) { return N % 320 == 0 || (N % 256 == 0 && splitk <= 1); }
 
 template <class Tag, int MODE>
@@ -362,11 +378,11 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         GemmParams q = p;
         q.splitk_seq = p.splitk;
         q.splitk = 1;
-        return mve_gemm_big_launch(Tag::dtype, MODE, &q, s);
+        return launch_tile256(Tag::dtype, MODE, &q, s);
     }
     if (gemm_big_min_blocks() > 0 && mve_gemm_big_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
         GemmParams q = p;
-        const int rc = mve_gemm_big_launch(Tag::dtype, MODE, &q, s);
+        const int rc = launch_tile256(Tag::dtype, MODE, &q, s);
         if (rc) return rc;
         if (p.splitk > 1) {
             k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
@@ -398,7 +414,8 @@ int mve_gemm_tune(int big_min_blocks) {
     const int old = gemm_big_min_blocks();
     if (big_min_blocks >= 0) {
         g_seq_splitk = (big_min_blocks & (1 << 29)) ? 0 : 1;
-        g_big_min_blocks = big_min_blocks & ~(3 << 28);
+        g_gemm_pp = (big_min_blocks & (1 << 27)) ? 0 : 1;
+        g_big_min_blocks = big_min_blocks & ~((3 << 28) | (1 << 27));
     }
     return old;
 }

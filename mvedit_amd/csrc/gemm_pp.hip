@@ -1,0 +1,379 @@
+// Ping-pong main loop for the 256 x {320,256} GEMM / implicit-GEMM conv tile (same tile, wave arrangement, MFMA order and epilogue
+// as gemm_big.hip, hence bit-identical results; only the schedule of one K step differs).
+//
+// Why: rocprofv3 PMC on k_gemm_big (profiles/r02_rocprof_v1_summary.txt) shows the MFMA pipe 47 % busy at the clock the kernel
+// actually runs at.  Its 8 waves run one K tile in lock-step -- all of them issue their 9 LDS-DMA pieces, then all of them read
+// fragments, then all of them issue MFMAs -- so the two waves that share a SIMD want the matrix pipe at the same time and leave it
+// idle at the same time.  Here the two wave groups (wm = 0: waves 0-3, wm = 1: waves 4-7, one wave of each per SIMD) run half a
+// step apart, held there by a barrier after every section:
+//
+//     interval   2k        2k+1      2k+2      2k+3
+//     group 0    L(k)      M(k)      L(k+1)    M(k+1)          L(k): 13 ds_read_b128 of step k's fragments + this wave's LDS-DMA
+//     group 1    M(k-1)    L(k)      M(k)      L(k+1)                pieces of step k+3;   M(k): 40 MFMA 16x16x32
+//
+// so one wave of every SIMD is always in its MFMA section while the other one does the LDS / DMA work.
+//   * K step = 32 (one MFMA k-step): only 13 fragments (52 VGPRs) are live next to the 160 accumulator registers.
+//   * LDS: a ring of 4 slots of 36 KiB (256 + 320 rows x 64 B) = 144 KiB, the same footprint as the two 72 KiB stages.  A slot
+//     row holds the 4 16-byte chunks of one (row, K step) XOR-swizzled by (row >> 2) & 3: a 16-lane ds_read_b128 group touches all
+//     16 slots of a bank row exactly once.  The swizzle is applied on the global side of the LDS-DMA (lane -> source chunk).
+//   * prefetch distance 3 steps, never drained: at the end of L(k) a wave waits (counted vmcnt) for ITS pieces of step k+1 only
+//     -- issued two steps earlier -- and the barrier that ends the interval publishes them.  Hazards, by interval number:
+//       RAW  step k+1 is read in 2k+2 (group 0) and 2k+3 (group 1); its B pieces were waited for by group 0 before the barrier
+//            ending 2k, its A pieces by group 1 before the barrier ending 2k+1.
+//       WAR  step k+3 goes to slot (k-1) & 3, last read in 2k-2 / 2k-1 with lgkmcnt(0) before the barrier ending 2k-1; the
+//            earliest issue is group 0's in 2k.
+//   * role split: group 0 streams the weight rows (5 pieces per wave and step for BN = 320), group 1 the activation rows (4 pieces):
+//     a wave carries the address state of one operand only.
+//   * addresses: buffer_load_dwordx4 ... lds with the step's uniform part (K offset, conv tap and channel slab) folded into the
+//     resource base by SALU and a per-lane byte offset that is constant (GEMM, weights) or recomputed once per 64-channel slab
+//     (conv).  Halo pixels and steps past the end of K use an out-of-range offset / a zero-sized resource: the DMA writes zeros.
+//   * LDS-DMA and waits are inline asm (hipcc would drain vmcnt to 0 at every barrier and before LDS reads it cannot disambiguate).
+#include "common.h"
+
+#include "gemm_shared.h"
+#include "gemm_big_epilogue.h"
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PBM = 256, PNTH = 512;
+constexpr int PROWB = 64;                               // bytes per row and K step
+constexpr int PNSLOT = 4;
+constexpr int P_A_SLOT = PBM * PROWB;                   // 16 KiB
+constexpr unsigned P_OOB = 0xFFFFFFF0u, P_NUMREC = 0xFFFFFF00u;
+constexpr int pp_slot_bytes(int bn) { return P_A_SLOT + bn * PROWB; }
+constexpr int pp_smem(int bn) { return PNSLOT * pp_slot_bytes(bn); }
+static_assert(64 * (320 + 4) * 4 <= pp_smem(320) && 64 * (256 + 4) * 4 <= pp_smem(256), "epilogue staging must fit");
+
+__device__ __forceinline__ i32x4 pp_rsrc(unsigned long long base, bool live) {
+    i32x4 r;          // readfirstlane: the operands are wave-uniform by construction; this pins them to SGPRs for the asm below
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xFFFFu));
+    r[2] = __builtin_amdgcn_readfirstlane(live ? (int)P_NUMREC : 0);
+    r[3] = 0x00020000;
+    return r;
+}
+
+// NP LDS-DMA pieces of 1 KiB (64 lanes x 16 B, lane-linear in LDS from `dst` + 1 KiB * q)
+template <int NP>
+__device__ __forceinline__ void pp_dma(const unsigned (&vo)[5], i32x4 rsrc, unsigned dst) {
+    unsigned keep;
+    static_assert(NP == 4 || NP == 5, "4 or 5 pieces per wave and step");
+    if constexpr (NP == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(rsrc), "s"(dst), "s"(dst + 1024u), "s"(dst + 2048u), "s"(dst + 3072u)
+                     : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "s"(rsrc), "s"(dst), "s"(dst + 1024u), "s"(dst + 2048u),
+                       "s"(dst + 3072u), "s"(dst + 4096u)
+                     : "memory");
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pp_barrier_lds() {      // end of an L section: fragments in registers, slot reads retired
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// In-place MFMA (acc += a x b) issued from asm: with the builtin, hipcc rotates the 160 accumulator registers through the unrolled
+// ring (destination != C operand on 168 of 240 MFMAs) and spills inside the loop.  The sections are hand-ordered anyway; what the
+// compiler no longer sees is the MFMA -> VALU read-after-write distance on the accumulators: pp_mfma_settle() pads it before the
+// accumulators are read by ordinary code.
+template <class Tag> struct PMfma;
+template <> struct PMfma<F16Tag> {
+    static __device__ __forceinline__ void run(f32x4& c, const f16x8& a, const f16x8& b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+};
+template <> struct PMfma<BF16Tag> {
+    static __device__ __forceinline__ void run(f32x4& c, const bf16x8& a, const bf16x8& b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+};
+__device__ __forceinline__ void pp_mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+template <class Tag, int MODE, bool SEQ, int BN2>        // MODE 1: slab-major (chunk64) conv only
+__global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
+    typedef typename Tag::V8 V8;
+    typedef typename Tag::T T;
+    constexpr int MF = 8, WTM = 128;
+    constexpr int WTN = BN2 / 4, NF = WTN / 16;                // 80 -> 5 fragments, 64 -> 4
+    constexpr int NPB = BN2 / 64;                              // weight pieces per group-0 wave and step: 5 | 4
+    constexpr int NPA = 4;                                     // activation pieces per group-1 wave and step
+    constexpr int SLOT = pp_slot_bytes(BN2);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;                     // wm doubles as the group / role index
+
+    const int tiles_n = (p.N + BN2 - 1) / BN2;
+    const int tiles_m = (p.M + PBM - 1) / PBM;
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    const unsigned lin = mve_xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n * S));
+    const int kslice = lin % S;
+    const unsigned tile = lin / S;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * PBM, n0 = tn * BN2;
+
+    const int nk_all = p.K / BK;
+    // (the 64-bit divisions are expanded on the VALU: readfirstlane returns the results to SGPRs)
+    const int kt_begin = __builtin_amdgcn_readfirstlane((int)((long long)nk_all * kslice / S));
+    const int kt_end = __builtin_amdgcn_readfirstlane((int)((long long)nk_all * (kslice + 1) / S));
+    const int nsteps = 2 * (kt_end - kt_begin);
+
+    // ---- DMA role state ------------------------------------------------------------------------------------------------------
+    // lane l of a piece writes LDS bytes [16 l, 16 l + 16): row l >> 2 of the piece, stored chunk l & 3 = source chunk ^ swizzle
+    const int prow = lane >> 2;
+    const unsigned c16 = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    unsigned u[5] = {0u, 0u, 0u, 0u, 0u};     // weights / dense A: byte offset of the lane's chunk in step 0; conv: biased pixel index of the row
+    unsigned vmask[NPA] = {0u, 0u, 0u, 0u};
+    unsigned vsel[5] = {0u, 0u, 0u, 0u, 0u};  // conv: the offsets of the current slab / tap (out-of-range marker for halo rows)
+    const unsigned smem_base = (unsigned)(size_t)smem;
+    unsigned long long op_base;               // group 0: weights; group 1: dense A (MODE 0)
+    unsigned dst0;                            // LDS offset of this wave's first piece inside a slot
+    const int conv_bias = p.g.Ws + 1;
+    if (wm == 0) {
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            int n = n0 + (wn * NPB + q) * 16 + prow;
+            n = n < p.N ? n : p.N - 1;
+            u[q] = (unsigned)n * (unsigned)p.ldw * 2u + c16;
+        }
+        op_base = (unsigned long long)p.W + (unsigned long long)kt_begin * (BK * 2);
+        dst0 = smem_base + P_A_SLOT + wn * NPB * 1024;
+    } else {
+        const int hw = p.g.Ho * p.g.Wo;
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            int m = m0 + (wn * NPA + q) * 16 + prow;
+            m = m < p.M ? m : p.M - 1;
+            if constexpr (MODE == 0) u[q] = (unsigned)m * (unsigned)p.lda * 2u + c16;
+            else {
+                const int b = m / hw, r = m - b * hw;
+                const int y = r / p.g.Wo;
+                const int cy = y * p.g.stride - p.g.pad, cx = (r - y * p.g.Wo) * p.g.stride - p.g.pad;
+                u[q] = (unsigned)((b * p.g.Hs + (cy >> p.g.ups)) * p.g.Ws + (cx >> p.g.ups) + conv_bias);
+                unsigned mk = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yi = cy + t / 3, xi = cx + t % 3;
+                    if (yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv) mk |= 1u << t;
+                }
+                if (p.g.ups) mk |= ((unsigned)(cy & 1) << 9) | ((unsigned)(cx & 1) << 10);
+                vmask[q] = mk;
+            }
+        }
+        op_base = (unsigned long long)p.A + (unsigned long long)kt_begin * (BK * 2);
+        dst0 = smem_base + wn * NPA * 1024;
+    }
+    unsigned long long conv_base = 0;         // resource base of the current (tap, slab), first 32-channel half
+
+    // issue this wave's pieces of step s (relative to kt_begin) into slot SL; steps past the end write zeros
+    auto issue = [&](int s) {
+        const bool live = s < nsteps;
+        const unsigned dst = dst0 + (unsigned)(s & 3) * SLOT;
+        if (wm == 0) {
+            pp_dma<NPB>(u, pp_rsrc(op_base + (unsigned long long)s * PROWB, live), dst);
+        } else if constexpr (MODE == 0) {
+            pp_dma<NPA>(u, pp_rsrc(op_base + (unsigned long long)s * PROWB, live), dst);
+        } else {
+            if (!(s & 1)) {
+                const int kt = kt_begin + (s >> 1);
+                int t_ = kt % 9, c0 = (kt / 9) * 64;
+                bool second = c0 >= p.g.C1;
+                const void* src = second ? p.A2 : p.A;
+                int cs = second ? p.g.C2 : p.g.C1;
+                int ch = second ? c0 - p.g.C1 : c0;
+                if (p.g.nk_main > 0 && kt >= p.g.nk_main) {            // 1x1 shortcut part: centre tap of the shortcut sources
+                    t_ = 4;
+                    c0 = (kt - p.g.nk_main) * 64;
+                    second = c0 >= p.g.C3;
+                    src = second ? p.A4 : p.A3;
+                    cs = second ? p.g.C4 : p.g.C3;
+                    ch = second ? c0 - p.g.C3 : c0;
+                }
+                const int dy = t_ / 3, dx = t_ - dy * 3;
+                const int toff = p.g.ups ? 0 : dy * p.g.Ws + dx;
+                conv_base = (unsigned long long)((long long)(size_t)src + 2ll * ((long long)(toff - conv_bias) * cs + ch));
+                const unsigned cs2 = (unsigned)cs * 2u;
+#pragma unroll
+                for (int q = 0; q < NPA; ++q) {
+                    unsigned px = u[q];
+                    if (p.g.ups) px += (unsigned)((int)((((vmask[q] >> 9) & 1u) + dy) >> 1) * p.g.Ws + (int)((((vmask[q] >> 10) & 1u) + dx) >> 1));
+                    const unsigned vo = px * cs2 + c16;
+                    vsel[q] = ((vmask[q] >> t_) & 1u) ? vo : P_OOB;
+                }
+            }
+            pp_dma<NPA>(vsel, pp_rsrc(conv_base + ((s & 1) ? PROWB : 0), live), dst);
+        }
+    };
+
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets inside a slot (lane constants): row r = ... + frow, stored chunk = fchunk ^ ((r >> 2) & 3)
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int fsw = (fchunk ^ ((frow >> 2) & 3)) << 4;
+    const int a_off = (wm * WTM + frow) * PROWB + fsw;
+    const int b_off = P_A_SLOT + (wn * WTN + frow) * PROWB + fsw;
+
+    auto wait_next = [&]() {                  // this wave's pieces of the NEXT step have landed; two steps stay in flight
+        if constexpr (NPB == NPA) pp_wait_vm<2 * NPA>();
+        else {
+            if (wm == 0) pp_wait_vm<2 * NPB>();
+            else pp_wait_vm<2 * NPA>();
+        }
+    };
+
+    issue(0);
+    issue(1);
+    issue(2);
+    wait_next();                              // step 0
+    pp_barrier();
+    if (wm == 1) pp_barrier();                // group 1 starts one interval late
+
+    const int SQ = SEQ ? p.splitk_seq : 1;
+    int sl_idx = 0;
+    int fold_at = SEQ ? 2 * __builtin_amdgcn_readfirstlane((int)((long long)nk_all * 1 / SQ)) : nsteps;      // first step index at which a slice is complete
+
+    // One copy of the step body: the slot offset is a run-time scalar (two v_add per step) rather than four unrolled copies --
+    // the SEQ fold below would otherwise be inlined into each of them.
+    auto step = [&](int k) {
+        V8 xf[MF], wf[NF];
+        const unsigned char* sp = smem + (k & 3) * SLOT;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const V8*>(sp + b_off + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const V8*>(sp + a_off + i * 1024);
+        issue(k + 3);
+        wait_next();
+        pp_barrier_lds();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int i = 0; i < MF; ++i) PMfma<Tag>::run(acc[j][i], wf[j], xf[i]);
+        __builtin_amdgcn_s_setprio(0);
+        pp_barrier();
+        if constexpr (SEQ) {
+            // sequential split-K emulation (GemmParams::splitk_seq): at a slice boundary the accumulators are folded into lane-private
+            // 16-byte slots of a block-private fp32 running total.  The fold's loads / stores are the compiler's: drain the DMA queue
+            // around it so that its vmcnt bookkeeping and the counted waits above stay exact.
+            if (k + 1 == fold_at) {
+                pp_mfma_settle();
+                pp_wait_vm<0>();
+                // (the offset passes through an opaque asm so that the 40 slot addresses are formed here, not hoisted out of the K loop
+                // into 80 registers that would be spilled -- scratch reloads on the hot path would drain vmcnt)
+                size_t tot_off = (size_t)tile * (PBM * BN2 / 4) + (size_t)wid * (NF * MF * 64) + lane;
+                asm volatile("" : "+v"(tot_off));
+                f32x4* tot = reinterpret_cast<f32x4*>(p.partial) + tot_off;
+                const bool last = sl_idx + 1 == SQ;
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) {
+                        f32x4* slot = tot + (j * MF + i) * 64;
+                        f32x4 t = acc[j][i];
+                        if (sl_idx > 0) { const f32x4 o = *slot; t = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]}; }
+                        if (last) acc[j][i] = t;
+                        else { *slot = t; acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                pp_wait_vm<0>();
+                ++sl_idx;
+                fold_at = 2 * __builtin_amdgcn_readfirstlane((int)((long long)nk_all * (sl_idx + 1) / SQ));
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) step(k);
+    if (wm == 0) pp_barrier();                // pairs with group 1's last barrier
+    pp_wait_vm<0>();                          // the zero-fill pieces of the steps past the end
+    pp_barrier();
+    pp_mfma_settle();
+
+    big_tile_epilogue<Tag, BN2>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
+}
+
+int pp_bn(int N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : 0); }
+
+template <class Tag, int MODE, bool SEQ, int BN2>
+int launch_pp3(const GemmParams& p, hipStream_t s) {
+    static bool configured[64] = {};
+    int dev = 0;
+    MVE_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !configured[dev]) {
+        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pp<Tag, MODE, SEQ, BN2>), hipFuncAttributeMaxDynamicSharedMemorySize, pp_smem(BN2)));
+        configured[dev] = true;
+    }
+    const unsigned grid = (unsigned)mve_cdiv(p.M, PBM) * (unsigned)mve_cdiv(p.N, BN2) * (unsigned)(p.splitk > 1 ? p.splitk : 1);
+    k_gemm_pp<Tag, MODE, SEQ, BN2><<<grid, PNTH, pp_smem(BN2), s>>>(p);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+template <class Tag, int MODE>
+int launch_pp(const GemmParams& p, hipStream_t s) {
+    if (pp_bn(p.N) == 256) return launch_pp3<Tag, MODE, false, 256>(p, s);
+    return p.splitk_seq > 1 ? launch_pp3<Tag, MODE, true, 320>(p, s) : launch_pp3<Tag, MODE, false, 320>(p, s);
+}
+
+// every per-lane byte offset must stay below the resource size (and the out-of-range marker above it)
+bool pp_fits(unsigned long long bytes) { return bytes + 65536ull < (unsigned long long)P_NUMREC; }
+
+bool pp_eligible(int mode, const GemmParams& p) {
+    const int bn = pp_bn(p.N);
+    if (bn == 0 || p.M < 64 || p.K % BK != 0) return false;
+    if (bn == 256 && (p.splitk > 1 || p.splitk_seq > 1)) return false;
+    if (!pp_fits((unsigned long long)p.N * p.ldw * 2)) return false;
+    if (mode == 0) return pp_fits((unsigned long long)p.M * p.lda * 2);
+    if (!p.g.chunk64) return false;
+    const int hw = p.g.Ho * p.g.Wo;
+    const unsigned long long px = (unsigned long long)((p.M + hw - 1) / hw) * p.g.Hs * p.g.Ws + 2ull * p.g.Ws + 4;
+    int cmax = p.g.C1 > p.g.C2 ? p.g.C1 : p.g.C2;
+    cmax = cmax > p.g.C3 ? cmax : p.g.C3;
+    cmax = cmax > p.g.C4 ? cmax : p.g.C4;
+    return pp_fits(px * cmax * 2);
+}
+
+}  // namespace
+
+// ping-pong main loop + epilogue (or split-K partials; the caller runs the reducer).  Returns 1 when the problem is not eligible
+// (the caller falls back to the two-stage kernel), MVE_OK after a launch, < 0 on error.
+int mve_gemm_pp_launch(int dtype, int mode, const void* params, void* stream) {
+    const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
+    if (!pp_eligible(mode, p)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MVE_F16) return mode == 0 ? launch_pp<F16Tag, 0>(p, s) : launch_pp<F16Tag, 1>(p, s);
+    if (dtype == MVE_BF16) return mode == 0 ? launch_pp<BF16Tag, 0>(p, s) : launch_pp<BF16Tag, 1>(p, s);
+    mve_set_error("gemm_pp: unsupported dtype %d", dtype);
+    return MVE_ERR_ARG;
+}

@@ -11,6 +11,10 @@ import math
 import numpy as np
 import pytest
 import torch
+
+# mve_gemm_tune settings under which every GEMM / conv result must be bit-identical: the 128-row kernel only, the 256-row tile from one
+# block up (ping-pong main loop where eligible, csrc/gemm_pp.hip), the same with the ping-pong loop disabled (two-stage loop, gemm_big.hip)
+TILE_MODES = (0, 1, 1 | (1 << 27))
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -349,10 +353,10 @@ def test_big_tile_kernel_is_bit_identical(lib):
             bias = rnd((N,), torch.float32, 3).cuda()
             res = None if fl else rnd((M, N), dtype, 4).cuda()
             outs = []
-            for big in (0, 1):
-                tune(1 if big else 0)
+            for big in TILE_MODES:
+                tune(big)
                 outs.append(ops.gemm(a, w, bias=bias, residual=res, flags=fl, rows_per_image=rpi))
-            assert torch.equal(outs[0], outs[1]), (M, N, K)
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (M, N, K)
         for (B, H, C1, C2, Cout, stride, ups) in [(4, 16, 320, 0, 320, 1, False), (3, 16, 640, 320, 640, 1, False), (2, 16, 320, 0, 320, 2, False),
                                                   (2, 8, 640, 0, 640, 1, True), (5, 9, 72, 0, 320, 1, False)]:
             x1 = to_nhwc(rnd((B, C1, H, H), dtype, 1)).cuda()
@@ -360,10 +364,10 @@ def test_big_tile_kernel_is_bit_identical(lib):
             wt = rnd((Cout, C1 + C2, 3, 3), dtype, 3, (9 * (C1 + C2)) ** -0.5)
             w_k, wflag = ops.pack_conv_weight(wt, (C1 % 64 == 0 and C2 % 64 == 0))
             outs = []
-            for big in (0, 1):
-                tune(1 if big else 0)
+            for big in TILE_MODES:
+                tune(big)
                 outs.append(ops.conv3x3(x1, w_k.cuda(), B, H, H, x2=x2, stride=stride, upsample=ups, flags=wflag)[0])
-            assert torch.equal(outs[0], outs[1]), (B, H, C1, C2, Cout, stride, ups)
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (B, H, C1, C2, Cout, stride, ups)
     finally:
         tune(old)
 
@@ -389,11 +393,11 @@ def test_conv3x3_with_fused_shortcut(lib, B, H, C1, C3, C4):
     old = tune(-1)
     try:
         outs = []
-        for big in (0, 1):
-            tune(1 if big else 0)
+        for big in TILE_MODES:
+            tune(big)
             outs.append(ops.conv3x3_shortcut(to_nhwc(h).cuda(), wcat.cuda(), B, H, H, to_nhwc(x3).cuda(),
                                              to_nhwc(x4).cuda() if C4 else None, bias=b2.cuda(), bias2=bs.cuda()))
-        assert torch.equal(outs[0], outs[1])
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
         check('conv3x3 + shortcut', outs[0], to_nhwc(ref), dtype)
     finally:
         tune(old)
@@ -416,12 +420,12 @@ def test_conv3x3_downsample_pad_bottom_right(lib, B, H, W, C, Cout):
         for chunk64 in ([False, True] if C % 64 == 0 else [False]):
             w_k, wflag = ops.pack_conv_weight(w, chunk64)
             outs = []
-            for big in (0, 1):
-                tune(1 if big else 0)
+            for big in TILE_MODES:
+                tune(big)
                 out, Ho, Wo = ops.conv3x3(to_nhwc(x).cuda(), w_k.cuda(), B, H, W, stride=2, bias=bias.cuda(), flags=wflag | ops.PAD_BR)
                 assert (Ho, Wo) == (H // 2, W // 2)
                 outs.append(out)
-            assert torch.equal(outs[0], outs[1])
+            assert all(torch.equal(outs[0], o) for o in outs[1:])
             check('conv3x3 pad_br', outs[0], to_nhwc(ref), dtype, f'chunk64={chunk64}')
     finally:
         tune(old)
@@ -467,13 +471,13 @@ def test_conv3x3_big_tiles_and_upsample_addressing(lib, dtype, B, H, W, C1, C2, 
     old = tune(-1)
     try:
         outs = []
-        for big in (0, 1):
-            tune(1 if big else 0)
+        for big in TILE_MODES:
+            tune(big)
             out, Ho, Wo = ops.conv3x3(to_nhwc(x1).cuda(), w_k.cuda(), B, H, W, x2=to_nhwc(x2).cuda() if C2 else None, stride=stride,
                                       upsample=ups, bias=bias.cuda(), flags=wflag)
             outs.append(out)
         assert (Ho, Wo) == tuple(ref.shape[2:])
-        assert torch.equal(outs[0], outs[1])
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
         check('conv3x3 big/upsample', outs[0], to_nhwc(ref), dtype, f'{(B, H, W, C1, C2, Cout, stride, ups)}')
     finally:
         tune(old)
@@ -490,10 +494,10 @@ def test_gemm_256_wide_tile_matches_small_kernel(lib):
     old = tune(-1)
     try:
         outs = []
-        for big in (0, 1):
-            tune(1 if big else 0)
+        for big in TILE_MODES:
+            tune(big)
             outs.append(ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda()))
-        assert torch.equal(outs[0], outs[1])
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
         check('gemm 256-wide', outs[0], a.float() @ w.float().t() + bias, dtype)
     finally:
         tune(old)
@@ -561,5 +565,47 @@ def test_attention_vt_store_swizzle_is_bit_identical(lib):
                     tune(variant)
                     o1 = ops.attention(q, k, v, 2, L, L, heads, d)
                     assert torch.equal(o0, o1), (dtype, heads, d, variant)
+    finally:
+        tune(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_pingpong_main_loop_is_bit_identical_and_race_free(lib, dtype):
+    """csrc/gemm_pp.hip keeps LDS-DMA in flight across barriers with counted vmcnt and a 4-slot ring: a slot read too early or
+    overwritten too early shows up as a wrong tile that comes and goes.  Many-block launches with long and short K, repeated, against
+    the two-stage kernel (same MFMA order -> identical bits): dense, GEGLU, split-K (parallel and sequential), conv with concat /
+    shortcut / halo rows, M and N tails."""
+    from mvedit_amd import ops, _lib
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    PP, BIG = 1, 1 | (1 << 27)
+    try:
+        for (M, N, K, rpi, fl) in [(70000, 320, 320, 0, 0), (33000, 960, 64, 0, 0), (20000, 2560, 320, 0, ops.GEGLU), (16384, 320, 1280, 0, 0),
+                                   (9000, 1280, 5120, 0, 0), (1024, 1280, 11520, 64, 0), (777, 512, 640, 0, 0), (4096, 256, 4608, 0, 0)]:
+            a, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
+            bias = rnd((N,), torch.float32, 3).cuda()
+            res = None if fl else rnd((M, N), dtype, 4).cuda()
+            tune(BIG)
+            ref = ops.gemm(a, w, bias=bias, residual=res, flags=fl, rows_per_image=rpi)
+            tune(PP)
+            for rep in range(4):
+                out = ops.gemm(a, w, bias=bias, residual=res, flags=fl, rows_per_image=rpi)
+                assert torch.equal(out, ref), (M, N, K, rep, int((out != ref).sum()))
+        for (B, H, C1, C2, Cout, stride, ups) in [(24, 32, 320, 0, 320, 1, False), (8, 32, 640, 320, 640, 1, False), (6, 32, 320, 0, 640, 2, False),
+                                                  (4, 16, 640, 0, 640, 1, True), (16, 8, 1280, 1280, 1280, 1, False), (2, 64, 128, 0, 256, 1, False),
+                                                  (3, 24, 192, 64, 512, 1, True)]:
+            x1 = to_nhwc(rnd((B, C1, H, H), dtype, 1)).cuda()
+            x2 = to_nhwc(rnd((B, C2, H, H), dtype, 2)).cuda() if C2 else None
+            wt = rnd((Cout, C1 + C2, 3, 3), dtype, 3, (9 * (C1 + C2)) ** -0.5)
+            w_k, wflag = ops.pack_conv_weight(wt, True)
+            w_k = w_k.cuda()
+            for sk in (False, True):
+                tune(BIG)
+                ref = ops.conv3x3(x1, w_k, B, H, H, x2=x2, stride=stride, upsample=ups, flags=wflag, splitk=sk)[0]
+                tune(PP)
+                for rep in range(3):
+                    out = ops.conv3x3(x1, w_k, B, H, H, x2=x2, stride=stride, upsample=ups, flags=wflag, splitk=sk)[0]
+                    assert torch.equal(out, ref), (B, H, C1, C2, Cout, stride, ups, sk, rep, int((out != ref).sum()))
     finally:
         tune(old)
