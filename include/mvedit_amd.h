@@ -179,10 +179,17 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int l
                      const void* d_residual, int ldr, int flags, float out_scale, void* d_workspace,
                      size_t workspace_bytes, int rows_per_image, void* stream);
 
-/* Tuning knob: GEMM / conv launches whose 256 x 320 tiling yields at least `big_min_blocks` blocks use the big-tile kernel
- * (csrc/gemm_big.hip; bit-identical results, so the choice never affects parity or batch invariance).  0 disables it, a negative
- * value only queries.  Returns the previous setting.  The default comes from the environment variable MVE_GEMM_BIG. */
+/* Tuning knob: GEMM / conv launches whose 256 x 320 tiling yields at least `big_min_blocks` (bits 0..26) blocks use the 256-row tile
+ * (bit-identical results, so the choice never affects parity or batch invariance).  0 disables it, a negative value only queries.
+ * Bit 27 set: the 256-row tile runs the two-stage main loop (csrc/gemm_big.hip) instead of the ping-pong loop (csrc/gemm_pp.hip);
+ * bit 29 set: real split-K + reducer instead of the sequential emulation.  Returns the previous block threshold.  The defaults
+ * come from the environment variables MVE_GEMM_BIG and MVE_GEMM_PP. */
 MVE_API int mve_gemm_tune(int big_min_blocks);
+
+/* Development aid for csrc/gemm_pp.hip: with `d_buf` (device, 64 uint64 per launched block) set, fp16 320-wide launches of the
+ * ping-pong kernel run an instrumented copy and every wave writes its shader-clock sums {L-section work, wait at the L barrier,
+ * M-section work, wait at the M barrier, fragment reads, address prep, 0, 0}; NULL turns it off.  (No reference counterpart.) */
+MVE_API int mve_gemm_pp_profile(void* d_buf);
 
 /* (No reference counterpart: scheduling detail of mve_gemm / mve_conv3x3.)  Split-K: at the deep UNet levels one image contributes only a few output tiles while K = 9*1280..9*2560; K is then cut
  * into slices that run concurrently and are summed in a fixed order by a second launch.  The slice count depends on

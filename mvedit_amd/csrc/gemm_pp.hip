@@ -30,6 +30,8 @@
 //   * LDS-DMA and waits are inline asm (hipcc would drain vmcnt to 0 at every barrier and before LDS reads it cannot disambiguate).
 #include "common.h"
 
+#include <type_traits>
+
 #include "gemm_shared.h"
 #include "gemm_big_epilogue.h"
 
@@ -55,34 +57,22 @@ __device__ __forceinline__ i32x4 pp_rsrc(unsigned long long base, bool live) {
     return r;
 }
 
-// NP LDS-DMA pieces of 1 KiB (64 lanes x 16 B, lane-linear in LDS from `dst` + 1 KiB * q)
-template <int NP>
-__device__ __forceinline__ void pp_dma(const unsigned (&vo)[5], i32x4 rsrc, unsigned dst) {
+// One LDS-DMA piece of 1 KiB: 64 lanes x 16 B, lane-linear in LDS from the offset held in M0.  The kernel owns M0 from pp_m0_take() to
+// pp_m0_give(): nothing hipcc emits for it touches M0 (no movrel, GWS, sendmsg or LDS-DMA builtin), which the build's ISA check
+// (tools/check_pp_isa.py) confirms, so the destination is written once per piece, one MFMA ahead of the load (the 1-wait-state
+// s_mov m0 -> LDS-DMA hazard is covered by that MFMA; pp_piece_now carries its own s_nop for the prologue).
+__device__ __forceinline__ unsigned pp_m0_take() {
     unsigned keep;
-    static_assert(NP == 4 || NP == 5, "4 or 5 pieces per wave and step");
-    if constexpr (NP == 4) {
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(rsrc), "s"(dst), "s"(dst + 1024u), "s"(dst + 2048u), "s"(dst + 3072u)
-                     : "memory");
-    } else {
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, 0 offen lds\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "s"(rsrc), "s"(dst), "s"(dst + 1024u), "s"(dst + 2048u),
-                       "s"(dst + 3072u), "s"(dst + 4096u)
-                     : "memory");
-    }
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+    return keep;
+}
+__device__ __forceinline__ void pp_m0_give(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep)); }
+__device__ __forceinline__ void pp_set_m0(unsigned dst) { asm volatile("s_mov_b32 m0, %0" ::"s"(dst)); }
+__device__ __forceinline__ void pp_dma_m0(unsigned vo, i32x4 rsrc) {
+    asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void pp_piece_now(unsigned vo, i32x4 rsrc, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(rsrc), "s"(dst) : "memory");
 }
 
 template <int N>
@@ -115,7 +105,12 @@ template <> struct PMfma<BF16Tag> {
 };
 __device__ __forceinline__ void pp_mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
-template <class Tag, int MODE, bool SEQ, int BN2>        // MODE 1: slab-major (chunk64) conv only
+// Section timing (development aid, mve_gemm_pp_profile): per wave, shader-clock sums of the four parts of a step.
+__device__ unsigned long long* g_pp_prof = nullptr;
+
+template <int V> struct PInt { static constexpr int value = V; };
+
+template <class Tag, int MODE, bool SEQ, int BN2, bool PROF = false>        // MODE 1: slab-major (chunk64) conv only
 __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
@@ -145,23 +140,36 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     const int kt_end = __builtin_amdgcn_readfirstlane((int)((long long)nk_all * (kslice + 1) / S));
     const int nsteps = 2 * (kt_end - kt_begin);
 
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned long long prof_v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_start = 0, prof_loop0 = 0, prof_end_loop = 0;
+    if constexpr (PROF) prof_start = __builtin_readcyclecounter();
+    // Everything from here to the end of the K loop exists once per role (ROLE 0: waves 0-3 stream the weight rows, ROLE 1: waves 4-7
+    // the activation rows): two straight-line copies instead of role tests, and their loop-carried copies, inside every step.
+    auto run = [&](auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr int NPM = ROLE == 0 ? NPB : NPA;                 // pieces this wave issues per step
     // ---- DMA role state ------------------------------------------------------------------------------------------------------
     // lane l of a piece writes LDS bytes [16 l, 16 l + 16): row l >> 2 of the piece, stored chunk l & 3 = source chunk ^ swizzle
     const int prow = lane >> 2;
     const unsigned c16 = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-    unsigned u[5] = {0u, 0u, 0u, 0u, 0u};     // weights / dense A: byte offset of the lane's chunk in step 0; conv: biased pixel index of the row
-    unsigned vmask[NPA] = {0u, 0u, 0u, 0u};
-    unsigned vsel[5] = {0u, 0u, 0u, 0u, 0u};  // conv: the offsets of the current slab / tap (out-of-range marker for halo rows)
+    unsigned vo[5] = {0u, 0u, 0u, 0u, 0u};    // per-piece byte offset of the lane's chunk: constant for weights / dense A, per (tap, slab) for conv rows
+    unsigned pixb[NPA] = {0u, 0u, 0u, 0u};    // conv rows: biased pixel index of the window origin
+    unsigned vmask[NPA] = {0u, 0u, 0u, 0u};   // conv rows: 9-bit tap validity + window-origin parities (upsample)
     const unsigned smem_base = (unsigned)(size_t)smem;
     unsigned long long op_base;               // group 0: weights; group 1: dense A (MODE 0)
     unsigned dst0;                            // LDS offset of this wave's first piece inside a slot
     const int conv_bias = p.g.Ws + 1;
-    if (wm == 0) {
+    if constexpr (ROLE == 0) {
 #pragma unroll
         for (int q = 0; q < NPB; ++q) {
             int n = n0 + (wn * NPB + q) * 16 + prow;
             n = n < p.N ? n : p.N - 1;
-            u[q] = (unsigned)n * (unsigned)p.ldw * 2u + c16;
+            vo[q] = (unsigned)n * (unsigned)p.ldw * 2u + c16;
         }
         op_base = (unsigned long long)p.W + (unsigned long long)kt_begin * (BK * 2);
         dst0 = smem_base + P_A_SLOT + wn * NPB * 1024;
@@ -171,12 +179,12 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
         for (int q = 0; q < NPA; ++q) {
             int m = m0 + (wn * NPA + q) * 16 + prow;
             m = m < p.M ? m : p.M - 1;
-            if constexpr (MODE == 0) u[q] = (unsigned)m * (unsigned)p.lda * 2u + c16;
+            if constexpr (MODE == 0) vo[q] = (unsigned)m * (unsigned)p.lda * 2u + c16;
             else {
                 const int b = m / hw, r = m - b * hw;
                 const int y = r / p.g.Wo;
                 const int cy = y * p.g.stride - p.g.pad, cx = (r - y * p.g.Wo) * p.g.stride - p.g.pad;
-                u[q] = (unsigned)((b * p.g.Hs + (cy >> p.g.ups)) * p.g.Ws + (cx >> p.g.ups) + conv_bias);
+                pixb[q] = (unsigned)((b * p.g.Hs + (cy >> p.g.ups)) * p.g.Ws + (cx >> p.g.ups) + conv_bias);
                 unsigned mk = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -191,73 +199,98 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
         dst0 = smem_base + wn * NPA * 1024;
     }
     unsigned long long conv_base = 0;         // resource base of the current (tap, slab), first 32-channel half
+    // conv sources as opaque scalars: left to itself hipcc turns `second ? p.g.C2 : p.g.C1` into a select of kernarg ADDRESSES and an
+    // s_load + lgkmcnt(0) inside the K loop
+    const int gC1 = p.g.C1, gC3 = p.g.C3, g_nkm = p.g.nk_main;
+    const int dC21 = p.g.C2 - p.g.C1, dC43 = p.g.C4 - p.g.C3;             // (differences: arithmetic results cannot be re-materialised as loads)
+    const long long gA1 = (long long)p.A, gA3 = (long long)p.A3;
+    const long long dA21 = (long long)p.A2 - (long long)p.A, dA43 = (long long)p.A4 - (long long)p.A3;
+    int i_kt = kt_begin, i_tap = kt_begin % 9, i_c0 = (kt_begin / 9) * 64, cs_cur = -1;      // issue-side K position (conv)
+    int d_px = 0, d_row = 0;                  // byte step of the base from one tap to the next: same row / next row
+    unsigned vrow[NPA] = {0u, 0u, 0u, 0u};    // conv rows: byte offset of the lane's chunk at the window origin for the current source
+    i32x4 r_cur;                              // resource and LDS destination of the step being issued
+    unsigned dst_cur;
 
-    // issue this wave's pieces of step s (relative to kt_begin) into slot SL; steps past the end write zeros
-    auto issue = [&](int s) {
+    // address part of issuing step s (relative to kt_begin): scalar work, plus 4 x ~5 VALU per 64-channel slab on the conv rows.
+    // Steps past the end get a zero-sized resource: their pieces write zeros and keep the vmcnt bookkeeping uniform.
+    auto prep = [&](int s) {
         const bool live = s < nsteps;
-        const unsigned dst = dst0 + (unsigned)(s & 3) * SLOT;
-        if (wm == 0) {
-            pp_dma<NPB>(u, pp_rsrc(op_base + (unsigned long long)s * PROWB, live), dst);
-        } else if constexpr (MODE == 0) {
-            pp_dma<NPA>(u, pp_rsrc(op_base + (unsigned long long)s * PROWB, live), dst);
+        dst_cur = dst0 + (unsigned)(s & 3) * SLOT;
+        if constexpr (MODE == 0 || ROLE == 0) {
+            r_cur = pp_rsrc(op_base + (unsigned long long)s * PROWB, live);
         } else {
             if (!(s & 1)) {
-                const int kt = kt_begin + (s >> 1);
-                int t_ = kt % 9, c0 = (kt / 9) * 64;
-                bool second = c0 >= p.g.C1;
-                const void* src = second ? p.A2 : p.A;
-                int cs = second ? p.g.C2 : p.g.C1;
-                int ch = second ? c0 - p.g.C1 : c0;
-                if (p.g.nk_main > 0 && kt >= p.g.nk_main) {            // 1x1 shortcut part: centre tap of the shortcut sources
-                    t_ = 4;
-                    c0 = (kt - p.g.nk_main) * 64;
-                    second = c0 >= p.g.C3;
-                    src = second ? p.A4 : p.A3;
-                    cs = second ? p.g.C4 : p.g.C3;
-                    ch = second ? c0 - p.g.C3 : c0;
-                }
-                const int dy = t_ / 3, dx = t_ - dy * 3;
-                const int toff = p.g.ups ? 0 : dy * p.g.Ws + dx;
-                conv_base = (unsigned long long)((long long)(size_t)src + 2ll * ((long long)(toff - conv_bias) * cs + ch));
-                const unsigned cs2 = (unsigned)cs * 2u;
+                // (tap, slab) of the K tile being issued (issue order is sequential: the counters advance by one tile per even step).
+                // Inside a 64-channel slab of the 3x3 part only the tap moves: the base advances by one pixel, or by a row minus two
+                // pixels, of the current source; everything else (slab, source, shortcut part) takes the full decode.
+                const bool shortcut = g_nkm > 0 && i_kt >= g_nkm;
+                int t_ = i_tap;
+                if (i_tap == 0 || shortcut || p.g.ups || cs_cur < 0) {       // (cs_cur < 0: first tile of a split-K slice that starts inside a slab)
+                    int c0 = i_c0;
+                    bool second = c0 >= gC1;
+                    long long src = gA1 + (second ? dA21 : 0ll);
+                    int cs = gC1 + (second ? dC21 : 0);
+                    int ch = second ? c0 - gC1 : c0;
+                    if (shortcut) {                                    // 1x1 shortcut part: centre tap of the shortcut sources
+                        t_ = 4;
+                        c0 = (i_kt - g_nkm) * 64;
+                        second = c0 >= gC3;
+                        src = gA3 + (second ? dA43 : 0ll);
+                        cs = gC3 + (second ? dC43 : 0);
+                        ch = second ? c0 - gC3 : c0;
+                    }
+                    const int dy = (t_ * 11) >> 5, dx = t_ - dy * 3;    // t_ / 3 for 0 <= t_ < 9
+                    const int toff = p.g.ups ? 0 : dy * p.g.Ws + dx;
+                    conv_base = (unsigned long long)(src + 2ll * ((long long)(toff - conv_bias) * cs + ch));
+                    d_px = p.g.ups ? 0 : cs * 2;
+                    d_row = p.g.ups ? 0 : (p.g.Ws - 2) * cs * 2;
+                    if (cs != cs_cur || p.g.ups) {                     // the row offsets depend on the source's channel count only (and on the tap when upsampling)
+                        cs_cur = cs;
 #pragma unroll
-                for (int q = 0; q < NPA; ++q) {
-                    unsigned px = u[q];
-                    if (p.g.ups) px += (unsigned)((int)((((vmask[q] >> 9) & 1u) + dy) >> 1) * p.g.Ws + (int)((((vmask[q] >> 10) & 1u) + dx) >> 1));
-                    const unsigned vo = px * cs2 + c16;
-                    vsel[q] = ((vmask[q] >> t_) & 1u) ? vo : P_OOB;
+                        for (int q = 0; q < NPA; ++q) {
+                            unsigned px = pixb[q];
+                            if (p.g.ups) px += (unsigned)((int)((((vmask[q] >> 9) & 1u) + dy) >> 1) * p.g.Ws + (int)((((vmask[q] >> 10) & 1u) + dx) >> 1));
+                            vrow[q] = px * ((unsigned)cs * 2u) + c16;
+                        }
+                    }
+                } else {
+                    conv_base += (unsigned long long)(long long)((i_tap == 3 || i_tap == 6) ? d_row : d_px);
                 }
+                ++i_kt;
+                if (++i_tap == 9) { i_tap = 0; i_c0 += 64; }
+#pragma unroll
+                for (int q = 0; q < NPA; ++q)      // halo row: all-ones offset = out of range (two VALU: v_bfe_i32 of the inverted mask, v_or)
+                    vo[q] = vrow[q] | (unsigned)__builtin_amdgcn_sbfe((int)~vmask[q], (unsigned)t_, 1u);
             }
-            pp_dma<NPA>(vsel, pp_rsrc(conv_base + ((s & 1) ? PROWB : 0), live), dst);
+            r_cur = pp_rsrc(conv_base + ((s & 1) ? PROWB : 0), live);
         }
     };
-
-    f32x4 acc[NF][MF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-#pragma unroll
-        for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (q is a compile-time constant at every call site; group 1 has no fifth piece)
+    auto piece_aim = [&](int q) { if (q < NPM) pp_set_m0(dst_cur + q * 1024); };
+    auto piece_fire = [&](int q) { if (q < NPM) pp_dma_m0(vo[q], r_cur); };
+    auto piece_now = [&](int q) { if (q < NPM) pp_piece_now(vo[q], r_cur, dst_cur + q * 1024); };
 
     // fragment read offsets inside a slot (lane constants): row r = ... + frow, stored chunk = fchunk ^ ((r >> 2) & 3)
     const int frow = lane & 15, fchunk = lane >> 4;
     const int fsw = (fchunk ^ ((frow >> 2) & 3)) << 4;
-    const int a_off = (wm * WTM + frow) * PROWB + fsw;
+    const int a_off = (ROLE * WTM + frow) * PROWB + fsw;          // wm == ROLE
     const int b_off = P_A_SLOT + (wn * WTN + frow) * PROWB + fsw;
 
-    auto wait_next = [&]() {                  // this wave's pieces of the NEXT step have landed; two steps stay in flight
-        if constexpr (NPB == NPA) pp_wait_vm<2 * NPA>();
-        else {
-            if (wm == 0) pp_wait_vm<2 * NPB>();
-            else pp_wait_vm<2 * NPA>();
-        }
-    };
+    // this wave's pieces of all but the newest 2 / 1 issued steps have landed
+    auto wait_keep2 = [&]() { pp_wait_vm<2 * NPM>(); };
+    auto wait_keep1 = [&]() { pp_wait_vm<NPM>(); };
 
-    issue(0);
-    issue(1);
-    issue(2);
-    wait_next();                              // step 0
+    if constexpr (PROF) prof_loop0 = __builtin_readcyclecounter();
+    const unsigned m0_keep = pp_m0_take();
+#pragma unroll 1
+    for (int s = 0; s < 3; ++s) {
+        prep(s);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) piece_now(q);
+    }
+    wait_keep2();                             // step 0
     pp_barrier();
-    if (wm == 1) pp_barrier();                // group 1 starts one interval late
+    if constexpr (ROLE == 1) pp_barrier();    // group 1 starts one interval late
 
     const int SQ = SEQ ? p.splitk_seq : 1;
     int sl_idx = 0;
@@ -265,23 +298,42 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
 
     // One copy of the step body: the slot offset is a run-time scalar (two v_add per step) rather than four unrolled copies --
     // the SEQ fold below would otherwise be inlined into each of them.
+    unsigned long long t_l = 0, t_b1 = 0, t_m = 0, t_b2 = 0, t_rd = 0, t_prep = 0;
     auto step = [&](int k) {
         V8 xf[MF], wf[NF];
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, ca = 0, cb = 0;
+        if constexpr (PROF) c0 = __builtin_readcyclecounter();
         const unsigned char* sp = smem + (k & 3) * SLOT;
+        // ---- L(k): fragments of step k; addresses of step k + 3; this wave's pieces of step k + 1 have landed ----
 #pragma unroll
         for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const V8*>(sp + b_off + j * 1024);
 #pragma unroll
         for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const V8*>(sp + a_off + i * 1024);
-        issue(k + 3);
-        wait_next();
+        if constexpr (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ca = __builtin_readcyclecounter(); }
+        prep(k + 3);
+        if constexpr (PROF) cb = __builtin_readcyclecounter();
+        wait_keep1();                         // in flight: steps k + 1 (issued in M(k-2)) and k + 2 (M(k-1)) -> k + 2 may stay
+        if constexpr (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c1 = __builtin_readcyclecounter(); }
         pp_barrier_lds();
+        if constexpr (PROF) c2 = __builtin_readcyclecounter();
+        // ---- M(k): 8 MFMAs per weight fragment; one LDS-DMA piece of step k + 3 goes out behind each group, its M0 one MFMA earlier ----
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < NF; ++j)
+        for (int j = 0; j < NF; ++j) {
 #pragma unroll
-            for (int i = 0; i < MF; ++i) PMfma<Tag>::run(acc[j][i], wf[j], xf[i]);
+            for (int i = 0; i < MF; ++i) {
+                PMfma<Tag>::run(acc[j][i], wf[j], xf[i]);
+                if (i == MF - 2) piece_aim(j);
+            }
+            piece_fire(j);
+        }
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (PROF) c3 = __builtin_readcyclecounter();
         pp_barrier();
+        if constexpr (PROF) {
+            const unsigned long long c4 = __builtin_readcyclecounter();
+            t_l += c1 - c0; t_b1 += c2 - c1; t_m += c3 - c2; t_b2 += c4 - c3; t_rd += ca - c0; t_prep += cb - ca;
+        }
         if constexpr (SEQ) {
             // sequential split-K emulation (GemmParams::splitk_seq): at a slice boundary the accumulators are folded into lane-private
             // 16-byte slots of a block-private fp32 running total.  The fold's loads / stores are the compiler's: drain the DMA queue
@@ -315,18 +367,46 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
 
 #pragma unroll 1
     for (int k = 0; k < nsteps; ++k) step(k);
-    if (wm == 0) pp_barrier();                // pairs with group 1's last barrier
+    pp_m0_give(m0_keep);
+    if constexpr (ROLE == 0) pp_barrier();    // pairs with group 1's last barrier
+    if constexpr (PROF) {
+        prof_v[0] = t_l; prof_v[1] = t_b1; prof_v[2] = t_m; prof_v[3] = t_b2; prof_v[4] = t_rd; prof_v[5] = t_prep;
+        prof_v[6] = prof_loop0 - prof_start;
+        prof_end_loop = __builtin_readcyclecounter();
+    }
+    };  // run
+    if (wm == 0) run(PInt<0>());
+    else run(PInt<1>());
     pp_wait_vm<0>();                          // the zero-fill pieces of the steps past the end
     pp_barrier();
     pp_mfma_settle();
-
     big_tile_epilogue<Tag, BN2>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
+    if constexpr (PROF) {
+        if (g_pp_prof && lane == 0) {
+            __builtin_amdgcn_s_waitcnt(0);     // the epilogue's stores have left the wave (vmcnt / lgkmcnt / expcnt all zero)
+            prof_v[7] = __builtin_readcyclecounter() - prof_end_loop;
+            unsigned long long* o = g_pp_prof + ((size_t)blockIdx.x * 8 + wid) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = prof_v[i];
+        }
+    }
 }
 
 int pp_bn(int N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : 0); }
 
+unsigned long long* g_pp_prof_host = nullptr;
+
 template <class Tag, int MODE, bool SEQ, int BN2>
 int launch_pp3(const GemmParams& p, hipStream_t s) {
+    if constexpr (std::is_same<Tag, F16Tag>::value && !SEQ && BN2 == 320) {
+        if (g_pp_prof_host) {
+            MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pp<Tag, MODE, SEQ, BN2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pp_smem(BN2)));
+            const unsigned grid = (unsigned)mve_cdiv(p.M, PBM) * (unsigned)mve_cdiv(p.N, BN2) * (unsigned)(p.splitk > 1 ? p.splitk : 1);
+            k_gemm_pp<Tag, MODE, SEQ, BN2, true><<<grid, PNTH, pp_smem(BN2), s>>>(p);
+            MVE_LAUNCH_CHECK();
+            return MVE_OK;
+        }
+    }
     static bool configured[64] = {};
     int dev = 0;
     MVE_HIP(hipGetDevice(&dev));
@@ -365,6 +445,14 @@ bool pp_eligible(int mode, const GemmParams& p) {
 }
 
 }  // namespace
+
+// development aid: with a device buffer of 32 x (number of blocks) uint64 set, fp16 320-wide launches run the instrumented kernel and
+// every wave writes its shader-clock sums {L work, wait at the L barrier, M work, wait at the M barrier}; nullptr turns it off
+extern "C" MVE_API int mve_gemm_pp_profile(void* buf) {
+    g_pp_prof_host = reinterpret_cast<unsigned long long*>(buf);
+    MVE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_prof), &g_pp_prof_host, sizeof(g_pp_prof_host)));
+    return MVE_OK;
+}
 
 // ping-pong main loop + epilogue (or split-K partials; the caller runs the reducer).  Returns 1 when the problem is not eligible
 // (the caller falls back to the two-stage kernel), MVE_OK after a launch, < 0 on error.
