@@ -324,7 +324,7 @@ def main():
         dom = max(('conv3x3', 'linear', 'attention'), key=lambda k: breakdown[k]['ms'])
         b = breakdown[dom]
         achieved = b['flops'] / (b['ms'] * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel={'conv3x3': 'k_gemm_big<MODE=1> implicit-GEMM conv3x3 (256x320 tile)', 'linear': 'k_gemm_big<MODE=0> (256x320 tile)',
+        roof = dict(bound='mfma', kernel={'conv3x3': 'k_gemm_pp<MODE=1> implicit-GEMM conv3x3 (256x320 tile, ping-pong loop)', 'linear': 'k_gemm_pp<MODE=0> (256x320 tile, ping-pong loop; the K = 320 level is HBM-bound)',
                                           'attention': 'k_attention'}[dom],
                     achieved=round(achieved, 1), peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(achieved / PEAK_TFLOPS_F16, 4),
                     traffic=pmc_traffic(dom), traffic_source='static: read from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '

@@ -7,6 +7,16 @@
 
 namespace {
 
+// Workgroup barrier for LDS hand-over only: LDS traffic of this wave has retired (lgkmcnt), global stores may still be in flight.
+// __syncthreads() carries a release fence: hipcc drains vmcnt to 0 in front of it, so every pass of the epilogue waited for the write
+// acknowledgements of its own 40 KiB of stores (~18 k cycles per tile for four passes, tools/pp_profile.py) although nothing after the
+// barrier depends on them.
+__device__ __forceinline__ void big_lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <class Tag, int BN2>
 __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&acc)[BN2 / 64][8], unsigned char* smem, int m0, int n0,
                                                   int kslice, int tid, int lane, int wm, int wn) {
@@ -36,7 +46,7 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
                 *reinterpret_cast<T2*>(Hs + (wm * WTM + i * 16 + (lane & 15)) * HS_LD + (c >> 1)) = o;
             }
         }
-        __syncthreads();
+        big_lds_barrier();
         constexpr int HCH = BN2 / 16;                   // 20 chunks of 8 output columns per row
         for (int task = tid; task < BM2 * HCH; task += NTH) {
             const int r = task / HCH, ch = task - r * HCH;
@@ -48,42 +58,107 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
     }
 
     // ---- epilogue: four 64-row passes through an fp32 LDS tile, 16-byte row-segment stores ----------------------------
+    // A thread owns ONE 8-column chunk (ch) for the whole epilogue and walks rows r0, r0 + RPI, ... of each pass: bias is loaded
+    // once, the per-image row vector once per pass, and the residual chunk of (pass + 1, k) is requested as soon as the registers of
+    // (pass, k) are free -- a full pass before its use.  On gfx9 a wave's vector loads and stores retire in issue order, so a load
+    // issued behind a store cannot return before that store is acknowledged (~2 k cycles): with the loads of a chunk issued right
+    // before its arithmetic every chunk waited out the previous chunk's store (60-70 k cycles per tile with bias + residual against
+    // 58 k for the whole K = 1280 loop, tools/pp_profile.py).
     float* Cs = reinterpret_cast<float*>(smem);
     constexpr int CHUNKS = BN2 / 8;
-    constexpr int TASKS = 64 * CHUNKS;
+    constexpr int RPI = NTH / CHUNKS;                   // rows per iteration: 12 (BN2 = 320, 480 of 512 threads busy) or 16
+    constexpr int NIT = (64 + RPI - 1) / RPI;           // 6 | 4
+    constexpr int NPASS = BM2 / 64;
+    // Every lane runs every chunk on clamped indices and only the store is predicated: a divergent region around a chunk makes hipcc
+    // copy the prefetched registers at its join, which needs their loads complete -- vmcnt(0) behind the chunk's own store again.
+    const bool partial = p.splitk > 1;
+    const int ch = tid % CHUNKS, r0 = tid / CHUNKS;
+    const bool active = r0 < RPI;
+    const int r0c = active ? r0 : RPI - 1;
+    const int n = n0 + ch * 8;
+    const int nc = n < p.N ? n : p.N - 8;
+    const bool col_ok = active && n < p.N;
+    const bool rv_pass = p.rowvec && p.rows_per_vec % 64 == 0;     // a 64-row pass lies inside one image (m0 is a multiple of 256)
+    f32x4 b0 = {}, b1 = {}, rv0 = {}, rv1 = {};
+    V8 rr[NIT];
 #pragma unroll
-    for (int pass = 0; pass < BM2 / 64; ++pass) {
+    for (int k = 0; k < NIT; ++k) rr[k] = V8{};
+    auto row_c = [&](int pass, int k) {                 // clamped global row of (pass, k)
+        const int r = r0c + RPI * k;
+        const int m = m0 + pass * 64 + (r < 64 ? r : 63);
+        return m < p.M ? m : p.M - 1;
+    };
+    auto load_rv = [&](int m, f32x4& a, f32x4& b) {
+        const float* rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.ldrv + nc;
+        a = *reinterpret_cast<const f32x4*>(rv);
+        b = *reinterpret_cast<const f32x4*>(rv + 4);
+    };
+    if (!partial) {
+        if (p.bias) {
+            b0 = *reinterpret_cast<const f32x4*>(p.bias + nc);
+            b1 = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
+        }
+        if (rv_pass) load_rv(m0 < p.M ? m0 : p.M - 1, rv0, rv1);
+        if (p.residual) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) rr[k] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)row_c(0, k) * p.ldr + nc);
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
         if (wm == pass / 2) {
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int i = (pass & 1) * 4 + i4;
                     const int r = i4 * 16 + (lane & 15);
                     const int c = wn * WTN + j * 16 + (lane >> 4) * 4;
                     *reinterpret_cast<f32x4*>(Cs + r * CS_LD + c) = acc[j][i];
                 }
         }
-        __syncthreads();
-        for (int task = tid; task < TASKS; task += NTH) {
-            const int r = task / CHUNKS, ch = task - r * CHUNKS;
-            const int m = m0 + pass * 64 + r, n = n0 + ch * 8;
-            if (m >= p.M || n >= p.N) continue;
+        big_lds_barrier();
+        const f32x4 crv0 = rv0, crv1 = rv1;
+        if (!partial && rv_pass && pass + 1 < NPASS) {
+            const int m = m0 + (pass + 1) * 64;
+            load_rv(m < p.M ? m : p.M - 1, rv0, rv1);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int r = r0c + RPI * k;
+            const int rcl = r < 64 ? r : 63;
+            const int m = m0 + pass * 64 + rcl;
+            const int mc = m < p.M ? m : p.M - 1;
+            const bool ok = col_ok && r < 64 && m < p.M;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + rcl * CS_LD + ch * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + rcl * CS_LD + ch * 8 + 4);
+            const V8 res = rr[k];
+            if (!partial && p.residual && pass + 1 < NPASS)
+                rr[k] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)row_c(pass + 1, k) * p.ldr + nc);
             float v[8];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-            if (p.splitk > 1) {
-                float* pp = p.partial + ((size_t)kslice * p.M + m) * p.N + n;
-                *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(pp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            if (partial) {
+                float* pp = p.partial + ((size_t)kslice * p.M + mc) * p.N + nc;
+                if (ok) {
+                    *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(pp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
                 continue;
             }
-            gemm_epilogue_store<Tag>(p, m, n, v);
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            }
+            if (p.rowvec) {
+                f32x4 a = crv0, b = crv1;
+                if (!rv_pass) load_rv(mc, a, b);         // general case: one row vector per row
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+            }
+            gemm_epilogue_tail<Tag>(p, mc, nc, v, res, ok);
         }
-        __syncthreads();
+        big_lds_barrier();
     }
 }
 

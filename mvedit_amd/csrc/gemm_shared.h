@@ -79,6 +79,40 @@ __device__ __forceinline__ const T* conv_src(const GemmParams& p, int cb, int cy
 }
 
 
+// Last part of the fused epilogue with the residual chunk already loaded (the 256-row tiles request it one pass ahead, see
+// gemm_big_epilogue.h): residual, output scale, storage-dtype (or fp32) store.  One definition, contraction off, so that every kernel
+// and the split-K reducer round identically.
+template <class Tag>
+__device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, int n, float (&v)[8], const typename Tag::V8& rr, bool ok = true) {
+#pragma clang fp contract(off)
+    typedef typename Tag::T T;
+    typedef typename Tag::V8 V8;
+    if (p.residual && !p.res_after_scale) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+    if (p.residual && p.res_after_scale) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
+    }
+    // (`ok` guards only the stores: callers that keep loads in flight across chunks must not wrap the arithmetic in divergent control flow)
+    if (p.out_f32) {
+        float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+        if (ok) {
+            *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    } else {
+        V8 pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
+        T* op = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n;
+        if (ok) *reinterpret_cast<V8*>(op) = pk;
+    }
+}
+
 // The fused epilogue on 8 consecutive output columns (n % 8 == 0) of row m: bias, per-image row vector (time embedding),
 // GEGLU, residual, output scale, storage-dtype (or fp32) store.  Shared by the GEMM kernels and the split-K reducer.
 template <class Tag>
@@ -106,28 +140,9 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, 
         *reinterpret_cast<T4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + (n >> 1)) = pk;
         return;
     }
-    if (p.residual && !p.res_after_scale) {
-        const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-    if (p.residual && p.res_after_scale) {
-        const V8 rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
-    }
-    if (p.out_f32) {
-        float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
-        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    } else {
-        V8 pk;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
-        *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n) = pk;
-    }
+    V8 rr = {};
+    if (p.residual) rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
+    gemm_epilogue_tail<Tag>(p, m, n, v, rr);
 }
 
 }  // namespace

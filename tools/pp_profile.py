@@ -52,3 +52,8 @@ for (M, N, K, fl) in [(B * 4096, 2560, 320, 1), (B * 4096, 320, 1280, 0), (B * 1
     w = torch.randn(N, K, device=dev, dtype=dt) * K ** -0.5
     f = lambda: ops.gemm(a, w, flags=ops.GEGLU if fl else 0, rows_per_image=0)
     report(f'gemm M={M} N={N} K={K}', f, (M // 256) * (N // 320), K // 32, 2 * M * N * K)
+    if not fl:      # the same launch with the epilogue's loads: bias + residual (attn.to_out / ff.out of the UNet)
+        bias = torch.randn(N, device=dev, dtype=torch.float32)
+        res = torch.randn(M, N, device=dev, dtype=dt)
+        f = lambda: ops.gemm(a, w, bias=bias, residual=res, rows_per_image=0)
+        report(f'gemm M={M} N={N} K={K} +bias+residual', f, (M // 256) * (N // 320), K // 32, 2 * M * N * K)
