@@ -88,6 +88,41 @@ def pmc_traffic(cls):
         return None
 
 
+def clock_probe(dev):
+    """Shader clock the chip sustains inside the dominant conv kernel (DVFS: the MFMA-heavy kernels run far below the 2.4 GHz the
+    2.5 PFLOP/s peak is quoted at).  One instrumented launch of the ping-pong conv kernel (mve_gemm_pp_profile: every wave records
+    s_memtime at kernel entry / exit) on a UNet level-1 shape; clock = cycles of the longest wave / HIP-event wall time."""
+    import ctypes
+    from mvedit_amd import ops, _lib
+    prof = _lib.raw('mve_gemm_pp_profile')
+    prof.argtypes = [ctypes.c_void_p]
+    B, H, C = 64, 32, 640
+    x = torch.randn(B * H * H, C, device=dev, dtype=torch.float16)
+    w = torch.randn(C, C // 64, 3, 3, 64, device=dev, dtype=torch.float16) * (9 * C) ** -0.5
+    f = lambda: ops.conv3x3(x, w, B, H, H, flags=ops.W_CHUNK64, splitk=False)
+    nblocks = (B * H * H // 256) * (C // 320)
+    buf = torch.zeros(nblocks * 64, dtype=torch.int64, device=dev)
+    try:
+        prof(ctypes.c_void_p(buf.data_ptr()))
+        f()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            f()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 3
+    finally:
+        prof(None)
+    v = buf.view(nblocks, 8, 8).double().cpu()
+    per_tile = float((v[:, :, :4].sum(-1) + v[:, :, 6] + v[:, :, 7]).mean())          # prologue + K loop + epilogue cycles of a tile
+    tiles_per_cu = (nblocks + 255) // 256
+    ghz = per_tile * tiles_per_cu / (ms * 1e-3) / 1e9
+    return dict(shader_ghz=round(ghz, 3), quoted_ghz=2.4, peak_at_clock=round(PEAK_TFLOPS_F16 * ghz / 2.4, 1),
+                probe='k_gemm_pp<MODE=1>, 64 x 32 x 32 x 640 -> 640 conv, s_memtime per wave / HIP-event wall time (lower bound: launch gaps count as cycles)')
+
+
 def surround_poses(n, radius=3.7, elev=0.2):
     """n look-at c2w matrices (OpenCV convention: x right, y down, z forward) on a circle, as the reference's camera rig
     (lib/apis/adapter3d.py:991-996: distance 3.7, fov 30 degrees)."""
@@ -350,6 +385,13 @@ def main():
             'rccl_world': dist.get_world_size() if use_dist else 1,
             'roofline': roof,
         }
+        if world == 1 and roof is not None:
+            try:
+                clk = clock_probe(dev)
+                clk['frac_at_clock'] = round(roof['achieved'] / clk['peak_at_clock'], 4)
+                roof['clock'] = clk
+            except Exception as e:      # informational only
+                roof['clock'] = {'error': repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         if world == 1 and not args.no_secondary:

@@ -348,47 +348,65 @@ int gemm_big_min_blocks() {
     return g_big_min_blocks;
 }
 
-// The big-tile kernel exists 320 columns wide (every UNet width) and 256 wide (the VAE's 256 / 512-channel convs; no split-K
-// variants).  Any other N -- 128 at image resolution, 8 for conv_out -- would leave most of a big tile dead and takes the
-// 128 x {64,128,160} kernel, whose results are bit-identical.
 // The 256-row tile has two main loops with bit-identical results: the ping-pong schedule (gemm_pp.hip) wherever it is eligible,
 // else the two-stage loop (gemm_big.hip).  mve_gemm_tune bit 27 / MVE_GEMM_PP=0 turn the former off (A/B).
 int g_gemm_pp = -1;
-int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
+bool gemm_pp_on() {
     if (g_gemm_pp < 0) {
         const char* e = getenv("MVE_GEMM_PP");
         g_gemm_pp = e ? atoi(e) : 1;
     }
-    if (g_gemm_pp) {
+    return g_gemm_pp != 0;
+}
+// MVE_OK after a launch, 1 when neither loop takes the problem (the caller falls back to the 128-row kernel), < 0 on error
+int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
+    if (gemm_pp_on()) {
         const int rc = mve_gemm_pp_launch(dtype, mode, q, s);
         if (rc <= 0) return rc;
     }
+    if (mve_gemm_big_blocks(q->M, q->N, q->splitk) <= 0) return 1;
     return mve_gemm_big_launch(dtype, mode, q, s);
 }
 
-bool big_tile_fits(int N, int splitk) { return N % 320 == 0 || (N % 256 == 0 && splitk <= 1); }
+// Width of the 256-row tile for N columns (0: none fits): 320 (every UNet width), 256 (the VAE's 256 / 512-channel convs; no
+// split-K variants), 128 (the VAE's 128-channel convs at image resolution; ping-pong loop only, no split-K).  Any other N -- 8 for
+// conv_out -- would leave most of a tile dead and takes the 128 x {64,128,160} kernel, whose results are bit-identical.
+int tile256_bn(int N, int splitk) {
+    if (N % 320 == 0) return 320;
+    if (splitk > 1) return 0;
+    if (N % 256 == 0) return 256;
+    if (N % 128 == 0 && gemm_pp_on()) return 128;
+    return 0;
+}
+long long tile256_blocks(int M, int N, int splitk) {
+    const int bn = tile256_bn(N, splitk);
+    if (bn == 0 || M < 64) return 0;
+    return (long long)mve_cdiv(M, 256) * (N / bn) * (splitk > 1 ? splitk : 1);
+}
 
 template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
-    if (!big_tile_fits(p.N, p.splitk)) return launch_v<Tag, MODE>(p, s);
+    if (tile256_bn(p.N, p.splitk) == 0) return launch_v<Tag, MODE>(p, s);
     // enough 256 x 320 tiles to fill the chip WITHOUT cutting K: one block per tile walks the slices one after the other and
     // reproduces the split-K rounding exactly (GemmParams::splitk_seq) -- no partial tiles, no reducer launch
-    if (gemm_big_min_blocks() > 0 && p.splitk > 1 && p.N % 320 == 0 && g_seq_splitk && mve_gemm_big_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&
-        (size_t)mve_gemm_big_blocks(p.M, p.N, 1) * 256 * 320 <= (size_t)p.splitk * p.M * p.N) {
+    if (gemm_big_min_blocks() > 0 && p.splitk > 1 && p.N % 320 == 0 && g_seq_splitk && tile256_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&
+        (size_t)tile256_blocks(p.M, p.N, 1) * 256 * 320 <= (size_t)p.splitk * p.M * p.N) {
         GemmParams q = p;
         q.splitk_seq = p.splitk;
         q.splitk = 1;
         return launch_tile256(Tag::dtype, MODE, &q, s);
     }
-    if (gemm_big_min_blocks() > 0 && mve_gemm_big_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
+    if (gemm_big_min_blocks() > 0 && tile256_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
         GemmParams q = p;
         const int rc = launch_tile256(Tag::dtype, MODE, &q, s);
-        if (rc) return rc;
-        if (p.splitk > 1) {
-            k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
-            MVE_LAUNCH_CHECK();
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            if (p.splitk > 1) {
+                k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
+                MVE_LAUNCH_CHECK();
+            }
+            return MVE_OK;
         }
-        return MVE_OK;
     }
     return launch_v<Tag, MODE>(p, s);
 }

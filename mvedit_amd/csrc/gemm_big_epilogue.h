@@ -17,13 +17,15 @@ __device__ __forceinline__ void big_lds_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <class Tag, int BN2>
-__device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&acc)[BN2 / 64][8], unsigned char* smem, int m0, int n0,
-                                                  int kslice, int tid, int lane, int wm, int wn) {
+// WAVES_N: waves along N (4: 2 x 4 arrangement, wave tile 128 x BN2/4;  2: 4 x 2 arrangement, wave tile 64 x BN2/2)
+template <class Tag, int BN2, int WAVES_N = 4>
+__device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&acc)[BN2 / WAVES_N / 16][256 / (8 / WAVES_N) / 16], unsigned char* smem,
+                                                  int m0, int n0, int kslice, int tid, int lane, int wm, int wn) {
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
-    constexpr int BM2 = 256, NTH = 512, MF = 8, WTM = 128;
-    constexpr int WTN = BN2 / 4, NF = WTN / 16;
+    constexpr int BM2 = 256, NTH = 512, WTM = 256 / (8 / WAVES_N), MF = WTM / 16;
+    constexpr int WTN = BN2 / WAVES_N, NF = WTN / 16;
+    constexpr int PPW = WTM / 64;                       // 64-row passes per wave row
     constexpr int CS_LD = BN2 + 4;
     // ---- GEGLU epilogue: out[m][i] = (v[2i] + b[2i]) * gelu(v[2i+1] + b[2i+1]).  A lane owns 4 consecutive n = two
     // (value, gate) pairs of one row, so the activation is evaluated on the accumulators; only the 16-bit results (half the
@@ -106,12 +108,12 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-        if (wm == pass / 2) {
+        if (wm == pass / PPW) {
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
-                    const int i = (pass & 1) * 4 + i4;
+                    const int i = (pass % PPW) * 4 + i4;
                     const int r = i4 * 16 + (lane & 15);
                     const int c = wn * WTN + j * 16 + (lane >> 4) * 4;
                     *reinterpret_cast<f32x4*>(Cs + r * CS_LD + c) = acc[j][i];

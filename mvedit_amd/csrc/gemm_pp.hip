@@ -43,10 +43,10 @@ constexpr int PBM = 256, PNTH = 512;
 constexpr int PROWB = 64;                               // bytes per row and K step
 constexpr int PNSLOT = 4;
 constexpr int P_A_SLOT = PBM * PROWB;                   // 16 KiB
-constexpr unsigned P_OOB = 0xFFFFFFF0u, P_NUMREC = 0xFFFFFF00u;
+constexpr unsigned P_NUMREC = 0xFFFFFF00u;              // resource size: every valid offset is below it, the all-ones halo offset above
 constexpr int pp_slot_bytes(int bn) { return P_A_SLOT + bn * PROWB; }
 constexpr int pp_smem(int bn) { return PNSLOT * pp_slot_bytes(bn); }
-static_assert(64 * (320 + 4) * 4 <= pp_smem(320) && 64 * (256 + 4) * 4 <= pp_smem(256), "epilogue staging must fit");
+static_assert(64 * (320 + 4) * 4 <= pp_smem(320) && 64 * (256 + 4) * 4 <= pp_smem(256) && 64 * (128 + 4) * 4 <= pp_smem(128), "epilogue staging must fit");
 
 __device__ __forceinline__ i32x4 pp_rsrc(unsigned long long base, bool live) {
     i32x4 r;          // readfirstlane: the operands are wave-uniform by construction; this pins them to SGPRs for the asm below
@@ -113,17 +113,20 @@ template <int V> struct PInt { static constexpr int value = V; };
 template <class Tag, int MODE, bool SEQ, int BN2, bool PROF = false>        // MODE 1: slab-major (chunk64) conv only
 __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     typedef typename Tag::V8 V8;
-    typedef typename Tag::T T;
-    constexpr int MF = 8, WTM = 128;
-    constexpr int WTN = BN2 / 4, NF = WTN / 16;                // 80 -> 5 fragments, 64 -> 4
-    constexpr int NPB = BN2 / 64;                              // weight pieces per group-0 wave and step: 5 | 4
+    // BN2 = 320 | 256: waves 2 (M) x 4 (N), wave tile 128 x {80, 64};  BN2 = 128 (the 128-channel convolutions of the VAE at image
+    // resolution): waves 4 x 2, wave tile 64 x 64 -- 16 MFMAs against 8 fragment reads per step, LDS-read bound (~3/4 of the MFMA rate)
+    constexpr int WAVES_N = BN2 == 128 ? 2 : 4, WAVES_M = 8 / WAVES_N;
+    constexpr int WTM = PBM / WAVES_M, MF = WTM / 16;
+    constexpr int WTN = BN2 / WAVES_N, NF = WTN / 16;
+    constexpr int NPB = BN2 / 64;                              // weight pieces per group-0 wave and step: 5 | 4 | 2
     constexpr int NPA = 4;                                     // activation pieces per group-1 wave and step
     constexpr int SLOT = pp_slot_bytes(BN2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;                     // wm doubles as the group / role index
+    const int role = wid >> 2, widx = wid & 3;                 // wave group = DMA role; index of the wave inside its group
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
 
     const int tiles_n = (p.N + BN2 - 1) / BN2;
     const int tiles_m = (p.M + PBM - 1) / PBM;
@@ -167,17 +170,17 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     if constexpr (ROLE == 0) {
 #pragma unroll
         for (int q = 0; q < NPB; ++q) {
-            int n = n0 + (wn * NPB + q) * 16 + prow;
+            int n = n0 + (widx * NPB + q) * 16 + prow;
             n = n < p.N ? n : p.N - 1;
             vo[q] = (unsigned)n * (unsigned)p.ldw * 2u + c16;
         }
         op_base = (unsigned long long)p.W + (unsigned long long)kt_begin * (BK * 2);
-        dst0 = smem_base + P_A_SLOT + wn * NPB * 1024;
+        dst0 = smem_base + P_A_SLOT + widx * NPB * 1024;
     } else {
         const int hw = p.g.Ho * p.g.Wo;
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
-            int m = m0 + (wn * NPA + q) * 16 + prow;
+            int m = m0 + (widx * NPA + q) * 16 + prow;
             m = m < p.M ? m : p.M - 1;
             if constexpr (MODE == 0) vo[q] = (unsigned)m * (unsigned)p.lda * 2u + c16;
             else {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
             }
         }
         op_base = (unsigned long long)p.A + (unsigned long long)kt_begin * (BK * 2);
-        dst0 = smem_base + wn * NPA * 1024;
+        dst0 = smem_base + widx * NPA * 1024;
     }
     unsigned long long conv_base = 0;         // resource base of the current (tap, slab), first 32-channel half
     // conv sources as opaque scalars: left to itself hipcc turns `second ? p.g.C2 : p.g.C1` into a select of kernarg ADDRESSES and an
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     // fragment read offsets inside a slot (lane constants): row r = ... + frow, stored chunk = fchunk ^ ((r >> 2) & 3)
     const int frow = lane & 15, fchunk = lane >> 4;
     const int fsw = (fchunk ^ ((frow >> 2) & 3)) << 4;
-    const int a_off = (ROLE * WTM + frow) * PROWB + fsw;          // wm == ROLE
+    const int a_off = (wm * WTM + frow) * PROWB + fsw;
     const int b_off = P_A_SLOT + (wn * WTN + frow) * PROWB + fsw;
 
     // this wave's pieces of all but the newest 2 / 1 issued steps have landed
@@ -375,12 +378,12 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
         prof_end_loop = __builtin_readcyclecounter();
     }
     };  // run
-    if (wm == 0) run(PInt<0>());
+    if (role == 0) run(PInt<0>());
     else run(PInt<1>());
     pp_wait_vm<0>();                          // the zero-fill pieces of the steps past the end
     pp_barrier();
     pp_mfma_settle();
-    big_tile_epilogue<Tag, BN2>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
+    big_tile_epilogue<Tag, BN2, WAVES_N>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
     if constexpr (PROF) {
         if (g_pp_prof && lane == 0) {
             __builtin_amdgcn_s_waitcnt(0);     // the epilogue's stores have left the wave (vmcnt / lgkmcnt / expcnt all zero)
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     }
 }
 
-int pp_bn(int N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : 0); }
+int pp_bn(int N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
 
 unsigned long long* g_pp_prof_host = nullptr;
 
@@ -423,6 +426,7 @@ int launch_pp3(const GemmParams& p, hipStream_t s) {
 template <class Tag, int MODE>
 int launch_pp(const GemmParams& p, hipStream_t s) {
     if (pp_bn(p.N) == 256) return launch_pp3<Tag, MODE, false, 256>(p, s);
+    if (pp_bn(p.N) == 128) return launch_pp3<Tag, MODE, false, 128>(p, s);
     return p.splitk_seq > 1 ? launch_pp3<Tag, MODE, true, 320>(p, s) : launch_pp3<Tag, MODE, false, 320>(p, s);
 }
 
@@ -432,7 +436,7 @@ bool pp_fits(unsigned long long bytes) { return bytes + 65536ull < (unsigned lon
 bool pp_eligible(int mode, const GemmParams& p) {
     const int bn = pp_bn(p.N);
     if (bn == 0 || p.M < 64 || p.K % BK != 0) return false;
-    if (bn == 256 && (p.splitk > 1 || p.splitk_seq > 1)) return false;
+    if (bn != 320 && (p.splitk > 1 || p.splitk_seq > 1)) return false;
     if (!pp_fits((unsigned long long)p.N * p.ldw * 2)) return false;
     if (mode == 0) return pp_fits((unsigned long long)p.M * p.lda * 2);
     if (!p.g.chunk64) return false;

@@ -91,8 +91,10 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
     }
+    if (p.out_scale != 1.0f) {           // (x * 1 == x bit for bit: the test only saves the multiplies)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+    }
     if (p.residual && p.res_after_scale) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);

@@ -582,7 +582,8 @@ def test_pingpong_main_loop_is_bit_identical_and_race_free(lib, dtype):
     PP, BIG = 1, 1 | (1 << 27)
     try:
         for (M, N, K, rpi, fl) in [(70000, 320, 320, 0, 0), (33000, 960, 64, 0, 0), (20000, 2560, 320, 0, ops.GEGLU), (16384, 320, 1280, 0, 0),
-                                   (9000, 1280, 5120, 0, 0), (1024, 1280, 11520, 64, 0), (777, 512, 640, 0, 0), (4096, 256, 4608, 0, 0)]:
+                                   (9000, 1280, 5120, 0, 0), (1024, 1280, 11520, 64, 0), (777, 512, 640, 0, 0), (4096, 256, 4608, 0, 0),
+                                   (20000, 128, 1152, 0, 0), (5000, 384, 640, 0, 0)]:      # 128-wide tile (4 x 2 waves)
             a, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
             bias = rnd((N,), torch.float32, 3).cuda()
             res = None if fl else rnd((M, N), dtype, 4).cuda()
@@ -594,7 +595,8 @@ def test_pingpong_main_loop_is_bit_identical_and_race_free(lib, dtype):
                 assert torch.equal(out, ref), (M, N, K, rep, int((out != ref).sum()))
         for (B, H, C1, C2, Cout, stride, ups) in [(24, 32, 320, 0, 320, 1, False), (8, 32, 640, 320, 640, 1, False), (6, 32, 320, 0, 640, 2, False),
                                                   (4, 16, 640, 0, 640, 1, True), (16, 8, 1280, 1280, 1280, 1, False), (2, 64, 128, 0, 256, 1, False),
-                                                  (3, 24, 192, 64, 512, 1, True)]:
+                                                  (3, 24, 192, 64, 512, 1, True),
+                                                  (2, 64, 128, 0, 128, 1, False), (2, 32, 256, 0, 128, 1, True), (3, 48, 64, 64, 128, 2, False)]:
             x1 = to_nhwc(rnd((B, C1, H, H), dtype, 1)).cuda()
             x2 = to_nhwc(rnd((B, C2, H, H), dtype, 2)).cuda() if C2 else None
             wt = rnd((Cout, C1 + C2, 3, 3), dtype, 3, (9 * (C1 + C2)) ** -0.5)
