@@ -14,3 +14,5 @@ cd $REPO/gpurun_out && find . -name "*.csv" | head -30 && du -sh .
 # keep only per-kernel aggregates of the PMC passes (raw per-dispatch csv can be large)
 python $REPO/tools/summarize_prof.py $REPO/gpurun_out > $REPO/gpurun_out/prof_summary.txt 2>&1
 tail -60 $REPO/gpurun_out/prof_summary.txt
+# afterwards, in the repo: python tools/summarize_prof.py gpurun_out > profiles/rNN_rocprof_vK_summary.txt
+#                           python tools/make_pmc_traffic.py gpurun_out profiles/rNN_rocprof_vK_summary.txt > profiles/pmc_traffic.json
