@@ -63,10 +63,10 @@ __device__ __forceinline__ i32x4 pp_rsrc(unsigned long long base, bool live) {
 // s_mov m0 -> LDS-DMA hazard is covered by that MFMA; pp_piece_now carries its own s_nop for the prologue).
 __device__ __forceinline__ unsigned pp_m0_take() {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+    asm volatile("s_mov_b32 %0, m0 ; pp_kloop_begin (marker for tools/check_pp_isa.py)" : "=s"(keep));
     return keep;
 }
-__device__ __forceinline__ void pp_m0_give(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep)); }
+__device__ __forceinline__ void pp_m0_give(unsigned keep) { asm volatile("s_mov_b32 m0, %0 ; pp_kloop_end" ::"s"(keep)); }
 __device__ __forceinline__ void pp_set_m0(unsigned dst) { asm volatile("s_mov_b32 m0, %0" ::"s"(dst)); }
 __device__ __forceinline__ void pp_dma_m0(unsigned vo, i32x4 rsrc) {
     asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(rsrc) : "memory");
