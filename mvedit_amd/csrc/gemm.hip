@@ -364,7 +364,7 @@ int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
         const int rc = mve_gemm_pp_launch(dtype, mode, q, s);
         if (rc <= 0) return rc;
     }
-    if (mve_gemm_big_blocks(q->M, q->N, q->splitk) <= 0) return 1;
+    if (q->tile_n == 160 || mve_gemm_big_blocks(q->M, q->N, q->splitk) <= 0) return 1;
     return mve_gemm_big_launch(dtype, mode, q, s);
 }
 
@@ -396,8 +396,12 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         q.splitk = 1;
         return launch_tile256(Tag::dtype, MODE, &q, s);
     }
-    if (gemm_big_min_blocks() > 0 && tile256_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks()) {
+    // small batches: 256 x 320 tiles would leave CUs without a block, 256 x 160 tiles (ping-pong loop only) still cover them
+    const bool narrow = gemm_big_min_blocks() > 0 && gemm_pp_on() && p.splitk <= 1 && p.N % 320 == 0 && p.M >= 64 &&
+                        tile256_blocks(p.M, p.N, 1) < gemm_big_min_blocks() && 2 * tile256_blocks(p.M, p.N, 1) >= gemm_big_min_blocks();
+    if (narrow || (gemm_big_min_blocks() > 0 && tile256_blocks(p.M, p.N, p.splitk) >= gemm_big_min_blocks())) {
         GemmParams q = p;
+        q.tile_n = narrow ? 160 : 0;
         const int rc = launch_tile256(Tag::dtype, MODE, &q, s);
         if (rc < 0) return rc;
         if (rc == 0) {

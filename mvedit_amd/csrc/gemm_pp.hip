@@ -45,8 +45,9 @@ constexpr int PNSLOT = 4;
 constexpr int P_A_SLOT = PBM * PROWB;                   // 16 KiB
 constexpr unsigned P_NUMREC = 0xFFFFFF00u;              // resource size: every valid offset is below it, the all-ones halo offset above
 constexpr int pp_slot_bytes(int bn) { return P_A_SLOT + bn * PROWB; }
-constexpr int pp_smem(int bn) { return PNSLOT * pp_slot_bytes(bn); }
-static_assert(64 * (320 + 4) * 4 <= pp_smem(320) && 64 * (256 + 4) * 4 <= pp_smem(256) && 64 * (128 + 4) * 4 <= pp_smem(128), "epilogue staging must fit");
+constexpr int pp_smem(int bn) { return PNSLOT * pp_slot_bytes(bn) + (bn == 160 ? 1024 : 0); }      // 160: + a 1 KiB dump for the filler piece
+static_assert(64 * (320 + 4) * 4 <= pp_smem(320) && 64 * (256 + 4) * 4 <= pp_smem(256) && 64 * (128 + 4) * 4 <= pp_smem(128) &&
+              64 * (160 + 4) * 4 <= pp_smem(160), "epilogue staging must fit");
 
 __device__ __forceinline__ i32x4 pp_rsrc(unsigned long long base, bool live) {
     i32x4 r;          // readfirstlane: the operands are wave-uniform by construction; this pins them to SGPRs for the asm below
@@ -115,10 +116,14 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     typedef typename Tag::V8 V8;
     // BN2 = 320 | 256: waves 2 (M) x 4 (N), wave tile 128 x {80, 64};  BN2 = 128 (the 128-channel convolutions of the VAE at image
     // resolution): waves 4 x 2, wave tile 64 x 64 -- 16 MFMAs against 8 fragment reads per step, LDS-read bound (~3/4 of the MFMA rate)
-    constexpr int WAVES_N = BN2 == 128 ? 2 : 4, WAVES_M = 8 / WAVES_N;
+    // BN2 = 160 (two tiles per 320 columns: small batches, where 256 x 320 tiles would leave CUs idle): waves 4 x 2, wave tile 64 x 80;
+    // its 10 weight pieces per step go 3 / 3 / 2 / 2 to the group-0 waves, the last two add a zero-fill piece into a dump area so that
+    // every wave of the group issues (and counts) three.
+    constexpr int WAVES_N = (BN2 == 128 || BN2 == 160) ? 2 : 4, WAVES_M = 8 / WAVES_N;
     constexpr int WTM = PBM / WAVES_M, MF = WTM / 16;
     constexpr int WTN = BN2 / WAVES_N, NF = WTN / 16;
-    constexpr int NPB = BN2 / 64;                              // weight pieces per group-0 wave and step: 5 | 4 | 2
+    constexpr int NPB_ALL = BN2 / 16, NPB_BASE = NPB_ALL / 4, NPB_REM = NPB_ALL % 4;
+    constexpr int NPB = NPB_BASE + (NPB_REM ? 1 : 0);          // weight pieces per group-0 wave and step: 5 | 4 | 2 | 3 (160: 3, 3, 2 + filler, 2 + filler)
     constexpr int NPA = 4;                                     // activation pieces per group-1 wave and step
     constexpr int SLOT = pp_slot_bytes(BN2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -168,14 +173,16 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     unsigned dst0;                            // LDS offset of this wave's first piece inside a slot
     const int conv_bias = p.g.Ws + 1;
     if constexpr (ROLE == 0) {
+        const int pstart = widx * NPB_BASE + (widx < NPB_REM ? widx : NPB_REM);      // first piece of this wave
 #pragma unroll
         for (int q = 0; q < NPB; ++q) {
-            int n = n0 + (widx * NPB + q) * 16 + prow;
+            int n = n0 + (pstart + q) * 16 + prow;
             n = n < p.N ? n : p.N - 1;
             vo[q] = (unsigned)n * (unsigned)p.ldw * 2u + c16;
         }
+        if (NPB_REM && widx >= NPB_REM) vo[NPB - 1] = 0xFFFFFFFFu;                    // filler piece: out of range, zeros
         op_base = (unsigned long long)p.W + (unsigned long long)kt_begin * (BK * 2);
-        dst0 = smem_base + P_A_SLOT + widx * NPB * 1024;
+        dst0 = smem_base + P_A_SLOT + pstart * 1024;
     } else {
         const int hw = p.g.Ho * p.g.Wo;
 #pragma unroll
@@ -213,12 +220,14 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     unsigned vrow[NPA] = {0u, 0u, 0u, 0u};    // conv rows: byte offset of the lane's chunk at the window origin for the current source
     i32x4 r_cur;                              // resource and LDS destination of the step being issued
     unsigned dst_cur;
+    unsigned dst_last = 0;                    // destination of piece NPB - 1: the dump area for a filler piece
 
     // address part of issuing step s (relative to kt_begin): scalar work, plus 4 x ~5 VALU per 64-channel slab on the conv rows.
     // Steps past the end get a zero-sized resource: their pieces write zeros and keep the vmcnt bookkeeping uniform.
     auto prep = [&](int s) {
         const bool live = s < nsteps;
         dst_cur = dst0 + (unsigned)(s & 3) * SLOT;
+        if constexpr (ROLE == 0 && NPB_REM != 0) dst_last = widx >= NPB_REM ? smem_base + PNSLOT * SLOT : dst_cur + (NPB - 1) * 1024;
         if constexpr (MODE == 0 || ROLE == 0) {
             r_cur = pp_rsrc(op_base + (unsigned long long)s * PROWB, live);
         } else {
@@ -269,9 +278,10 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
         }
     };
     // (q is a compile-time constant at every call site; group 1 has no fifth piece)
-    auto piece_aim = [&](int q) { if (q < NPM) pp_set_m0(dst_cur + q * 1024); };
+    auto piece_dst = [&](int q) { return (ROLE == 0 && NPB_REM != 0 && q == NPB - 1) ? dst_last : dst_cur + q * 1024; };
+    auto piece_aim = [&](int q) { if (q < NPM) pp_set_m0(piece_dst(q)); };
     auto piece_fire = [&](int q) { if (q < NPM) pp_dma_m0(vo[q], r_cur); };
-    auto piece_now = [&](int q) { if (q < NPM) pp_piece_now(vo[q], r_cur, dst_cur + q * 1024); };
+    auto piece_now = [&](int q) { if (q < NPM) pp_piece_now(vo[q], r_cur, piece_dst(q)); };
 
     // fragment read offsets inside a slot (lane constants): row r = ... + frow, stored chunk = fchunk ^ ((r >> 2) & 3)
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -396,6 +406,7 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
 }
 
 int pp_bn(int N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
+int pp_bn(const GemmParams& p) { return (p.tile_n == 160 && p.N % 160 == 0) ? 160 : pp_bn(p.N); }
 
 unsigned long long* g_pp_prof_host = nullptr;
 
@@ -425,8 +436,9 @@ int launch_pp3(const GemmParams& p, hipStream_t s) {
 
 template <class Tag, int MODE>
 int launch_pp(const GemmParams& p, hipStream_t s) {
-    if (pp_bn(p.N) == 256) return launch_pp3<Tag, MODE, false, 256>(p, s);
-    if (pp_bn(p.N) == 128) return launch_pp3<Tag, MODE, false, 128>(p, s);
+    if (pp_bn(p) == 256) return launch_pp3<Tag, MODE, false, 256>(p, s);
+    if (pp_bn(p) == 128) return launch_pp3<Tag, MODE, false, 128>(p, s);
+    if (pp_bn(p) == 160) return launch_pp3<Tag, MODE, false, 160>(p, s);
     return p.splitk_seq > 1 ? launch_pp3<Tag, MODE, true, 320>(p, s) : launch_pp3<Tag, MODE, false, 320>(p, s);
 }
 
@@ -434,7 +446,7 @@ int launch_pp(const GemmParams& p, hipStream_t s) {
 bool pp_fits(unsigned long long bytes) { return bytes + 65536ull < (unsigned long long)P_NUMREC; }
 
 bool pp_eligible(int mode, const GemmParams& p) {
-    const int bn = pp_bn(p.N);
+    const int bn = pp_bn(p);
     if (bn == 0 || p.M < 64 || p.K % BK != 0) return false;
     if (bn != 320 && (p.splitk > 1 || p.splitk_seq > 1)) return false;
     if (!pp_fits((unsigned long long)p.N * p.ldw * 2)) return false;

@@ -48,6 +48,8 @@ struct GemmParams {
     int splitk_seq;    // > 1 (big-tile kernel only): ONE block walks all of K but rounds like `splitk_seq` concurrent slices --
                        // at every slice boundary the accumulators are folded into a block-private fp32 running total kept in
                        // `partial`, so the result is bit-identical to split-K + reducer without the reducer's traffic / launch
+    int tile_n;        // 256-row ping-pong tile only: 0 = widest width that divides N (320 / 256 / 128); 160 = the 160-wide tile (N % 160 == 0),
+                       // which the dispatcher picks when the 320-wide tiling would leave CUs without a block (small batches)
     ConvGeom g;
 };
 

@@ -611,3 +611,41 @@ def test_pingpong_main_loop_is_bit_identical_and_race_free(lib, dtype):
                     assert torch.equal(out, ref), (B, H, C1, C2, Cout, stride, ups, sk, rep, int((out != ref).sum()))
     finally:
         tune(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_pingpong_160_wide_tile_for_small_batches(lib, dtype):
+    """When 256 x 320 tiles would leave CUs without a block the dispatcher halves the tile width (256 x 160, waves 4 x 2, the 10 weight
+    pieces of a step split 3 / 3 / 2 / 2 with a zero-fill filler): same K order, same bits as the 128-row kernel.  The block threshold
+    is set so that the 320-wide tiling falls short and the 160-wide one does not."""
+    from mvedit_amd import ops, _lib
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        for (M, N, K, fl, thr) in [(2048, 320, 640, 0, 12), (2000, 640, 320, 0, 20), (1024, 2560, 320, ops.GEGLU, 40), (4096, 320, 2560, 0, 24)]:
+            a, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
+            bias = rnd((N,), torch.float32, 3).cuda()
+            res = None if fl else rnd((M, N), dtype, 4).cuda()
+            tune(0)
+            ref = ops.gemm(a, w, bias=bias, residual=res, flags=fl)
+            tune(thr)
+            for rep in range(3):
+                out = ops.gemm(a, w, bias=bias, residual=res, flags=fl)
+                assert torch.equal(out, ref), (M, N, K, rep, int((out != ref).sum()))
+        for (B, H, C1, C2, Cout, stride, ups, thr) in [(2, 32, 320, 0, 320, 1, False, 12), (1, 32, 640, 320, 640, 1, False, 12), (2, 16, 320, 0, 320, 1, True, 12),
+                                                       (3, 32, 64, 0, 320, 2, False, 5)]:
+            x1 = to_nhwc(rnd((B, C1, H, H), dtype, 1)).cuda()
+            x2 = to_nhwc(rnd((B, C2, H, H), dtype, 2)).cuda() if C2 else None
+            wt = rnd((Cout, C1 + C2, 3, 3), dtype, 3, (9 * (C1 + C2)) ** -0.5)
+            w_k, wflag = ops.pack_conv_weight(wt, True)
+            w_k = w_k.cuda()
+            bias = rnd((Cout,), torch.float32, 4).cuda()
+            tune(0)
+            ref = ops.conv3x3(x1, w_k, B, H, H, x2=x2, stride=stride, upsample=ups, bias=bias, flags=wflag, splitk=False)[0]
+            tune(thr)
+            for rep in range(3):
+                out = ops.conv3x3(x1, w_k, B, H, H, x2=x2, stride=stride, upsample=ups, bias=bias, flags=wflag, splitk=False)[0]
+                assert torch.equal(out, ref), (B, H, C1, C2, Cout, stride, ups, rep, int((out != ref).sum()))
+    finally:
+        tune(old)
