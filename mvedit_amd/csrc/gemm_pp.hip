@@ -1,33 +1,39 @@
-// Ping-pong main loop for the 256 x {320,256} GEMM / implicit-GEMM conv tile (same tile, wave arrangement, MFMA order and epilogue
-// as gemm_big.hip, hence bit-identical results; only the schedule of one K step differs).
+// Ping-pong main loop for the 256-row GEMM / implicit-GEMM conv tile (same tile, wave arrangement, MFMA order and epilogue as
+// gemm_big.hip, hence bit-identical results; only the schedule of one K step differs).  Tile widths 320 / 256 (waves 2 x 4) and
+// 160 / 128 (waves 4 x 2); the description below is for 320.
 //
 // Why: rocprofv3 PMC on k_gemm_big (profiles/r02_rocprof_v1_summary.txt) shows the MFMA pipe 47 % busy at the clock the kernel
 // actually runs at.  Its 8 waves run one K tile in lock-step -- all of them issue their 9 LDS-DMA pieces, then all of them read
 // fragments, then all of them issue MFMAs -- so the two waves that share a SIMD want the matrix pipe at the same time and leave it
-// idle at the same time.  Here the two wave groups (wm = 0: waves 0-3, wm = 1: waves 4-7, one wave of each per SIMD) run half a
-// step apart, held there by a barrier after every section:
+// idle at the same time.  Here the two wave groups (waves 0-3 and 4-7, one wave of each per SIMD) run half a step apart, held there
+// by a barrier after every section:
 //
 //     interval   2k        2k+1      2k+2      2k+3
-//     group 0    L(k)      M(k)      L(k+1)    M(k+1)          L(k): 13 ds_read_b128 of step k's fragments + this wave's LDS-DMA
-//     group 1    M(k-1)    L(k)      M(k)      L(k+1)                pieces of step k+3;   M(k): 40 MFMA 16x16x32
+//     group 0    L(k)      M(k)      L(k+1)    M(k+1)          L(k): 13 ds_read_b128 of step k's fragments, address part of step k+3
+//     group 1    M(k-1)    L(k)      M(k)      L(k+1)          M(k): 40 MFMA 16x16x32, this wave's LDS-DMA pieces of step k+3 between them
 //
-// so one wave of every SIMD is always in its MFMA section while the other one does the LDS / DMA work.
+// so one wave of every SIMD is always in its MFMA section while the other one does the LDS work.
 //   * K step = 32 (one MFMA k-step): only 13 fragments (52 VGPRs) are live next to the 160 accumulator registers.
 //   * LDS: a ring of 4 slots of 36 KiB (256 + 320 rows x 64 B) = 144 KiB, the same footprint as the two 72 KiB stages.  A slot
 //     row holds the 4 16-byte chunks of one (row, K step) XOR-swizzled by (row >> 2) & 3: a 16-lane ds_read_b128 group touches all
 //     16 slots of a bank row exactly once.  The swizzle is applied on the global side of the LDS-DMA (lane -> source chunk).
-//   * prefetch distance 3 steps, never drained: at the end of L(k) a wave waits (counted vmcnt) for ITS pieces of step k+1 only
-//     -- issued two steps earlier -- and the barrier that ends the interval publishes them.  Hazards, by interval number:
+//   * prefetch distance 3 steps, never drained: the pieces of step k+3 leave inside M(k) (one behind each group of 8 MFMAs, M0
+//     written one MFMA earlier: ~10 cycles per piece there against 60-180 in an L section busy with LDS reads); at the end of L(k) a
+//     wave waits (counted vmcnt) for ITS pieces of step k+1 only -- issued in M(k-2) -- and the barrier that ends the interval
+//     publishes them.  Hazards, by interval number:
 //       RAW  step k+1 is read in 2k+2 (group 0) and 2k+3 (group 1); its B pieces were waited for by group 0 before the barrier
 //            ending 2k, its A pieces by group 1 before the barrier ending 2k+1.
 //       WAR  step k+3 goes to slot (k-1) & 3, last read in 2k-2 / 2k-1 with lgkmcnt(0) before the barrier ending 2k-1; the
-//            earliest issue is group 0's in 2k.
+//            earliest issue is group 0's in 2k+1.
 //   * role split: group 0 streams the weight rows (5 pieces per wave and step for BN = 320), group 1 the activation rows (4 pieces):
-//     a wave carries the address state of one operand only.
+//     a wave carries the address state of one operand only, and each role has its own straight-line copy of the loop.
 //   * addresses: buffer_load_dwordx4 ... lds with the step's uniform part (K offset, conv tap and channel slab) folded into the
-//     resource base by SALU and a per-lane byte offset that is constant (GEMM, weights) or recomputed once per 64-channel slab
-//     (conv).  Halo pixels and steps past the end of K use an out-of-range offset / a zero-sized resource: the DMA writes zeros.
-//   * LDS-DMA and waits are inline asm (hipcc would drain vmcnt to 0 at every barrier and before LDS reads it cannot disambiguate).
+//     resource base by SALU and a per-lane byte offset that is constant (GEMM, weights) or changes with the conv's source tensor
+//     only.  Halo pixels use an all-ones offset, steps past the end of K a zero-sized resource: the DMA writes zeros.
+//   * LDS-DMA, waits and MFMAs are inline asm: hipcc would drain vmcnt to 0 at every barrier and before LDS reads it cannot
+//     disambiguate, and it rotates the accumulators through the loop when the MFMAs are builtins.  tools/check_pp_isa.py (a CPU
+//     test) verifies on the device assembly that the compiler adds no spill, wait, vector memory instruction or M0 user to the loops.
+//   * section timing: tools/pp_profile.py (mve_gemm_pp_profile).
 #include "common.h"
 
 #include <type_traits>
