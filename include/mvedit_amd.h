@@ -238,6 +238,10 @@ MVE_API int mve_attention(int dtype, const void* d_Q, int ldq, const void* d_K, 
  * v_permlane16_swap for P (8: 4 waves / 2 LDS stages, 9: 8 waves / 2, 10: 4 waves / 3, 11: 8 waves / 3 stages); other head dims keep 0.
  * Negative: query only.  Returns the previous value.  tools/ab_attention.py measures them on one box. */
 MVE_API int mve_attention_tune(int variant);
+/* Development aid (tools/ab_attention_ablate.py): bits 8-19 of mve_attention_tune's argument select a timing-only ablation of the
+ * head_dim 40 kernel (results are wrong by construction); those launches add per-wave shader-clock and 100 MHz durations to a device
+ * accumulator which this call reads into out4 = {shader cycles, 10 ns ticks, waves, 0} and resets. */
+MVE_API int mve_attention_profile(unsigned long long* out4);
 /* The same attention with Q ALREADY multiplied by softmax_scale * log2(e) (= head_dim^-1/2 * 1.442695...): the logits are in log2 units
  * and no per-logit multiply remains.  This is how the UNet / ControlNet executors call it: they fold the factor into the to_q rows when the
  * weights are packed (fp32 multiply, then the one rounding to 16 bit), which replaces the `scale=` handling of

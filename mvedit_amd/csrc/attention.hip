@@ -431,6 +431,9 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (D > 80 ? 1 : 2))) void k_attentio
 __device__ __attribute__((aligned(16))) unsigned short g_attn_ones_f16[8] = {0x3C00u, 0, 0, 0, 0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) unsigned short g_attn_ones_bf16[8] = {0x3F80u, 0, 0, 0, 0, 0, 0, 0};
 
+// development aid (mve_attention_profile): with ABL bit 10 a wave adds its shader-clock (s_memtime) and 100 MHz (s_memrealtime) durations here
+__device__ unsigned long long g_attn_prof[4] = {0ull, 0ull, 0ull, 0ull};
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -451,7 +454,10 @@ __device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_dst) {
 // takes C = -m_run (16 registers holding the lane's own query's value) instead of 0.  exp2 is then applied to the accumulator as it is:
 // the 32 v_fma per tile of the generic path disappear (rocprofv3: the kernel is VALU-issue bound -- SQ_ACTIVE_INST_VALU 77 % of the
 // SIMD cycles against 38 % MFMA busy).  A growing maximum (rare after the first tiles) subtracts the growth from S and rescales O.
-template <class Tag, bool SEG2, int NW, int NST, int WPS, bool PRE, bool PIPE>
+// ABL: timing-only ablation mask (tools/ab_attention_ablate.py; results are WRONG for ABL != 0).  bit 0: no s_barrier; 1: no vmcnt wait;
+// 2: no LDS-DMA; 3: no v_exp; 4: no row-maximum chain; 5: no Q K^T MFMAs; 6: no P V MFMAs; 7: no K fragment reads; 8: no V^T fragment reads;
+// 9: no permlane16 swaps
+template <class Tag, bool SEG2, int NW, int NST, int WPS, bool PRE, bool PIPE, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p) {
     constexpr int D = 40, KB = 64, QB = 32 * NW;
     constexpr int K_ROW = 80, V_ROW = 96;
@@ -468,6 +474,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l32 = lane & 31, hi = lane >> 5, l16 = lane & 15, g = lane >> 4;
+    unsigned long long prof_t0 = 0, prof_r0 = 0;
+    if constexpr ((ABL & 1024) != 0) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_t0), "=s"(prof_r0) :: "memory");
 
     const int q_tiles = (p.Lq + QB - 1) / QB;
     const unsigned nblk = (unsigned)(q_tiles * p.heads * p.B);
@@ -559,6 +567,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
     // tile t (t >= 1 is always issued one tile ahead, in order)
     const int n_tiles = (Ltot + KB - 1) / KB, n_full = Ltot / KB;
     auto dma = [&](int t, int stage_off) {
+        if constexpr ((ABL & 4) != 0) return;
         if constexpr (SEG2) dma_any(t, stage_off);
         else { if (t < n_full) dma_fast(stage_off); else dma_any(t, stage_off); }
     };
@@ -595,8 +604,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
             const int o = st < 2 ? k_off01 + 32 * st : k_off2;
-            const V8 ka = *reinterpret_cast<const V8*>(St + o);
-            const V8 kb_ = *reinterpret_cast<const V8*>(St + o + 32 * K_ROW);
+            V8 ka, kb_;
+            if constexpr ((ABL & 128) != 0) { ka = qf[st]; kb_ = qf[(st + 1) % 3]; }
+            else { ka = *reinterpret_cast<const V8*>(St + o); kb_ = *reinterpret_cast<const V8*>(St + o + 32 * K_ROW); }
+            if constexpr ((ABL & 32) != 0) {          // no MFMA: keep the fragments alive, S = C operand
+                asm volatile("" :: "v"(ka), "v"(kb_));
+                if (st == 0) { s.a = negm; s.b = negm; }
+                continue;
+            }
             if (PRE && st == 0) {
                 // D != C written out by hand: for a C operand that stays live hipcc copies it into the accumulator first (8 v_mov_b64 per
                 // chain and tile -- what the saved v_fma bought).  Operands come from waited-for loads / old VALU results; the only
@@ -628,9 +643,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
             }
         }
         float mx = fmaxf(s.a[0], s.b[0]);
+        if constexpr ((ABL & 16) == 0) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s.a[r]), s.b[r]);          // v_max3_f32 (built with -fno-honor-nans: no canonicalising v_max)
-        mx = mve_max_xor32(mx);
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s.a[r]), s.b[r]);      // v_max3_f32 (built with -fno-honor-nans: no canonicalising v_max)
+            mx = mve_max_xor32(mx);
+        }
         float a0 = 1.f, a1 = 1.f;
         bool rescale = false;
         if constexpr (PRE) {
@@ -678,7 +695,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
                 float e0, e1;
-                if constexpr (PRE) {
+                if constexpr (PRE && (ABL & 8) != 0) {
+                    e0 = sk[2 * r2]; e1 = sk[2 * r2 + 1];
+                } else if constexpr (PRE) {
                     e0 = __builtin_amdgcn_exp2f(sk[2 * r2]);
                     e1 = __builtin_amdgcn_exp2f(sk[2 * r2 + 1]);
                 } else {
@@ -690,6 +709,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int ai = v < 2 ? v : v + 2;
+                if constexpr ((ABL & 512) != 0) { pb.w[kb][0][v] = pk[ai]; pb.w[kb][1][v] = pk[ai + 2]; continue; }
                 const auto r = __builtin_amdgcn_permlane16_swap(pk[ai], pk[ai + 2], false, false);
                 pb.w[kb][0][v] = r[0];
                 pb.w[kb][1][v] = r[1];
@@ -706,6 +726,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
         for (int kb = 0; kb < 2; ++kb) {
             s16x4 lo[3], up[3];
             const unsigned va0 = (unsigned)(uintptr_t)(lds_ptr_t)(St + v_off + kb * 32 * V_ROW);
+            if constexpr ((ABL & 256) != 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { lo[i] = __builtin_bit_cast(s16x4, u32x2{pb.w[kb][0][i], va0}); up[i] = __builtin_bit_cast(s16x4, u32x2{va0, pb.w[kb][1][i]}); }
+            } else
             asm volatile("ds_read_b64_tr_b16 %0, %6\n\t"
                          "ds_read_b64_tr_b16 %1, %6 offset:%7\n\t"
                          "ds_read_b64_tr_b16 %2, %6 offset:32\n\t"
@@ -722,6 +746,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
                     const u32x4 pw = {pb.w[kb][f][0], pb.w[kb][f][1], pb.w[kb][f][2], pb.w[kb][f][3]};
+                    if constexpr ((ABL & 64) != 0) { asm volatile("" : "+v"(oacc[i][f]) : "v"(va), "v"(pw)); continue; }
                     oacc[i][f] = Tag::mfma16(va, __builtin_bit_cast(V8, pw), oacc[i][f]);
                 }
             }
@@ -729,6 +754,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
     };
 
     auto wait_sync = [&](int keep) {          // s_waitcnt vmcnt(keep) (wave-uniform, 0..3), drain the LDS reads, barrier
+        if constexpr ((ABL & 3) == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
+        else if constexpr ((ABL & 1) != 0) { asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); return; }
+        else if constexpr ((ABL & 2) != 0) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); return; }
         if (keep >= 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -827,6 +855,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
             }
         }
     }
+    if constexpr ((ABL & 1024) != 0) {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+        if (lane == 0 && (blockIdx.x & 63) == 5) {        // a sample of the blocks: contended atomics cost ~12 ns each
+            atomicAdd(&g_attn_prof[0], t1 - prof_t0);
+            atomicAdd(&g_attn_prof[1], r1 - prof_r0);
+            atomicAdd(&g_attn_prof[2], 1ull);
+        }
+    }
 }
 
 // 0: the measured configuration.  2 (d = 80 / 160, single KV segment): conflict-free K swizzle, same arithmetic (bit-identical results).
@@ -835,6 +872,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
 // an experiment for the VALU-bound d = 40 case (mve_attention_tune; results are NOT bit-identical across variants: the online-softmax
 // rescale points move with the fill size).
 int g_attn_variant = 9;
+int g_attn_ablate = 0;       // k_attention3's ABL mask (timing experiments only; mve_attention_tune bits 8-19)
 
 template <class Tag, int D>
 int launch(const AttnParams& p, hipStream_t s) {
@@ -853,6 +891,22 @@ int launch(const AttnParams& p, hipStream_t s) {
 #define MVE_A3(NW_, NST_, WPS_, PIPE_) do { \
                 if (p.Lk2 > 0) { if (p.prescaled && !PIPE_) MVE_A3P(true, NW_, NST_, WPS_, (!PIPE_), PIPE_); else MVE_A3P(true, NW_, NST_, WPS_, false, PIPE_); } \
                 else { if (p.prescaled && !PIPE_) MVE_A3P(false, NW_, NST_, WPS_, (!PIPE_), PIPE_); else MVE_A3P(false, NW_, NST_, WPS_, false, PIPE_); } } while (0)
+            if (g_attn_ablate != 0) {       // timing-only ablations of the default configuration (fp16, single segment, pre-scaled Q)
+                if constexpr (std::is_same<Tag, F16Tag>::value) {
+                    if (p.Lk2 == 0 && p.prescaled) {
+                        const unsigned grid9 = (unsigned)(((p.Lq + 255) / 256) * p.heads * p.B);
+                        bool hit = true;
+                        switch (g_attn_ablate) {
+#define MVE_ABL(A) case A: k_attention3<Tag, false, 8, 2, 4, true, false, (A) | 1024><<<grid9, 512, 0, s>>>(p); break;
+                            MVE_ABL(2048) MVE_ABL(1) MVE_ABL(3) MVE_ABL(7) MVE_ABL(8) MVE_ABL(16) MVE_ABL(24) MVE_ABL(32) MVE_ABL(64) MVE_ABL(96) MVE_ABL(128) MVE_ABL(256)
+                            MVE_ABL(384) MVE_ABL(512) MVE_ABL(536) MVE_ABL(927) MVE_ABL(480) MVE_ABL(1023)
+#undef MVE_ABL
+                            default: hit = false;
+                        }
+                        if (hit) { MVE_LAUNCH_CHECK(); return MVE_OK; }
+                    }
+                }
+            }
             switch (var) {
                 case 8: MVE_A3(4, 2, 4, false); break;
                 case 9: MVE_A3(8, 2, 4, false); break;
@@ -914,9 +968,19 @@ int dispatch_d(const AttnParams& p, int d, hipStream_t s) {
 
 }  // namespace
 
+// development aid: sums over the waves of the profiled (ablation) launches since the last call: {shader cycles, 10 ns ticks, waves, 0}; resets them
+extern "C" int mve_attention_profile(unsigned long long* out4) {
+    MVE_CHECK(out4, MVE_ERR_ARG, "attention_profile: null pointer");
+    MVE_HIP(hipDeviceSynchronize());
+    MVE_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_attn_prof), 4 * sizeof(unsigned long long)));
+    const unsigned long long z[4] = {0ull, 0ull, 0ull, 0ull};
+    MVE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z)));
+    return MVE_OK;
+}
+
 extern "C" int mve_attention_tune(int variant) {
-    const int old = g_attn_variant;
-    if (variant >= 0) g_attn_variant = variant;
+    const int old = g_attn_variant | (g_attn_ablate << 8);
+    if (variant >= 0) { g_attn_variant = variant & 255; g_attn_ablate = (variant >> 8) & 4095; }
     return old;
 }
 
