@@ -55,14 +55,17 @@ struct GemmParams {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// exact (erf) GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the 16-bit output rounding): one rcp,
-// one exp and five FMAs instead of erff's ~40 instructions -- the GEGLU epilogue evaluates 3.4e8 of these per level-0 launch
+// erf-GELU x * Phi(x) with Phi(x) = 0.5 + t P(t^2) / Q(t^2), t = clamp(x, -5, 5): a (3, 3) rational minimax fit (tools/fit_gelu.py) whose
+// absolute error is <= 1.1e-5 over all x when evaluated in fp32 -- 1/45 of the fp16 rounding step of an output of magnitude 1 -- for 11 plain
+// VALU operations and one reciprocal.  The GEGLU epilogue evaluates 3.4e8 of these per level-0 launch and is VALU-bound: the previous form
+// (Abramowitz & Stegun 7.1.26 through rcp + exp, 16 plain operations + 2 transcendentals, |error| <= 1.5e-7) cost 0.19 ms of a 0.78 ms launch
+// (profiles/r03_ab_gelu.log).  Q >= 1 everywhere: the reciprocal is safe.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    const float t = __builtin_amdgcn_fmed3f(x, -5.0f, 5.0f);
+    const float u = t * t;
+    const float P = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.99665181e-05f, u, 0.00375327937f), u, 0.0294303672f), u, 0.398879537f);
+    const float Q = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.00109351574f, u, 0.0246359949f), u, 0.240117083f), u, 1.0f);
+    return x * __builtin_fmaf(t * P, __builtin_amdgcn_rcpf(Q), 0.5f);
 }
 
 // address of the 16-byte source chunk of im2col element (row = output pixel (cb,cy,cx), tap, channel `cin`)
