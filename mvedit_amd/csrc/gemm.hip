@@ -44,6 +44,7 @@ constexpr int BM = 128;
 long long mve_gemm_big_blocks(int M, int N, int splitk);
 int mve_gemm_big_launch(int dtype, int mode, const void* params, void* stream);
 int mve_gemm_pp_launch(int dtype, int mode, const void* params, void* stream);      // gemm_pp.hip; 1 = not eligible
+void mve_gemm_pp_old_swizzle(int on);
 namespace {
 
 template <class Tag, int BN, int MODE>   // MODE 0: dense A, 1: conv3x3 gather
@@ -358,8 +359,23 @@ bool gemm_pp_on() {
     }
     return g_gemm_pp != 0;
 }
+// The two-blocks-per-CU 256 x 160 tile (gemm_pp.hip, NSL = 3) for dense GEMMs: mve_gemm_tune bit 26 / MVE_GEMM_PP2 (A/B; bit-identical results)
+int g_gemm_pp2 = -1;
+bool gemm_pp2_on() {
+    if (g_gemm_pp2 < 0) {
+        const char* e = getenv("MVE_GEMM_PP2");
+        g_gemm_pp2 = e ? atoi(e) : 0;
+    }
+    return g_gemm_pp2 != 0;
+}
 // MVE_OK after a launch, 1 when neither loop takes the problem (the caller falls back to the 128-row kernel), < 0 on error
 int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
+    if (gemm_pp_on() && gemm_pp2_on() && mode == 0 && q->tile_n == 0 && q->splitk <= 1 && q->splitk_seq <= 1) {
+        GemmParams r = *q;
+        r.tile_n = 161;
+        const int rc = mve_gemm_pp_launch(dtype, mode, &r, s);
+        if (rc <= 0) return rc;
+    }
     if (gemm_pp_on()) {
         const int rc = mve_gemm_pp_launch(dtype, mode, q, s);
         if (rc <= 0) return rc;
@@ -437,7 +453,9 @@ int mve_gemm_tune(int big_min_blocks) {
     if (big_min_blocks >= 0) {
         g_seq_splitk = (big_min_blocks & (1 << 29)) ? 0 : 1;
         g_gemm_pp = (big_min_blocks & (1 << 27)) ? 0 : 1;
-        g_big_min_blocks = big_min_blocks & ~((3 << 28) | (1 << 27));
+        g_gemm_pp2 = (big_min_blocks & (1 << 26)) ? 1 : 0;
+        mve_gemm_pp_old_swizzle((big_min_blocks >> 25) & 1);
+        g_big_min_blocks = big_min_blocks & ~((3 << 28) | (1 << 27) | (1 << 26) | (1 << 25));
     }
     return old;
 }

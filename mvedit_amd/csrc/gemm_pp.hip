@@ -15,7 +15,8 @@
 // so one wave of every SIMD is always in its MFMA section while the other one does the LDS work.
 //   * K step = 32 (one MFMA k-step): only 13 fragments (52 VGPRs) are live next to the 160 accumulator registers.
 //   * LDS: a ring of 4 slots of 36 KiB (256 + 320 rows x 64 B) = 144 KiB, the same footprint as the two 72 KiB stages.  A slot
-//     row holds the 4 16-byte chunks of one (row, K step) XOR-swizzled by (row >> 2) & 3: a 16-lane ds_read_b128 group touches all
+//     row holds the 4 16-byte chunks of one (row, K step) XOR-swizzled by (row >> 1) & 3: a ds_read_b128 lane group -- the hardware's groups
+//     are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md), not 16 consecutive lanes -- touches all
 //     16 slots of a bank row exactly once.  The swizzle is applied on the global side of the LDS-DMA (lane -> source chunk).
 //   * prefetch distance 3 steps, never drained: the pieces of step k+3 leave inside M(k) (one behind each group of 8 MFMAs, M0
 //     written one MFMA earlier: ~10 cycles per piece there against 60-180 in an L section busy with LDS reads); at the end of L(k) a
@@ -51,7 +52,8 @@ constexpr int PNSLOT = 4;
 constexpr int P_A_SLOT = PBM * PROWB;                   // 16 KiB
 constexpr unsigned P_NUMREC = 0xFFFFFF00u;              // resource size: every valid offset is below it, the all-ones halo offset above
 constexpr int pp_slot_bytes(int bn) { return P_A_SLOT + bn * PROWB; }
-constexpr int pp_smem(int bn) { return PNSLOT * pp_slot_bytes(bn) + (bn == 160 ? 1024 : 0); }      // 160: + a 1 KiB dump for the filler piece
+constexpr int pp_smem(int bn, int nsl = PNSLOT) { return nsl * pp_slot_bytes(bn) + (bn == 160 ? 1024 : 0); }      // 160: + a 1 KiB dump for the filler piece
+static_assert(2 * pp_smem(160, 3) <= 160 * 1024, "two blocks of the three-slot 256 x 160 tile per CU");
 static_assert(64 * (320 + 4) * 4 <= pp_smem(320) && 64 * (256 + 4) * 4 <= pp_smem(256) && 64 * (128 + 4) * 4 <= pp_smem(128) &&
               64 * (160 + 4) * 4 <= pp_smem(160), "epilogue staging must fit");
 
@@ -112,13 +114,113 @@ template <> struct PMfma<BF16Tag> {
 };
 __device__ __forceinline__ void pp_mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
+
+// Epilogue of the two-blocks-per-CU tile (NSL = 3: 256 x 160, waves 4 x 2, wave tile 64 x 80).  Every wave finishes its own sub-tile through a
+// wave-private LDS window -- no workgroup barrier: a wave's LDS operations execute in order, so its staging writes, the reads behind them and
+// the next group's writes need no fence, and the eight waves drift apart instead of meeting four times per tile.  Only what the launcher
+// admits (pp2_eligible): 16-bit output, unit output scale, residual (if any) added before it, no per-image row vector, no split K, whole
+// tiles.  Same operations in the same order as gemm_epilogue_tail / the GEGLU path of big_tile_epilogue: identical bits.
+constexpr int P2_CS_LD = 84;                              // floats per staged row (80 + 4: the 8-lane groups of a ds_write_b128 hit 8 distinct bank quads)
+constexpr int P2_CS_WAVE = 16 * P2_CS_LD * 4;             // 16 rows at a time: 5376 B per wave
+constexpr int P2_HS_LD = 56;                              // GEGLU: 16-bit elements per staged row (40 + 16: 112-byte rows keep the 16-byte reads aligned)
+constexpr int P2_HS_WAVE = 64 * P2_HS_LD * 2;             // all 64 rows of the wave: 7168 B
+static_assert(8 * P2_CS_WAVE <= pp_smem(160, 3) && 8 * P2_HS_WAVE <= pp_smem(160, 3), "epilogue staging must fit");
+
+template <class Tag>
+__device__ __forceinline__ void pp2_epilogue(const GemmParams& p, f32x4 (&acc)[5][4], unsigned char* smem, int m0, int n0, int wid, int lane, int wm, int wn) {
+#pragma clang fp contract(off)
+    typedef typename Tag::T T;
+    typedef typename Tag::V8 V8;
+    constexpr int NF = 5, MF = 4;
+    const int mw = m0 + wm * 64, nw = n0 + wn * 80;
+    if (p.geglu) {
+        // out[m][i] = (v[2i] + b[2i]) * gelu(v[2i+1] + b[2i+1]): a lane owns two (value, gate) pairs of a row per fragment
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        T* Hs = reinterpret_cast<T*>(smem + wid * P2_HS_WAVE);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int c = j * 16 + (lane >> 4) * 4;
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + nw + c);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const f32x4 v = acc[j][i];
+                T2 o;
+                o[0] = Tag::from_f32((v[0] + b4[0]) * gelu_erf(v[1] + b4[1]));
+                o[1] = Tag::from_f32((v[2] + b4[2]) * gelu_erf(v[3] + b4[3]));
+                *reinterpret_cast<T2*>(Hs + (i * 16 + (lane & 15)) * P2_HS_LD + (c >> 1)) = o;
+            }
+        }
+        // 64 rows x 40 outputs = 320 chunks of 8: five per lane, row-contiguous 80-byte segments
+        T* outw = reinterpret_cast<T*>(p.out) + (size_t)mw * p.ldc + (nw >> 1);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int task = k * 64 + lane;
+            const int r = task / 5, ch = task - r * 5;
+            *reinterpret_cast<V8*>(outw + (size_t)r * p.ldc + ch * 8) = *reinterpret_cast<const V8*>(Hs + r * P2_HS_LD + ch * 8);
+        }
+        return;
+    }
+    // 16 rows at a time through fp32 staging; lane = (8-column chunk ch of the 10, row r0 of 6), rows r0, r0 + 6, r0 + 12 of a group
+    float* Cs = reinterpret_cast<float*>(smem + wid * P2_CS_WAVE);
+    const bool act = lane < 60;
+    const int ch = act ? lane % 10 : 0, r0 = act ? lane / 10 : 0;
+    const int n = nw + ch * 8;
+    f32x4 fb0 = f32x4{0.f, 0.f, 0.f, 0.f}, fb1 = fb0;
+    if (p.bias) { fb0 = *reinterpret_cast<const f32x4*>(p.bias + n); fb1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+    T* outb = reinterpret_cast<T*>(p.out) + (size_t)(mw + r0) * p.ldc + n;
+    const T* resb = reinterpret_cast<const T*>(p.residual) + (size_t)(mw + r0) * p.ldr + n;
+    const bool has_res = p.residual != nullptr;
+    // row of chunk k relative to r0: the third one exists for r0 < 4 only; the other lanes redo their second row and store nothing
+    const int rel2 = r0 < 4 ? 12 : 6;
+    auto run = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+        V8 fr[3];
+        if constexpr (RES) {
+            fr[0] = *reinterpret_cast<const V8*>(resb);
+            fr[1] = *reinterpret_cast<const V8*>(resb + (size_t)6 * p.ldr);
+            fr[2] = *reinterpret_cast<const V8*>(resb + (size_t)rel2 * p.ldr);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                *reinterpret_cast<f32x4*>(Cs + (lane & 15) * P2_CS_LD + j * 16 + (lane >> 4) * 4) = acc[j][i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int rel = k == 0 ? 0 : (k == 1 ? 6 : rel2);
+                const bool ok = act && (k < 2 || r0 < 4);
+                const float* cs = Cs + (r0 + rel) * P2_CS_LD + ch * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(cs), hi = *reinterpret_cast<const f32x4*>(cs + 4);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e] + fb0[e]; v[4 + e] = hi[e] + fb1[e]; }
+                if constexpr (RES) {
+                    const V8 res = fr[k];
+                    if (i + 1 < MF) fr[k] = *reinterpret_cast<const V8*>(resb + (size_t)((i + 1) * 16 + rel) * p.ldr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(res[e]);
+                }
+                V8 pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
+                if (ok) *reinterpret_cast<V8*>(outb + (size_t)(i * 16 + rel) * p.ldc) = pk;
+            }
+        }
+    };
+    if (has_res) run(std::true_type()); else run(std::false_type());
+}
+
 // Section timing (development aid, mve_gemm_pp_profile): per wave, shader-clock sums of the four parts of a step.
 __device__ unsigned long long* g_pp_prof = nullptr;
 
 template <int V> struct PInt { static constexpr int value = V; };
 
-template <class Tag, int MODE, bool SEQ, int BN2, bool PROF = false>        // MODE 1: slab-major (chunk64) conv only
-__global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
+// NSL: LDS ring slots (prefetch distance NSL - 1).  NSL = 3 (BN2 = 160, dense GEMM only): the tile that lets TWO blocks share a CU -- 128
+// registers, 79 KiB -- so that one block's epilogue (memory-latency bound: residual reads, stores; no MFMA) runs under the other block's
+// K loop and the fragment reads of either hide behind the other's MFMAs; its epilogue is per wave (pp2_epilogue), without block barriers.
+template <class Tag, int MODE, bool SEQ, int BN2, bool PROF = false, int NSL = PNSLOT>        // MODE 1: slab-major (chunk64) conv only
+__global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmParams p) {
     typedef typename Tag::V8 V8;
     // BN2 = 320 | 256: waves 2 (M) x 4 (N), wave tile 128 x {80, 64};  BN2 = 128 (the 128-channel convolutions of the VAE at image
     // resolution): waves 4 x 2, wave tile 64 x 64 -- 16 MFMAs against 8 fragment reads per step, LDS-read bound (~3/4 of the MFMA rate)
@@ -132,6 +234,8 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     constexpr int NPB = NPB_BASE + (NPB_REM ? 1 : 0);          // weight pieces per group-0 wave and step: 5 | 4 | 2 | 3 (160: 3, 3, 2 + filler, 2 + filler)
     constexpr int NPA = 4;                                     // activation pieces per group-1 wave and step
     constexpr int SLOT = pp_slot_bytes(BN2);
+    constexpr int DIST = NSL - 1;                              // a step's pieces leave DIST steps before it is read
+    static_assert(NSL == 4 || (NSL == 3 && BN2 == 160 && MODE == 0 && !SEQ), "three slots: the two-blocks-per-CU GEMM tile only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -170,7 +274,8 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     // ---- DMA role state ------------------------------------------------------------------------------------------------------
     // lane l of a piece writes LDS bytes [16 l, 16 l + 16): row l >> 2 of the piece, stored chunk l & 3 = source chunk ^ swizzle
     const int prow = lane >> 2;
-    const unsigned c16 = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    // row of the piece = lane >> 2: swizzle (row >> 1) & 3  (p.old_swizzle: the round-2 term (row >> 2) & 3, 2-way conflicted -- same-box A/B only)
+    const unsigned c16 = (unsigned)(((lane & 3) ^ ((lane >> (p.old_swizzle ? 4 : 3)) & 3)) << 4);
     unsigned vo[5] = {0u, 0u, 0u, 0u, 0u};    // per-piece byte offset of the lane's chunk: constant for weights / dense A, per (tap, slab) for conv rows
     unsigned pixb[NPA] = {0u, 0u, 0u, 0u};    // conv rows: biased pixel index of the window origin
     unsigned vmask[NPA] = {0u, 0u, 0u, 0u};   // conv rows: 9-bit tap validity + window-origin parities (upsample)
@@ -227,13 +332,15 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     i32x4 r_cur;                              // resource and LDS destination of the step being issued
     unsigned dst_cur;
     unsigned dst_last = 0;                    // destination of piece NPB - 1: the dump area for a filler piece
+    int slot_is = 0;                          // ring slot of the step being issued (steps are issued in order)
 
     // address part of issuing step s (relative to kt_begin): scalar work, plus 4 x ~5 VALU per 64-channel slab on the conv rows.
     // Steps past the end get a zero-sized resource: their pieces write zeros and keep the vmcnt bookkeeping uniform.
     auto prep = [&](int s) {
         const bool live = s < nsteps;
-        dst_cur = dst0 + (unsigned)(s & 3) * SLOT;
-        if constexpr (ROLE == 0 && NPB_REM != 0) dst_last = widx >= NPB_REM ? smem_base + PNSLOT * SLOT : dst_cur + (NPB - 1) * 1024;
+        dst_cur = dst0 + (unsigned)slot_is * SLOT;
+        slot_is = slot_is + 1 == NSL ? 0 : slot_is + 1;
+        if constexpr (ROLE == 0 && NPB_REM != 0) dst_last = widx >= NPB_REM ? smem_base + NSL * SLOT : dst_cur + (NPB - 1) * 1024;
         if constexpr (MODE == 0 || ROLE == 0) {
             r_cur = pp_rsrc(op_base + (unsigned long long)s * PROWB, live);
         } else {
@@ -289,20 +396,20 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     auto piece_fire = [&](int q) { if (q < NPM) pp_dma_m0(vo[q], r_cur); };
     auto piece_now = [&](int q) { if (q < NPM) pp_piece_now(vo[q], r_cur, piece_dst(q)); };
 
-    // fragment read offsets inside a slot (lane constants): row r = ... + frow, stored chunk = fchunk ^ ((r >> 2) & 3)
+    // fragment read offsets inside a slot (lane constants): row r = ... + frow, stored chunk = fchunk ^ ((r >> 1) & 3)
     const int frow = lane & 15, fchunk = lane >> 4;
-    const int fsw = (fchunk ^ ((frow >> 2) & 3)) << 4;
+    const int fsw = (fchunk ^ ((frow >> (p.old_swizzle ? 2 : 1)) & 3)) << 4;
     const int a_off = (wm * WTM + frow) * PROWB + fsw;
     const int b_off = P_A_SLOT + (wn * WTN + frow) * PROWB + fsw;
 
-    // this wave's pieces of all but the newest 2 / 1 issued steps have landed
-    auto wait_keep2 = [&]() { pp_wait_vm<2 * NPM>(); };
-    auto wait_keep1 = [&]() { pp_wait_vm<NPM>(); };
+    // this wave's pieces of all but the newest DIST - 1 / DIST - 2 issued steps have landed (four slots: 2 / 1; three slots: 1 / 0)
+    auto wait_keep2 = [&]() { pp_wait_vm<(DIST - 1) * NPM>(); };
+    auto wait_keep1 = [&]() { pp_wait_vm<(DIST - 2) * NPM>(); };
 
     if constexpr (PROF) prof_loop0 = __builtin_readcyclecounter();
     const unsigned m0_keep = pp_m0_take();
 #pragma unroll 1
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < DIST; ++s) {
         prep(s);
 #pragma unroll
         for (int q = 0; q < 5; ++q) piece_now(q);
@@ -318,33 +425,43 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     // One copy of the step body: the slot offset is a run-time scalar (two v_add per step) rather than four unrolled copies --
     // the SEQ fold below would otherwise be inlined into each of them.
     unsigned long long t_l = 0, t_b1 = 0, t_m = 0, t_b2 = 0, t_rd = 0, t_prep = 0;
+    int slot_rd = 0;                          // ring slot of the step being read
     auto step = [&](int k) {
         V8 xf[MF], wf[NF];
         unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, ca = 0, cb = 0;
         if constexpr (PROF) c0 = __builtin_readcyclecounter();
-        const unsigned char* sp = smem + (k & 3) * SLOT;
+        const unsigned char* sp = smem + slot_rd * SLOT;
+        slot_rd = slot_rd + 1 == NSL ? 0 : slot_rd + 1;
         // ---- L(k): fragments of step k; addresses of step k + 3; this wave's pieces of step k + 1 have landed ----
+        if constexpr (NSL == 3) {
+            // three slots: the pieces of step k + 2 leave at the TOP of L(k) (their slot was last read in L(k-1), one barrier ago for either group),
+            // two intervals before their wait at the end of L(k+1): issued from M(k) they had one interval, less than an HBM round trip
+            prep(k + DIST);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) piece_now(q);
+        }
 #pragma unroll
         for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const V8*>(sp + b_off + j * 1024);
 #pragma unroll
         for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const V8*>(sp + a_off + i * 1024);
         if constexpr (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ca = __builtin_readcyclecounter(); }
-        prep(k + 3);
+        if constexpr (NSL != 3) prep(k + DIST);
         if constexpr (PROF) cb = __builtin_readcyclecounter();
-        wait_keep1();                         // in flight: steps k + 1 (issued in M(k-2)) and k + 2 (M(k-1)) -> k + 2 may stay
+        if constexpr (NSL == 3) pp_wait_vm<NPM>();          // in flight: steps k + 1 (issued in L(k-1)) and k + 2 (just now) -> k + 2 may stay
+        else wait_keep1();                         // four slots: in flight are steps k + 1 (issued in M(k-2)) and k + 2 (M(k-1)) -> k + 2 may stay; three: k + 1 only
         if constexpr (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c1 = __builtin_readcyclecounter(); }
         pp_barrier_lds();
         if constexpr (PROF) c2 = __builtin_readcyclecounter();
-        // ---- M(k): 8 MFMAs per weight fragment; one LDS-DMA piece of step k + 3 goes out behind each group, its M0 one MFMA earlier ----
+        // ---- M(k): MF MFMAs per weight fragment; one LDS-DMA piece of step k + DIST goes out behind each group, its M0 one MFMA earlier ----
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 PMfma<Tag>::run(acc[j][i], wf[j], xf[i]);
-                if (i == MF - 2) piece_aim(j);
+                if constexpr (NSL != 3) { if (i == MF - 2) piece_aim(j); }
             }
-            piece_fire(j);
+            if constexpr (NSL != 3) piece_fire(j);
         }
         __builtin_amdgcn_s_setprio(0);
         if constexpr (PROF) c3 = __builtin_readcyclecounter();
@@ -399,7 +516,8 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
     pp_wait_vm<0>();                          // the zero-fill pieces of the steps past the end
     pp_barrier();
     pp_mfma_settle();
-    big_tile_epilogue<Tag, BN2, WAVES_N>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
+    if constexpr (NSL == 3) pp2_epilogue<Tag>(p, acc, smem, m0, n0, wid, lane, wm, wn);
+    else big_tile_epilogue<Tag, BN2, WAVES_N>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
     if constexpr (PROF) {
         if (g_pp_prof && lane == 0) {
             __builtin_amdgcn_s_waitcnt(0);     // the epilogue's stores have left the wave (vmcnt / lgkmcnt / expcnt all zero)
@@ -410,6 +528,9 @@ __global__ __launch_bounds__(PNTH, 2) void k_gemm_pp(const GemmParams p) {
         }
     }
 }
+
+// every per-lane byte offset must stay below the resource size (and the out-of-range marker above it)
+bool pp_fits(unsigned long long bytes) { return bytes + 65536ull < (unsigned long long)P_NUMREC; }
 
 int pp_bn(int N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 0)); }
 int pp_bn(const GemmParams& p) { return (p.tile_n == 160 && p.N % 160 == 0) ? 160 : pp_bn(p.N); }
@@ -440,6 +561,43 @@ int launch_pp3(const GemmParams& p, hipStream_t s) {
     return MVE_OK;
 }
 
+// The two-blocks-per-CU tile: dense GEMM, whole 256 x 160 tiles, the epilogue configuration pp2_epilogue implements
+bool pp2_eligible(int mode, const GemmParams& p) {
+    if (mode != 0 || p.N % 160 != 0 || p.M % PBM != 0 || p.K % BK != 0) return false;
+    if (p.splitk > 1 || p.splitk_seq > 1 || p.rowvec || p.out_f32 || p.out_scale != 1.0f || (p.residual && p.res_after_scale)) return false;
+    if (p.geglu && (p.ldc % 8 != 0)) return false;
+    if (!p.geglu && p.ldc % 8 != 0) return false;
+    return pp_fits((unsigned long long)p.N * p.ldw * 2) && pp_fits((unsigned long long)p.M * p.lda * 2);
+}
+
+template <class Tag>
+int launch_pp2(const GemmParams& p, hipStream_t s) {
+    static bool configured[64] = {};
+    int dev = 0;
+    MVE_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !configured[dev]) {
+        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pp<Tag, 0, false, 160, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, pp_smem(160, 3)));
+        configured[dev] = true;
+        if (getenv("MVE_DEBUG")) {
+            int nb = -1;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_gemm_pp<Tag, 0, false, 160, false, 3>), PNTH, pp_smem(160, 3));
+            fprintf(stderr, "[mve] k_gemm_pp<160, 3 slots>: %d blocks per CU by the occupancy API (LDS %d B per block)\n", nb, pp_smem(160, 3));
+        }
+    }
+    const unsigned grid = (unsigned)(p.M / PBM) * (unsigned)(p.N / 160);
+    if constexpr (std::is_same<Tag, F16Tag>::value) {
+        if (g_pp_prof_host) {
+            MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pp<Tag, 0, false, 160, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, pp_smem(160, 3)));
+            k_gemm_pp<Tag, 0, false, 160, true, 3><<<grid, PNTH, pp_smem(160, 3), s>>>(p);
+            MVE_LAUNCH_CHECK();
+            return MVE_OK;
+        }
+    }
+    k_gemm_pp<Tag, 0, false, 160, false, 3><<<grid, PNTH, pp_smem(160, 3), s>>>(p);
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
 template <class Tag, int MODE>
 int launch_pp(const GemmParams& p, hipStream_t s) {
     if (pp_bn(p) == 256) return launch_pp3<Tag, MODE, false, 256>(p, s);
@@ -448,8 +606,7 @@ int launch_pp(const GemmParams& p, hipStream_t s) {
     return p.splitk_seq > 1 ? launch_pp3<Tag, MODE, true, 320>(p, s) : launch_pp3<Tag, MODE, false, 320>(p, s);
 }
 
-// every per-lane byte offset must stay below the resource size (and the out-of-range marker above it)
-bool pp_fits(unsigned long long bytes) { return bytes + 65536ull < (unsigned long long)P_NUMREC; }
+int g_pp_old_swizzle = 0;
 
 bool pp_eligible(int mode, const GemmParams& p) {
     const int bn = pp_bn(p);
@@ -476,12 +633,23 @@ extern "C" MVE_API int mve_gemm_pp_profile(void* buf) {
     return MVE_OK;
 }
 
+// A/B aid: 1 = the ring swizzle of round 2 ((row >> 2) & 3: every fragment read 2-way bank conflicted); results are identical either way
+void mve_gemm_pp_old_swizzle(int on) { g_pp_old_swizzle = on ? 1 : 0; }
+
 // ping-pong main loop + epilogue (or split-K partials; the caller runs the reducer).  Returns 1 when the problem is not eligible
 // (the caller falls back to the two-stage kernel), MVE_OK after a launch, < 0 on error.
 int mve_gemm_pp_launch(int dtype, int mode, const void* params, void* stream) {
-    const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
-    if (!pp_eligible(mode, p)) return 1;
+    GemmParams p = *reinterpret_cast<const GemmParams*>(params);
+    p.old_swizzle = g_pp_old_swizzle;
     hipStream_t s = (hipStream_t)stream;
+    if (p.tile_n == 161) {               // the caller asks for the two-blocks-per-CU tile
+        if (!pp2_eligible(mode, p)) return 1;
+        if (dtype == MVE_F16) return launch_pp2<F16Tag>(p, s);
+        if (dtype == MVE_BF16) return launch_pp2<BF16Tag>(p, s);
+        mve_set_error("gemm_pp: unsupported dtype %d", dtype);
+        return MVE_ERR_ARG;
+    }
+    if (!pp_eligible(mode, p)) return 1;
     if (dtype == MVE_F16) return mode == 0 ? launch_pp<F16Tag, 0>(p, s) : launch_pp<F16Tag, 1>(p, s);
     if (dtype == MVE_BF16) return mode == 0 ? launch_pp<BF16Tag, 0>(p, s) : launch_pp<BF16Tag, 1>(p, s);
     mve_set_error("gemm_pp: unsupported dtype %d", dtype);

@@ -50,6 +50,7 @@ struct GemmParams {
                        // `partial`, so the result is bit-identical to split-K + reducer without the reducer's traffic / launch
     int tile_n;        // 256-row ping-pong tile only: 0 = widest width that divides N (320 / 256 / 128); 160 = the 160-wide tile (N % 160 == 0),
                        // which the dispatcher picks when the 320-wide tiling would leave CUs without a block (small batches)
+    int old_swizzle;   // ping-pong tile only, A/B aid: 1 = round 2's ring swizzle (2-way bank conflicts on every fragment read)
     ConvGeom g;
 };
 

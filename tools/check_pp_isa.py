@@ -24,10 +24,14 @@ SRC = os.path.join(ROOT, 'mvedit_amd', 'csrc', 'gemm_pp.hip')
 
 
 def device_asm():
+    # the flags of the shipped object (mvedit_amd/build.py): the checked assembly must be the assembly that is linked
+    sys.path.insert(0, ROOT)
+    from mvedit_amd import build as mve_build
     hipcc = os.environ.get('HIPCC') or '/opt/rocm/bin/hipcc'
+    flags = mve_build.COMMON_FLAGS + mve_build.EXTRA_FLAGS.get(os.path.basename(SRC), [])
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, 'gemm_pp.s')
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-S', '--offload-device-only', SRC, '-o', out]
+        cmd = [hipcc] + flags + ['-S', '--offload-device-only', SRC, '-o', out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed:\n' + r.stderr[-2000:])
