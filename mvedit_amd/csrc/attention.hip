@@ -729,17 +729,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attention3(const AttnParams p)
             if constexpr ((ABL & 256) != 0) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { lo[i] = __builtin_bit_cast(s16x4, u32x2{pb.w[kb][0][i], va0}); up[i] = __builtin_bit_cast(s16x4, u32x2{va0, pb.w[kb][1][i]}); }
-            } else
-            asm volatile("ds_read_b64_tr_b16 %0, %6\n\t"
-                         "ds_read_b64_tr_b16 %1, %6 offset:%7\n\t"
-                         "ds_read_b64_tr_b16 %2, %6 offset:32\n\t"
-                         "ds_read_b64_tr_b16 %3, %6 offset:%8\n\t"
-                         "ds_read_b64_tr_b16 %4, %6 offset:64\n\t"
-                         "ds_read_b64_tr_b16 %5, %6 offset:%9\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(lo[0]), "=&v"(up[0]), "=&v"(lo[1]), "=&v"(up[1]), "=&v"(lo[2]), "=&v"(up[2])
-                         : "v"(va0), "i"(16 * V_ROW), "i"(16 * V_ROW + 32), "i"(16 * V_ROW + 64)
-                         : "memory");
+            } else {
+                // the transpose-read builtin: the compiler counts lgkmcnt itself and lets the first MFMAs start while the later reads are still
+                // in flight (the round-2 asm block waited for all six: +3..4 % on the level-0 self-attention, tools/attn_lab)
+                typedef __attribute__((address_space(3))) s16x4* lp;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    lo[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_ptr_t)(St + v_off + kb * 32 * V_ROW + 32 * i));
+                    up[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_ptr_t)(St + v_off + kb * 32 * V_ROW + 32 * i + 16 * V_ROW));
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const V8 va = __builtin_bit_cast(V8, __builtin_shufflevector(lo[i], up[i], 0, 1, 2, 3, 4, 5, 6, 7));

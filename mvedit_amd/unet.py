@@ -23,6 +23,12 @@ SD15_CONFIG = dict(
     down_attn=(True, True, True, False), num_heads=(8, 8, 8, 8), cross_attention_dim=768, norm_num_groups=32,
     norm_eps=1e-5, transformer_layers=(1, 1, 1, 1), use_linear_projection=False)
 
+# Stable Diffusion 2.1 topology (the Zero123++ base model, lib/pipelines/zero123plus.py): head_dim 64, linear projections, ctx 1024
+SD21_CONFIG = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+    down_attn=(True, True, True, False), num_heads=(5, 10, 20, 20), cross_attention_dim=1024, norm_num_groups=32,
+    norm_eps=1e-5, transformer_layers=(1, 1, 1, 1), use_linear_projection=True)
+
 OP_CLASSES = ('conv3x3', 'linear', 'attention', 'norm', 'other')
 
 

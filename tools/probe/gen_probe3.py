@@ -253,6 +253,57 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 '''
 
+EXTRA = r'''
+// ---- power-limited MFMA peak on RANDOM operands: 16 (or 8) MFMAs per iteration over 4 x 4 different random fragment pairs -----------------
+template <int BIG, int WPS>
+__global__ __launch_bounds__(256 * WPS) void k_mfma_random(unsigned long long* out, const h8* frags, int iters) {
+    const int lane = threadIdx.x & 63;
+    h8 a[4], b[4];
+    for (int i = 0; i < 4; ++i) { a[i] = frags[(i * 64 + lane) & 1023]; b[i] = frags[512 + ((i * 64 + lane) & 511)]; }
+    f4 q[16]; f16v acc[4];
+    for (int i = 0; i < 16; ++i) q[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    __syncthreads();
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (BIG) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(a[i & 3]), "v"(b[(i >> 1) & 3]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(q[i]) : "v"(a[i & 3]), "v"(b[i >> 2]));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += q[i][0] + q[i][3];
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
+    if (s == 1.2345e-30f) out[0] = 1;
+    if (lane == 0) { const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); out[2 * w] = t1 - t0; out[2 * w + 1] = r1 - r0; }
+}
+
+template <int BIG, int WPS>
+void run_random(const char* name, unsigned long long* d_out, const h8* d_frags, int iters) {
+    const int grid = 256, nth = 256 * WPS, nw = grid * nth / 64;
+    k_mfma_random<BIG, WPS><<<grid, nth>>>(d_out, d_frags, iters);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 20; ++r) k_mfma_random<BIG, WPS><<<grid, nth>>>(d_out, d_frags, iters);      // ~10 ms: long enough for the power loop to settle
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+    std::vector<unsigned long long> h(2 * nw);
+    CK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
+    double t = 0, q = 0; for (int w = 0; w < nw; ++w) { t += h[2 * w]; q += h[2 * w + 1]; }
+    const double flops = 2.0 * 131072 * iters * (double)nw;      // 8 MFMA32 or 16 MFMA16 = 131072 MAC per iteration per wave
+    printf("%-46s %d waves/SIMD: %7.1f cycles/iter/wave, clock %5.3f GHz, wall %7.3f ms = %7.1f TFLOP/s\n", name, WPS, t / nw / iters, t / q / 10.0, ms, flops / ms / 1e9);
+}
+'''
+
 MAIN = r'''
 struct Res { double ticks[2], real[2], wall_ms; };
 
@@ -284,7 +335,23 @@ Res run(K kern, int wps, unsigned long long* d_out, int iters) {
 }
 
 int main() {
-    unsigned long long* d_out; CK(hipMalloc(&d_out, 2 * 8 * 256 * 8 * 2));
+    unsigned long long* d_out; CK(hipMalloc(&d_out, 2 * 8 * 256 * 8 * 2 * 2));
+    {   // power-limited MFMA peak: constant-ish operands (the generated streams below) vs random operands
+        std::vector<_Float16> hf(1024 * 8);
+        unsigned sd = 12345u;
+        auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return ((sd >> 8) & 0xFFFF) / 65536.0f; };
+        for (auto& v : hf) { float g = 0; for (int i = 0; i < 4; ++i) g += rnd(); v = (_Float16)((g - 2.0f) * 1.732f); }
+        h8* d_frags; CK(hipMalloc(&d_frags, hf.size() * 2)); CK(hipMemcpy(d_frags, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; ++rep) {
+            run_random<0, 1>("MFMA 16x16x32 f16, random normal operands", d_out, d_frags, 4096);
+            run_random<0, 2>("MFMA 16x16x32 f16, random normal operands", d_out, d_frags, 4096);
+            run_random<1, 1>("MFMA 32x32x16 f16, random normal operands", d_out, d_frags, 4096);
+            run_random<1, 2>("MFMA 32x32x16 f16, random normal operands", d_out, d_frags, 4096);
+        }
+        CK(hipMemset(d_frags, 0, hf.size() * 2));
+        run_random<0, 1>("MFMA 16x16x32 f16, ZERO operands", d_out, d_frags, 4096);
+        run_random<1, 1>("MFMA 32x32x16 f16, ZERO operands", d_out, d_frags, 4096);
+    }
     const int iters = 2048;
     printf("# ticks = s_memtime (shader cycles) per iteration per wave; real = s_memrealtime (10 ns units -> ns) per iteration; clock = ticks / real\n");
     printf("%-14s %-64s %9s %9s %7s | %9s %9s | %8s\n", "kernel", "what", "cyc/it r0", "ns/it r0", "GHz", "cyc/it r1", "ns/it r1", "wall us");
@@ -296,6 +363,7 @@ def main():
     w(HEADER)
     for name, wps, s0, s1, nm, note in KERNELS:
         w(emit_kernel(name, wps, s0, s1) + "\n\n")
+    w(EXTRA)
     w(MAIN)
     for name, wps, s0, s1, nm, note in KERNELS:
         n0 = len(s0)
