@@ -361,6 +361,7 @@ bool gemm_pp_on() {
 }
 // The two-blocks-per-CU 256 x 160 tile (gemm_pp.hip, NSL = 3) for dense GEMMs: mve_gemm_tune bit 26 / MVE_GEMM_PP2 (A/B; bit-identical results)
 int g_gemm_pp2 = -1;
+int g_old_swizzle = 0;
 bool gemm_pp2_on() {
     if (g_gemm_pp2 < 0) {
         const char* e = getenv("MVE_GEMM_PP2");
@@ -449,12 +450,15 @@ int check_common(const GemmParams& p, const char* who) {
 extern "C" {
 
 int mve_gemm_tune(int big_min_blocks) {
-    const int old = gemm_big_min_blocks();
+    // the whole previous word comes back (threshold + option bits), so that old = tune(x); ...; tune(old) restores every switch
+    const int old = gemm_big_min_blocks() | (g_seq_splitk ? 0 : (1 << 29)) | (gemm_pp_on() ? 0 : (1 << 27)) | (gemm_pp2_on() ? (1 << 26) : 0) |
+                    (g_old_swizzle ? (1 << 25) : 0);
     if (big_min_blocks >= 0) {
         g_seq_splitk = (big_min_blocks & (1 << 29)) ? 0 : 1;
         g_gemm_pp = (big_min_blocks & (1 << 27)) ? 0 : 1;
         g_gemm_pp2 = (big_min_blocks & (1 << 26)) ? 1 : 0;
-        mve_gemm_pp_old_swizzle((big_min_blocks >> 25) & 1);
+        g_old_swizzle = (big_min_blocks >> 25) & 1;
+        mve_gemm_pp_old_swizzle(g_old_swizzle);
         g_big_min_blocks = big_min_blocks & ~((3 << 28) | (1 << 27) | (1 << 26) | (1 << 25));
     }
     return old;

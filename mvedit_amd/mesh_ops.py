@@ -3,6 +3,8 @@ import torch
 
 from . import _lib
 
+_WARNED_TEXC_DETACH = False
+
 
 def _inference_only(name, *tensors):
     """Ops whose reference counterparts are differentiable torch expressions but which the optimisation loops never differentiate
@@ -386,6 +388,19 @@ class MeshRenderer:
             texc_da = None
             if self.texture_filter == 'linear-mipmap-linear':                         # :241, :260-261
                 texc_da = interpolate_da(mesh.vt[None], rast, rasterize_db(g['v_clip'], f, rast), mesh.ft)
+            if torch.is_grad_enabled() and (texc.requires_grad or (texc_da is not None and texc_da.requires_grad)):
+                # trainable vertices under a textured mesh: the reference propagates d albedo / d uv through dr.texture; no such kernel is
+                # built here (the shipped pipelines render in_mesh.detach()).  The fetch position is treated as a constant -- the gradient
+                # still reaches the vertices through rasterize / interpolate / antialias and the texture through the fetch -- and says so
+                # once; the public texture() op keeps refusing.
+                global _WARNED_TEXC_DETACH
+                if not _WARNED_TEXC_DETACH:
+                    import warnings
+                    warnings.warn('MeshRenderer.forward: texture coordinates are detached (no gradient w.r.t. uv through the texture fetch); '
+                                  'vertex gradients through the albedo term are missing', stacklevel=2)
+                    _WARNED_TEXC_DETACH = True
+                texc = texc.detach()
+                texc_da = texc_da.detach() if texc_da is not None else None
             albedo = texture(mesh.albedo[None, ..., :3], texc, rast, uv_da=texc_da, filter_mode=self.texture_filter)   # background 0 (:264)
         elif getattr(mesh, 'vc', None) is not None:
             rgba = interpolate(mesh.vc.float()[None] if mesh.vc.dim() == 2 else mesh.vc.float(), rast, f)

@@ -296,6 +296,41 @@ def test_texture_fitting_through_mesh_renderer(lib, filt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('filt', ['linear', 'linear-mipmap-linear'])
+def test_textured_mesh_with_trainable_vertices_renders_and_backpropagates(lib, filt):
+    """A textured mesh (vt + albedo) whose VERTICES require grad (base_mesh_renderer.py:240-264 with a trainable in_mesh): forward must
+    render (the texture coordinates are treated as constants of the fetch, with one warning), the texture and the vertices both receive
+    finite gradients -- the vertices through rasterise / interpolate / antialias -- and the public texture() op still refuses a uv that
+    requires grad."""
+    import warnings
+    from mvedit_amd import mesh_ops
+    from mvedit_amd.mesh_ops import MeshRenderer, Mesh
+    from scene import icosphere, face_atlas
+    v, f = icosphere(3, 0.6)
+    vn = (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+    vt, ft = face_atlas(f)
+    S, nv = 64, 4
+    poses, intr = _clip_positions(v, nv, S)
+    t = lambda a: torch.from_numpy(a).cuda()
+    mr = MeshRenderer(near=0.01, far=100, texture_filter=filt)
+    verts = t(v).clone().requires_grad_(True)
+    tex = torch.rand(64, 64, 3, generator=torch.Generator().manual_seed(2)).cuda().requires_grad_(True)
+    mesh = Mesh(verts, t(f), t(vt), t(ft), vn=t(vn), fn=t(f), albedo=tex)
+    mesh_ops._WARNED_TEXC_DETACH = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        out = mr([mesh], t(poses)[None], t(intr)[None], S, S)['rgba']
+    assert any('texture coordinates are detached' in str(x.message) for x in w)
+    loss = (out[..., :3] ** 2).mean() + out[..., 3].mean()
+    loss.backward()
+    assert torch.isfinite(tex.grad).all() and tex.grad.abs().sum() > 0
+    assert torch.isfinite(verts.grad).all() and verts.grad.abs().sum() > 0
+    uv = torch.rand(1, 8, 8, 2, device='cuda', requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        mesh_ops.texture(tex[None].detach(), uv)
+
+
+@pytest.mark.gpu
 def test_bake_xyz_shading_fun_and_cam_weights_uv(lib):
     """The two remaining public methods of the reference MeshRenderer (base_mesh_renderer.py:397-505) against the oracle pieces."""
     from mvedit_amd.mesh_ops import MeshRenderer, Mesh

@@ -368,6 +368,289 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attn4(const AttnParams p) {
 }
 
 
+// ---- k_attn6: two 32-query blocks per wave (K / V fragments, LDS-DMA and barriers shared) -----------------------------------------------
+template <int NW, int NST, int WPS, int VAR>
+__global__ __launch_bounds__(64 * NW, WPS) void k_attn6(const AttnParams p) {
+    constexpr int D = 40, KB = 64, QB = 64 * NW;      // two 32-query blocks per wave: K / V fragments, DMA and barriers shared
+    constexpr int K_ROW = 80, V_ROW = 96;
+    constexpr int K_BYTES = KB * K_ROW, V_BYTES = KB * V_ROW, STAGE = K_BYTES + V_BYTES;
+    constexpr int N_DMA = STAGE / 1024, K_DMA = K_BYTES / 1024, DMA_PER_WAVE = (N_DMA + NW - 1) / NW;
+    constexpr bool PIPE = (VAR & 1) != 0, TREE = (VAR & 2) != 0, TRB = (VAR & 4) != 0;
+    
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l32 = lane & 31, hi = lane >> 5, l16 = lane & 15, g = lane >> 4;
+    unsigned long long prof_t0 = 0, prof_r0 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_t0), "=s"(prof_r0) :: "memory");
+
+    const int q_tiles = (p.Lq + QB - 1) / QB;
+    const unsigned nblk = (unsigned)(q_tiles * p.heads * p.B);
+    const unsigned bid = mve_xcd_remap(blockIdx.x, nblk);
+    const int qt = bid % q_tiles;
+    const int h = (bid / q_tiles) % p.heads;
+    const int b = bid / (q_tiles * p.heads);
+
+    const T* kb1 = reinterpret_cast<const T*>(p.K) + (size_t)b * p.Lk * p.ldk + h * D;
+    const T* vb1 = reinterpret_cast<const T*>(p.V) + (size_t)b * p.Lk * p.ldv + h * D;
+    const T* ones = reinterpret_cast<const T*>(g_ones_f16);
+
+    const int q_base = qt * QB + wid * 64;
+    V8 qf[2][3];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int q = q_base + qb * 32 + l32;
+        q = q < p.Lq ? q : p.Lq - 1;
+        const T* row = reinterpret_cast<const T*>(p.Q) + ((size_t)b * p.Lq + q) * p.ldq + h * D;
+        qf[qb][0] = __builtin_bit_cast(V8, *reinterpret_cast<const u32x4*>(row + 8 * hi));
+        qf[qb][1] = __builtin_bit_cast(V8, *reinterpret_cast<const u32x4*>(row + 16 + 8 * hi));
+        u32x4 t = {0u, 0u, 0u, 0u};
+        if (hi == 0) t = *reinterpret_cast<const u32x4*>(row + 32);
+        qf[qb][2] = __builtin_bit_cast(V8, t);
+    }
+
+    const int wv = __builtin_amdgcn_readfirstlane(wid);
+    const unsigned smem_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const T* d_src[DMA_PER_WAVE];
+    int d_ld[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int inst = wv + NW * i;
+        const int o = inst * 1024 + lane * 16;
+        if (inst < K_DMA) {
+            const int c = o >> 4;
+            const int key = c / 5, col = (c - key * 5) * 8;
+            d_ld[i] = p.ldk;
+            d_src[i] = kb1 + (size_t)key * p.ldk + col;
+        } else {
+            const int c = (o - K_BYTES) >> 4;
+            const int r = c / 6, col = c - r * 6;
+            const int key = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+            d_ld[i] = col < 5 ? p.ldv : 0;
+            d_src[i] = col < 5 ? vb1 + (size_t)key * p.ldv + col * 8 : ones;
+        }
+    }
+    auto dma = [&](int stage_off) {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int inst = wv + NW * i;
+            if (inst < N_DMA) {
+                attn_dma16(d_src[i], smem_base + stage_off + inst * 1024);
+                d_src[i] += (size_t)KB * d_ld[i];
+            }
+        }
+    };
+    const int n_tiles = p.Lk / KB;                 // lab: Lk % 64 == 0
+    const int n_mine = (N_DMA - wv + NW - 1) / NW;
+
+    const int k_off01 = l32 * K_ROW + hi * 16;
+    const int k_off2 = l32 * K_ROW + 64;
+    const int v_off = K_BYTES + (lane >> 2) * V_ROW + (lane & 3) * 8;
+
+    f32x4 oacc[2][3][2];
+    float m_run[2] = {0.f, 0.f};
+    f32x16 negm[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) oacc[qb][i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
+    }
+
+    struct S2 { f32x16 a, b; };
+    struct PB { unsigned w[2][2][4]; };
+    struct KF { V8 a[3], b[3]; };
+    struct VF { s16x4 lo[2][3], up[2][3]; };
+
+    auto load_k = [&](const unsigned char* St) -> KF {
+        KF k;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int o = st < 2 ? k_off01 + 32 * st : k_off2;
+            k.a[st] = *reinterpret_cast<const V8*>(St + o);
+            k.b[st] = *reinterpret_cast<const V8*>(St + o + 32 * K_ROW);
+        }
+        return k;
+    };
+    auto qk_mfma = [&](const KF& k, int qb) -> S2 {
+        S2 s;
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s.a) : "v"(k.a[0]), "v"(qf[qb][0]), "v"(negm[qb]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s.b) : "v"(k.b[0]), "v"(qf[qb][0]), "v"(negm[qb]));
+#pragma unroll
+        for (int st = 1; st < 3; ++st) {
+            s.a = F16Tag::mfma32(k.a[st], qf[qb][st], s.a);
+            s.b = F16Tag::mfma32(k.b[st], qf[qb][st], s.b);
+        }
+        return s;
+    };
+    auto load_v = [&](const unsigned char* St) -> VF {
+        VF v;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if constexpr (TRB) {
+                typedef __attribute__((address_space(3))) s16x4* lp;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    v.lo[kb][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_ptr_t)(St + v_off + kb * 32 * V_ROW + 32 * i));
+                    v.up[kb][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_ptr_t)(St + v_off + kb * 32 * V_ROW + 32 * i + 16 * V_ROW));
+                }
+            } else {
+                const unsigned va0 = (unsigned)(uintptr_t)(lds_ptr_t)(St + v_off + kb * 32 * V_ROW);
+                asm volatile("ds_read_b64_tr_b16 %0, %6\n\t"
+                             "ds_read_b64_tr_b16 %1, %6 offset:%7\n\t"
+                             "ds_read_b64_tr_b16 %2, %6 offset:32\n\t"
+                             "ds_read_b64_tr_b16 %3, %6 offset:%8\n\t"
+                             "ds_read_b64_tr_b16 %4, %6 offset:64\n\t"
+                             "ds_read_b64_tr_b16 %5, %6 offset:%9\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(v.lo[kb][0]), "=&v"(v.up[kb][0]), "=&v"(v.lo[kb][1]), "=&v"(v.up[kb][1]), "=&v"(v.lo[kb][2]), "=&v"(v.up[kb][2])
+                             : "v"(va0), "i"(16 * V_ROW), "i"(16 * V_ROW + 32), "i"(16 * V_ROW + 64)
+                             : "memory");
+            }
+        }
+        return v;
+    };
+
+    auto softmax_max = [&](S2& s, bool first, int qb) {
+        float mx;
+        if constexpr (TREE) {
+            float t[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = fmaxf(fmaxf(s.a[2 * r], s.a[2 * r + 1]), fmaxf(s.b[2 * r], s.b[2 * r + 1]));
+            mx = fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), fmaxf(fmaxf(t[4], t[5]), fmaxf(t[6], t[7])));
+        } else {
+            mx = fmaxf(s.a[0], s.b[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s.a[r]), s.b[r]);
+        }
+        mx = mve_max_xor32(mx);
+        if (__builtin_expect(first || __any(mx > 0.f), 0)) {
+            const float delta = first ? mx : fmaxf(mx, 0.f);
+            m_run[qb] += delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s.a[r] -= delta; s.b[r] -= delta; negm[qb][r] = -m_run[qb]; }
+            if (!first) {
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+                const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { oacc[qb][i][0][r] *= a0; oacc[qb][i][1][r] *= a1; }
+            }
+        }
+    };
+    auto softmax_exp = [&](const S2& s) -> PB {
+        PB pb;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const f32x16& sk = kb ? s.b : s.a;
+            unsigned pk[8];
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+                const float e0 = __builtin_amdgcn_exp2f(sk[2 * r2]);
+                const float e1 = __builtin_amdgcn_exp2f(sk[2 * r2 + 1]);
+                pk[r2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e0, e1}, T2));
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ai = v < 2 ? v : v + 2;
+                const auto r = __builtin_amdgcn_permlane16_swap(pk[ai], pk[ai + 2], false, false);
+                pb.w[kb][0][v] = r[0];
+                pb.w[kb][1][v] = r[1];
+            }
+        }
+        return pb;
+    };
+    auto pv_mfma = [&](const VF& v, const PB& pb, int qb) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const V8 va = __builtin_bit_cast(V8, __builtin_shufflevector(v.lo[kb][i], v.up[kb][i], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const u32x4 pw = {pb.w[kb][f][0], pb.w[kb][f][1], pb.w[kb][f][2], pb.w[kb][f][3]};
+                    oacc[qb][i][f] = F16Tag::mfma16(va, __builtin_bit_cast(V8, pw), oacc[qb][i][f]);
+                }
+            }
+    };
+
+    auto wait_sync = [&](int keep) {
+        if (keep >= 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    auto next_stage = [&](int off) { return off + STAGE == NST * STAGE ? 0 : off + STAGE; };
+
+    constexpr int PD = NST - 1;
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+        if (i < n_tiles) dma(i * STAGE);
+    asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]));
+
+    {
+        wait_sync(n_mine * ((n_tiles < PD ? n_tiles : PD) - 1));
+        int cur = 0, nxt = PD * STAGE;
+        if (nxt == NST * STAGE) nxt = 0;
+        for (int t = 0; t < n_tiles; ++t) {
+            if (t + PD < n_tiles) dma(nxt);
+            const KF kf = load_k(smem + cur);
+            S2 s0 = qk_mfma(kf, 0);
+            S2 s1 = qk_mfma(kf, 1);
+            const VF vf = load_v(smem + cur);
+            softmax_max(s0, t == 0, 0);
+            const PB pb0 = softmax_exp(s0);
+            pv_mfma(vf, pb0, 0);
+            softmax_max(s1, t == 0, 1);
+            const PB pb1 = softmax_exp(s1);
+            pv_mfma(vf, pb1, 1);
+            const int last_issued = t + PD < n_tiles ? t + PD : n_tiles - 1;
+            wait_sync(last_issued > t + 1 ? n_mine * (last_issued - (t + 1)) : 0);
+            nxt = cur;
+            cur = next_stage(cur);
+        }
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const float l = __shfl(oacc[qb][2][f][0], 32 + l16, 64);
+        const float inv = 1.0f / l;
+        const int q = q_base + qb * 32 + f * 16 + l16;
+        if (q < p.Lq) {
+            T* orow = reinterpret_cast<T*>(p.O) + ((size_t)b * p.Lq + q) * p.ldo + h * D;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int dv = i * 16 + g * 4;
+                if (dv < D) {
+                    T4 o4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o4[r] = (T)(oacc[qb][i][f][r] * inv);
+                    *reinterpret_cast<T4*>(orow + dv) = o4;
+                }
+            }
+        }
+    }
+    {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+        if (lane == 0 && (blockIdx.x & 63) == 5 && p.prof) {
+            atomicAdd(&p.prof[0], t1 - prof_t0);
+            atomicAdd(&p.prof[1], r1 - prof_r0);
+            atomicAdd(&p.prof[2], 1ull);
+        }
+    }
+}
+
+
+
 // ---- k_attn5: P V on v_mfma_f32_32x32x16 as well -----------------------------------------------------------------------------------------
 // O^T[dv][q] += V^T[dv][key] P^T[key][q] with the SAME 32x32 shape as S^T: the B operand P^T wants lane (q = lane & 31, hi) to hold 8 keys of
 // a 16-key step, and that is exactly what the S^T accumulator holds after packing pairs (step s of key block kb = registers 8 s .. 8 s + 7 =
@@ -667,8 +950,8 @@ static void run_variant(const char* name, const Problem& small, const float* ref
     {
         AttnParams p = params_of(small, nullptr);
         CK(hipMemset(small.o, 0, small.n * 2));
-        const unsigned grid = (unsigned)(((p.Lq + 32 * NW - 1) / (32 * NW)) * p.heads * p.B);
-        if (KID == 4) k_attn4<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else k_attn5<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p);
+        const int qpb = (KID == 6 ? 64 : 32) * NW; const unsigned grid = (unsigned)(((p.Lq + qpb - 1) / qpb) * p.heads * p.B);
+        if (KID == 4) k_attn4<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else if (KID == 5) k_attn5<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else k_attn6<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p);
         CK(hipDeviceSynchronize());
         std::vector<T> h(small.n);
         CK(hipMemcpy(h.data(), small.o, small.n * 2, hipMemcpyDeviceToHost));
@@ -686,14 +969,14 @@ static void run_variant(const char* name, const Problem& small, const float* ref
     }
     {
         AttnParams p = params_of(big, d_prof);
-        const unsigned grid = (unsigned)(((p.Lq + 32 * NW - 1) / (32 * NW)) * p.heads * p.B);
-        if (KID == 4) k_attn4<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else k_attn5<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p);
+        const int qpb = (KID == 6 ? 64 : 32) * NW; const unsigned grid = (unsigned)(((p.Lq + qpb - 1) / qpb) * p.heads * p.B);
+        if (KID == 4) k_attn4<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else if (KID == 5) k_attn5<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else k_attn6<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p);
         CK(hipDeviceSynchronize());
         CK(hipMemset(d_prof, 0, 32));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int it = 10;
         CK(hipEventRecord(e0));
-        for (int i = 0; i < it; ++i) { if (KID == 4) k_attn4<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else k_attn5<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); }
+        for (int i = 0; i < it; ++i) { if (KID == 4) k_attn4<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else if (KID == 5) k_attn5<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); else k_attn6<NW, NST, WPS, VAR><<<grid, 64 * NW>>>(p); }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
         unsigned long long pr[4];
@@ -721,15 +1004,11 @@ int main(int argc, char** argv) {
     for (int r = 0; r < rounds; ++r) {
 #define RUN(KID, NW, NST, WPS, VAR) run_variant<KID, NW, NST, WPS, VAR>("k" #KID " NW" #NW " NST" #NST " WPS" #WPS " VAR" #VAR, small, ref.data(), big, d_prof)
         RUN(4, 8, 2, 4, 4);
-        RUN(5, 8, 2, 4, 0);
-        RUN(5, 8, 2, 4, 2);
-        RUN(5, 8, 2, 4, 8);
-        RUN(5, 8, 2, 3, 0);
-        RUN(5, 8, 2, 3, 8);
-        RUN(5, 8, 3, 3, 8);
-        RUN(5, 4, 2, 4, 0);
-        RUN(5, 4, 2, 3, 8);
-        RUN(5, 8, 2, 2, 8);
+        RUN(6, 4, 2, 2, 4);
+        RUN(6, 4, 3, 2, 4);
+        RUN(6, 8, 2, 2, 4);
+        RUN(6, 4, 2, 2, 6);
+        RUN(6, 2, 2, 2, 4);
 #undef RUN
     }
     return 0;
