@@ -804,6 +804,51 @@ MVE_API int mve_antialias_backward_pos(const float* d_color, const float* d_grad
                                        const float* d_pos, int V, const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_pos,
                                        void* stream);
 
+/* TRACER-B7 foreground segmentor (lib/models/segmentors/tracer_b7.py:16-73, called once per denoise step from
+ * lib/pipelines/adapter3d_mixin.py:14-19; EfficientNet-B7 encoder lib/models/architecture/tracerb7/efficientnet.py + TRACER decoder
+ * tracer.py / att_modules.py / conv_modules.py): the operators the GEMM / 3x3-conv entry points do not cover.  Activations are NHWC
+ * 16-bit ([B, H, W, C] contiguous: a 1x1 convolution is mve_gemm on [B*H*W, C]); single-channel decoder maps are fp32; BatchNorm
+ * arrives folded into weights + bias (mvedit_amd/segmentor.py folds it when the state dict is loaded).  act: 0 none, 1 swish,
+ * 2 SELU, 3 ReLU, 4 sigmoid.
+ *   seg_conv2d      : nn.Conv2d with groups = C (depthwise = 1: weights [kh][kw][C] f32; the _depthwise_conv of MBConvBlock,
+ *                     efficientnet.py:66-75, with the STATIC TensorFlow-"SAME" padding of effi_utils.py:270-315 passed as explicit
+ *                     top / left padding, and DWConv / DWSConv of conv_modules.py:42-88) or groups = 1 (weights [Cout][kh][kw][Cin] f32:
+ *                     BasicConv2d with 1xk / kx1 / dilated kernels, conv_modules.py:11-39, att_modules.py:16-41).  out = act(conv + bias)
+ *                     [* mul] [+ add]; x / out / mul / add rows are ldx / ldo / ld2 channels wide (channel slices of wider tensors).
+ *   seg_act         : in-place activation of a GEMM / conv3x3 output (the swish / SELU behind a BatchNorm).
+ *   seg_channel_mean: F.adaptive_avg_pool2d(x, 1) / GlobalAvgPool -> f32 [B][C].
+ *   seg_se_gate     : sigmoid(_se_expand(swish(_se_reduce(pooled)))) (efficientnet.py:124-129), w1 [S][C], w2 [C][S] f32.
+ *   seg_scale       : x = src * A[b][c] (+ S[b][c]) -- the SE gating; UnionAttentionModule's x * att + x, BatchNorm and confidence mask.
+ *   seg_resize      : bilinear F.interpolate / torchvision Resize(antialias=False) (align_corners flag); in_mode 0: NHWC dtype, 1: NHWC
+ *                     f32, 2: NCHW f32; optional (x - mean[c]) / std[c] (transforms.Normalize, tracer_b7.py:39-44).
+ *   seg_uam_channel : UnionAttentionModule.channel_tracer + masking (att_modules.py:135-168) on the pooled vector; C <= 256.  Outputs the
+ *                     sigmoid gate att and the per-(image, channel) affine A, S with BatchNorm(x * att + x) * mask = x * A + S (:163-174).
+ *   seg_mul         : elementwise x * y (* z) (Aggregation.forward's gating products, att_modules.py:226-233).
+ *   seg_uam_spatial : the spatial SDPA of UnionAttentionModule.forward (:176-187) over qkv [B][H*W][3] f32.
+ *   seg_object_mix  : ObjectAttention's masked encoder map (att_modules.py:277-282).
+ *   seg_fuse        : sigmoid((up4(d2) + up8(d1) + up8(d0)) / 3) (tracer.py:86-97).
+ *   seg_post        : -max_pool2d(-m, 2 e + 1), resize to [Ho][Wo], failure rule (tracer_b7.py:66-72); out [B][Ho][Wo] dtype or f32. */
+MVE_API int mve_seg_conv2d(int dtype, const void* d_x, int B, int H, int W, int Cin, int ldx, const float* d_w, const float* d_bias, void* d_out,
+                           int Ho, int Wo, int Cout, int ldo, int kh, int kw, int stride, int pad_t, int pad_l, int dil, int depthwise, int act,
+                           const void* d_mul, const void* d_add, int ld2, int out_f32, void* stream);
+MVE_API int mve_seg_act(int dtype, void* d_x, size_t n, int act, void* stream);
+MVE_API int mve_seg_channel_mean(int dtype, const void* d_x, int B, int HW, int C, float* d_out, void* stream);
+MVE_API int mve_seg_se_gate(const float* d_pooled, int B, int C, int S, const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2,
+                            float* d_gate, void* stream);
+MVE_API int mve_seg_scale(int dtype, void* d_x, const void* d_src, int B, int HW, int C, const float* d_A, const float* d_S, void* stream);
+MVE_API int mve_seg_resize(int dtype, const void* d_x, int B, int H, int W, int C, void* d_out, int Ho, int Wo, int align_corners, int in_mode,
+                           int out_f32, const float* d_mean, const float* d_std, void* stream);
+MVE_API int mve_seg_uam_channel(const float* d_pooled, int B, int C, const float* d_ns, const float* d_nb, const float* d_wq, const float* d_wk,
+                                const float* d_wv, const float* d_wfc, float ratio, const float* d_bn_scale, const float* d_bn_shift, float* d_att,
+                                float* d_A, float* d_S, void* stream);
+MVE_API int mve_seg_mul(int dtype, const void* d_x, const void* d_y, const void* d_z, void* d_out, size_t n, void* stream);
+MVE_API int mve_seg_uam_spatial(const float* d_qkv, int B, int H, int W, float* d_out, void* stream);
+MVE_API int mve_seg_object_mix(int dtype, const float* d_map, const void* d_enc, void* d_out, int B, int HW, int C, void* stream);
+MVE_API int mve_seg_fuse(const float* d_d0, const float* d_d1, const float* d_d2, int B, int Hs, int Ws, float* d_out, void* stream);
+MVE_API size_t mve_seg_post_workspace_bytes(int B, int Hs, int Ws, int Ho, int Wo);
+MVE_API int mve_seg_post(int dtype, const float* d_m, int B, int Hs, int Ws, int erosion, void* d_out, int Ho, int Wo, int out_f32,
+                         void* d_workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

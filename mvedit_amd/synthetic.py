@@ -241,3 +241,89 @@ def make_srvgg_state_dict(seed=99, dtype=torch.float32, **kw):
             t = torch.randn(shape, generator=g) * math.sqrt(1.6 / (shape[1] * 9))
         sd[name] = t.to(dtype)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# TRACER-B7 segmentor (lib/models/segmentors/tracer_b7.py): the reference modules' parameter names (num_batches_tracked left out)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def tracer_param_shapes():
+    from .segmentor import block_table, _round_filters, RFB_CH, FEAT_CH
+    s = {}
+
+    def bn(name, c):
+        for p in ('weight', 'bias', 'running_mean', 'running_var'):
+            s[f'{name}.{p}'] = (c,)
+
+    def basic(name, cin, cout, k):
+        kh, kw = (k, k) if isinstance(k, int) else k
+        s[f'{name}.conv.weight'] = (cout, cin, kh, kw)
+        bn(f'{name}.bn', cout)
+
+    _, blocks = block_table()
+    s['encoder._conv_stem.weight'] = (_round_filters(32), 3, 3, 3)
+    bn('encoder._bn0', _round_filters(32))
+    for n, (k, st, e, cin, cout, se, pad) in enumerate(blocks):
+        b, mid = f'encoder._blocks.{n}', cin * e
+        if e != 1:
+            s[f'{b}._expand_conv.weight'] = (mid, cin, 1, 1)
+            bn(f'{b}._bn0', mid)
+        s[f'{b}._depthwise_conv.weight'] = (mid, 1, k, k)
+        bn(f'{b}._bn1', mid)
+        s[f'{b}._se_reduce.weight'] = (se, mid, 1, 1)
+        s[f'{b}._se_reduce.bias'] = (se,)
+        s[f'{b}._se_expand.weight'] = (mid, se, 1, 1)
+        s[f'{b}._se_expand.bias'] = (mid,)
+        s[f'{b}._project_conv.weight'] = (cout, mid, 1, 1)
+        bn(f'{b}._bn2', cout)
+    for name, cin, c in (('rfb2', FEAT_CH[1], RFB_CH[0]), ('rfb3', FEAT_CH[2], RFB_CH[1]), ('rfb4', FEAT_CH[3], RFB_CH[2])):
+        basic(f'{name}.branch0.0', cin, c, 1)
+        for br, kk in ((1, 3), (2, 5), (3, 7)):
+            basic(f'{name}.branch{br}.0', cin, c, 1)
+            basic(f'{name}.branch{br}.1', c, c, (1, kk))
+            basic(f'{name}.branch{br}.2', c, c, (kk, 1))
+            basic(f'{name}.branch{br}.3', c, c, 3)
+        basic(f'{name}.conv_cat', 4 * c, c, 3)
+        basic(f'{name}.conv_res', cin, c, 1)
+    c0, c1, c2 = RFB_CH
+    for n, ci, co in (('conv_upsample1', c2, c1), ('conv_upsample2', c2, c0), ('conv_upsample3', c1, c0), ('conv_upsample4', c2, c2),
+                      ('conv_upsample5', c2 + c1, c2 + c1), ('conv_concat2', c2 + c1, c2 + c1), ('conv_concat3', c0 + c1 + c2, c0 + c1 + c2)):
+        basic(f'agg.{n}', ci, co, 3)
+    ct = c0 + c1 + c2
+    bn('agg.UAM.bn', ct)
+    bn('agg.UAM.norm.0', ct)
+    for n in ('channel_q', 'channel_k', 'channel_v', 'fc'):
+        s[f'agg.UAM.{n}.weight'] = (ct, ct, 1, 1)
+    for n in ('spatial_q', 'spatial_k', 'spatial_v'):
+        s[f'agg.UAM.{n}.weight'] = (1, ct, 1, 1)
+    for name, ch in (('ObjectAttention2', FEAT_CH[1]), ('ObjectAttention1', FEAT_CH[0])):
+        h = ch // 2
+        s[f'{name}.DWSConv.DWConv.weight'] = (ch, 1, 3, 3)
+        bn(f'{name}.DWSConv.bn', ch)
+        s[f'{name}.DWSConv.PWConv.weight'] = (h, ch, 1, 1)
+        bn(f'{name}.DWSConv.bn2', h)
+        for i, k in ((1, 1), (2, 3), (3, 3), (4, 3)):
+            s[f'{name}.DWConv{i}.0.DWConv.weight'] = (h, 1, k, k)
+            bn(f'{name}.DWConv{i}.0.bn', h)
+            basic(f'{name}.DWConv{i}.1', h, ch // 8, 1)
+        basic(f'{name}.conv1', h, 1, 1)
+    return s
+
+
+def make_tracer_state_dict(seed=0, dtype=torch.float32):
+    """Seeded stand-in for the Carve/tracer_b7 checkpoint (not reachable offline): variance-preserving convolutions and BatchNorm
+    statistics near the identity keep the 55-block encoder's activations in range."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shape in tracer_param_shapes().items():
+        if name.endswith('running_var'):
+            t = 1.0 + 0.3 * torch.rand(shape, generator=g)
+        elif name.endswith('running_mean'):
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith('.bias'):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = torch.randn(shape, generator=g) * math.sqrt(1.7 / (shape[1] * shape[2] * shape[3]))
+        out[name] = t.to(dtype)
+    return out

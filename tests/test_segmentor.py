@@ -1,0 +1,105 @@
+"""TRACER-B7 foreground segmentor (second half): lib/models/segmentors/tracer_b7.py:16-73 over
+lib/models/architecture/tracerb7/.  CPU: the oracle restatement equals the outputs of the REFERENCE modules executed from /root/reference
+(tests/golden/tracer_ref.npz, written by tests/golden/make_tracer_golden.py) bit for bit in fp32; the product's synthetic state dict is the
+oracle's inventory.  GPU: the HIP engine (mvedit_amd.segmentor, kernels csrc/tracer.hip + mve_gemm + mve_conv3x3) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tracer_oracle as T
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tracer_ref.npz')
+
+
+def _img(sd, x, size):
+    import torch.nn.functional as F
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return (F.interpolate(x, size=(size, size), mode='bilinear', align_corners=False) - mean) / std
+
+
+def test_oracle_equals_reference_executed_golden():
+    g = np.load(GOLD)
+    sd = T.random_params(seed=11)
+    sdf = {k: v.float() for k, v in sd.items()}
+    ident = lambda t: t
+    for tag, size in (('s192', 192), ('s256', 256)):
+        x = torch.from_numpy(g[f'{tag}_x'])
+        with torch.no_grad():
+            mask = T.forward(sd, x, input_image_size=size, erosion=1, batch_size=2)
+            feats = T.encoder(sdf, _img(sd, x[:2], size), ident)
+            raw = T.decoder(sdf, feats, ident)
+        assert torch.equal(mask, torch.from_numpy(g[f'{tag}_mask'])), tag            # whole wrapper incl. erosion, resize, failure rule
+        assert torch.equal(raw, torch.from_numpy(g[f'{tag}_raw']))
+        for i, f in enumerate(feats):
+            assert torch.equal(f[:, :8], torch.from_numpy(g[f'{tag}_feat{i}']))
+            st = g[f'{tag}_feat{i}_stat']
+            assert abs(float(f.mean()) - st[0]) < 1e-6 and abs(float(f.std()) - st[1]) < 1e-6
+        assert 0.2 < float(raw.max() - raw.min()), 'the seeded network must not collapse to a constant mask'
+
+
+def test_block_table_and_inventory():
+    from mvedit_amd import segmentor as SG, synthetic as S
+    assert SG.block_table() == T.block_table()
+    stem_pad, blocks = T.block_table()
+    assert stem_pad == (0, 1) and len(blocks) == 55
+    assert [blocks[i][4] for i in T.FEATURE_BLOCKS] == list(T.FEAT_CH)
+    # the stride-2 stages: 300 -> 150 (k3: pad 0/1), 150 -> 75 (k5: 1/2), 75 -> 38 (k3 on an odd size: 1/1), 38 -> 19 (k5: 1/2)
+    s2 = [(b[0], b[6]) for b in blocks if b[1] == 2]
+    assert s2 == [(3, (0, 1)), (5, (1, 2)), (3, (1, 1)), (5, (1, 2))], s2
+    a, b = S.make_tracer_state_dict(3), T.random_params(3)
+    assert list(a.keys()) == list(b.keys()) and all(torch.equal(a[k], b[k]) for k in a)
+    assert sum(v.numel() for v in a.values()) > 66e6                               # EfficientNet-B7 + decoder: 66 M parameters
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_engine_vs_oracle(lib, dtype):
+    """The engine's raw sigmoid map and final masks against the fp32 oracle and against the oracle with 16-bit rounding at every layer
+    boundary (what the reference's `.to(dtype)` module computes): the engine rounds less often (BatchNorm folded, fused activations), so it
+    must be at least as close to fp32 as the emulated module, and within a small absolute bar of it (masks live in [0, 1])."""
+    from mvedit_amd.segmentor import TracerUniversalB7Engine
+    from mvedit_amd import synthetic as S
+    sd = S.make_tracer_state_dict(11)
+    g = np.load(GOLD)
+    x = torch.from_numpy(g['s192_x'])
+    size = 192
+    sdq = {k: v.to(dtype).float() for k, v in sd.items()}
+    q = lambda t: t.to(dtype).float()
+    with torch.no_grad():
+        img = _img(sd, x, size)
+        raw32 = T.model({k: v.float() for k, v in sd.items()}, img)
+        raw16 = T.model(sdq, img, q)
+        mask32 = T.forward(sd, x, input_image_size=size, erosion=1, batch_size=2)
+        pre32 = T.forward(sd, x, input_image_size=size, erosion=1, batch_size=2, failure_rule=False)
+    eng = TracerUniversalB7Engine(input_image_size=size, batch_size=2, torch_dtype=dtype, erosion=1).load_state_dict(sd)
+    raw = eng.raw_mask(x.cuda()).float().cpu()[:, None]
+    assert raw.shape == raw32.shape and torch.isfinite(raw).all()
+    e_eng, e_emu = float((raw - raw32).abs().max()), float((raw16 - raw32).abs().max())
+    m_eng, m_emu = float((raw - raw32).abs().mean()), float((raw16 - raw32).abs().mean())
+    print(f'{dtype}: raw map max|engine - fp32| {e_eng:.2e} (emulated 16-bit module {e_emu:.2e}); mean {m_eng:.2e} ({m_emu:.2e})')
+    assert m_eng <= 1.5 * m_emu + 2e-3, (m_eng, m_emu)
+    assert e_eng <= 3 * e_emu + 2e-2, (e_eng, e_emu)
+    masks = eng(x.cuda()).float().cpu()
+    assert masks.shape == mask32.shape and masks.dtype == torch.float32
+    # masks: the failure rule zeroes pixels below 0.8 -- a pixel within rounding of the threshold may fall on either side; compare away from it
+    assert float(pre32.min()) > 0.25, 'every pixel of the seeded network is above 0.2: the failure rule applies to all images (both sides must agree)'
+    diff = (masks - mask32).abs()
+    near = (pre32 - 0.8).abs() < 0.05
+    assert float(diff[~near].max()) <= 3 * e_emu + 3e-2, float(diff[~near].max())
+    assert float(near.float().mean()) < 0.5
+
+
+@pytest.mark.gpu
+def test_engine_batch_chunks_and_shapes(lib):
+    """batch_size chunking (tracer_b7.py:63) gives the same masks as one chunk; non-square callers' sizes are restored."""
+    from mvedit_amd.segmentor import TracerUniversalB7Engine
+    from mvedit_amd import synthetic as S
+    sd = S.make_tracer_state_dict(5)
+    x = torch.rand(3, 3, 100, 140, generator=torch.Generator().manual_seed(1))
+    a = TracerUniversalB7Engine(input_image_size=128, batch_size=8, torch_dtype='bfloat16').load_state_dict(sd)(x.cuda())
+    b = TracerUniversalB7Engine(input_image_size=128, batch_size=2, torch_dtype='bfloat16').load_state_dict(sd)(x.cuda())
+    assert a.shape == (3, 1, 100, 140) and a.dtype == torch.bfloat16
+    assert torch.equal(a, b)

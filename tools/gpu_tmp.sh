@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 600 python tools/ab_deep_conv.py 64 > gpurun_out/r03_ab_deep_conv.log 2>&1; echo "rc=$?"; grep -v amdgpu gpurun_out/r03_ab_deep_conv.log
+timeout 900 python -m pytest tests/test_segmentor.py -m gpu -x -q -s -p no:cacheprovider 2>&1 | tail -40 | cut -c1-400 | tee gpurun_out/r03_segmentor_tests.log
