@@ -295,6 +295,13 @@ def secondary(dev):
         t = timed(lambda: enh(lo_res), it=2)
         fl = enh.plan(VIEWS, side, side, torch.float16)['flops']['conv']
         out[f'image_enhancer_{side}'] = dict(ms=round(t * 1e3, 2), views=VIEWS, ms_per_view=round(t * 1e3 / VIEWS, 3), tflops_per_s=round(fl / t / 1e12, 1))
+    del enh
+    # ---- TRACER-B7 foreground masks of the V denoised views (adapter3d_mixin.py:14-19 -> tracer_b7.py:56-73; 640^2 input, chunks of 8, bf16) ----
+    from mvedit_amd.segmentor import TracerUniversalB7Engine
+    seg = TracerUniversalB7Engine(input_image_size=640, batch_size=8, torch_dtype='bfloat16', erosion=1, device=dev).load_state_dict(SY.make_tracer_state_dict(3))
+    views = torch.rand(VIEWS, 3, 8 * LATENT, 8 * LATENT, device=dev)
+    t = timed(lambda: seg(views), it=2)
+    out['tracer_b7_masks'] = dict(ms=round(t * 1e3, 2), views=VIEWS, ms_per_view=round(t * 1e3 / VIEWS, 3), input=640)
     return out
 
 

@@ -23,6 +23,14 @@ from ..unet import unet_dec, unet_enc
 class Adapter3DMixin:
     fuse_chunks = True
 
+    def get_tgt_masks(self, tgt_images, seg_padding):
+        """lib/pipelines/adapter3d_mixin.py:14-19: foreground masks of the denoised views ([1, V, H, W, 3] -> [1, V, H, W, 1]) from
+        `self.segmentation` (mvedit_amd.segmentor.TracerUniversalB7Engine) with the pipeline's background colour override."""
+        from .utils import do_segmentation
+        tgt_images = tgt_images.squeeze(0).clip(min=0, max=1).permute(0, 3, 1, 2)
+        images_masked = do_segmentation(tgt_images, self.segmentation, padding=seg_padding, bg_color=self.bg_color)
+        return images_masked[:, 3][None, ..., None]
+
     def _unet_chunk(self, latent, prompt_embeds, ctrl_images, ctrl_depths, extra_control, t, tile_weight, depth_weight,
                     added_cond_kwargs):
         """One chunk of the reference loop body (adapter3d_mixin.py:85-128)."""

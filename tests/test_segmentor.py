@@ -103,3 +103,40 @@ def test_engine_batch_chunks_and_shapes(lib):
     b = TracerUniversalB7Engine(input_image_size=128, batch_size=2, torch_dtype='bfloat16').load_state_dict(sd)(x.cuda())
     assert a.shape == (3, 1, 100, 140) and a.dtype == torch.bfloat16
     assert torch.equal(a, b)
+
+
+def test_do_segmentation_host_logic_equals_reference_function():
+    """mvedit_amd.pipelines.utils.do_segmentation / Adapter3DMixin.get_tgt_masks against the reference's own functions EXECUTED
+    (lib/pipelines/utils.py:73-107, adapter3d_mixin.py:14-19, cut out with ast) over a stand-in segmentor; skipped where /root/reference is absent."""
+    import ast
+    import types
+    import torch.nn.functional as F
+    ref = '/root/reference/lib/pipelines/utils.py'
+    if not os.path.exists(ref):
+        pytest.skip('reference tree not present (GPU box)')
+    ns = dict(np=np, torch=torch, F=F)
+    for node in ast.parse(open(ref).read()).body:
+        if isinstance(node, ast.FunctionDef) and node.name == 'do_segmentation':
+            exec(compile(ast.Module([node], []), ref, 'exec'), ns)
+    from mvedit_amd.pipelines.utils import do_segmentation
+    from mvedit_amd.pipelines.adapter3d_mixin import Adapter3DMixin
+
+    class Seg(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([0.6, -0.2, 0.4]))
+
+        def forward(self, x):
+            return torch.sigmoid((x * self.w.view(1, 3, 1, 1)).sum(1, keepdim=True) * 3 - 1)
+    seg = Seg()
+    x = torch.rand(3, 3, 20, 24, generator=torch.Generator().manual_seed(0))
+    x[0, :, :8] = 1.0                                    # a white (background-coloured) band
+    for pad, bg in ((0, None), (4, None), (3, (1.0, 1.0, 1.0))):
+        want = ns['do_segmentation'](x, seg, padding=pad, bg_color=bg)
+        got = do_segmentation(x, seg, padding=pad, bg_color=bg)
+        assert torch.equal(got, want), (pad, bg)
+    host = types.SimpleNamespace(segmentation=seg, bg_color=(1.0, 1.0, 1.0))
+    imgs = x.permute(0, 2, 3, 1)[None] * 1.2 - 0.1
+    got = Adapter3DMixin.get_tgt_masks(host, imgs, 3)
+    want = ns['do_segmentation'](imgs.squeeze(0).clip(min=0, max=1).permute(0, 3, 1, 2), seg, padding=3, bg_color=(1.0, 1.0, 1.0))[:, 3][None, ..., None]
+    assert torch.equal(got, want) and got.shape == (1, 3, 20, 24, 1)

@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_segmentor.py -m gpu -x -q -s -p no:cacheprovider 2>&1 | tail -40 | cut -c1-400 | tee gpurun_out/r03_segmentor_tests.log
+timeout 900 python bench.py --secondary-only 2>gpurun_out/r03_secondary.err | tee gpurun_out/r03_secondary.log | cut -c1-3000; tail -3 gpurun_out/r03_secondary.err
