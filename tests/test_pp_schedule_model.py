@@ -22,8 +22,9 @@ Hazards:
 import pytest
 
 
-def schedule(nsteps, R, D, W):
-    """-> (reads, issues, waits): lists of (interval, group, step); prologue events carry interval -1"""
+def schedule(nsteps, R, D, W, issue_in='M'):
+    """-> (reads, issues, waits): lists of (interval, group, step); prologue events carry interval -1.
+    issue_in = 'L': the pieces of step k + D leave at the TOP of L(k) instead of in M(k) (the three-slot kernel, NSL = 3)"""
     reads, issues, waits = [], [], []
     for g in (0, 1):
         for s in range(D):
@@ -33,12 +34,12 @@ def schedule(nsteps, R, D, W):
             tl, tm = 2 * k + g, 2 * k + g + 1
             reads.append((tl, g, k))
             waits.append((tl, g, k + W))
-            issues.append((tm, g, k + D))
+            issues.append((tm if issue_in == 'M' else tl, g, k + D))
     return reads, issues, waits
 
 
-def hazards(nsteps, R, D, W):
-    reads, issues, waits = schedule(nsteps, R, D, W)
+def hazards(nsteps, R, D, W, issue_in='M'):
+    reads, issues, waits = schedule(nsteps, R, D, W, issue_in)
     errs = []
     wait_at = {(g, s): t for t, g, s in waits}
     issue_at = {(g, s): t for t, g, s in issues}
@@ -56,7 +57,7 @@ def hazards(nsteps, R, D, W):
             errs.append(f'WAR: group {g} issues step {s} into slot {s % R} in interval {t}, step {prev} is read there until {last_read[prev]}')
     for (g, s), w in wait_at.items():                       # program order of issue and wait inside a wave, and the vmcnt count
         i = issue_at.get((g, s))
-        if i is None or i > w or (i == w and i >= 0):      # (L comes before M inside an interval pair: an issue in M(k) is after L(k)'s wait)
+        if i is None or i > w or (i == w and i >= 0 and issue_in == 'M'):   # (an issue in M(k) is after L(k)'s wait; one at the top of L(k) before it)
             errs.append(f'order: group {g} waits for step {s} in {w} but issues it in {i}')
         in_flight = sum(1 for (gg, ss), ii in issue_at.items() if gg == g and ss > s and (ii < w or ii == -1))
         if w >= 0 and in_flight != D - W - 1:
@@ -68,6 +69,18 @@ def test_shipped_schedule_is_hazard_free():
     # ring of 4 slots, distance 3, wait for the next step: what csrc/gemm_pp.hip does (wait_keep1 leaves exactly one step in flight)
     for n in (2, 3, 10, 57, 360):
         assert hazards(n, R=4, D=3, W=1) == [], hazards(n, 4, 3, 1)[:3]
+
+
+def test_three_slot_schedule_is_hazard_free():
+    # NSL = 3 (two blocks per CU): ring of 3 slots, pieces of step k + 2 leave at the top of L(k), wait for step k + 1 at its end with one
+    # step (k + 2) still in flight -- pp_wait_vm<NPM>
+    for n in (2, 3, 10, 57, 360):
+        assert hazards(n, R=3, D=2, W=1, issue_in='L') == [], hazards(n, 3, 2, 1, 'L')[:3]
+    # the same ring with the four-slot kernel's distance, or the issue one step further ahead, is not
+    assert any(e.startswith('WAR') for e in hazards(40, 3, 3, 1, 'L'))
+    assert any(e.startswith('WAR') for e in hazards(40, 2, 2, 1, 'L'))
+    # issued in M(k) with distance 2 is safe as well, but nothing is in flight at the wait (D - W - 1 = 0: the first version, DMA latency exposed)
+    assert hazards(40, 3, 2, 1, 'M') == []
 
 
 @pytest.mark.parametrize('R,D,W,kind', [
