@@ -450,6 +450,29 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
 
+    # the step's collectives on their own (outside the timed region; N > 1 only): the all-gather of the views' maps that every step performs
+    # and the drift-guard broadcast of the scene (parallel.sync_scene, ~56 MiB, once per OUTER step -- a second collective beyond
+    # north_star's one), so that a scaling projection can carry them
+    collectives = None
+    if use_dist and shards:
+        def timed(fn, n=10):
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n * 1e3
+        scene = torch.empty(56 << 20, dtype=torch.uint8, device=dev)
+        ag = timed(lambda: dist.all_gather_into_tensor(gathered, maps_local))
+        bc = timed(lambda: dist.broadcast(scene, src=0))
+        tc = torch.tensor([ag, bc], device=dev, dtype=torch.float64)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        collectives = dict(all_gather_ms=round(float(tc[0]), 3), all_gather_bytes=int(gathered.numel() * gathered.element_size()),
+                           sync_scene_broadcast_ms=round(float(tc[1]), 3), sync_scene_bytes=56 << 20,
+                           note='max over ranks, 10 back-to-back calls each, outside the timed steps (the all-gather is also inside them)')
+
     # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------------------------
     roof = None
     breakdown = {}
@@ -502,6 +525,8 @@ def main():
             'rccl_world': dist.get_world_size() if use_dist else 1,
             'roofline': roof,
         }
+        if collectives is not None:
+            line['collectives'] = collectives
         if sampler is not None and sampler.summary() is not None:
             line['power'] = sampler.summary()
         if world == 1 and roof is not None:

@@ -258,6 +258,10 @@ MVE_API int mve_attention_prescaled(int dtype, const void* d_Q, int ldq, const v
  * gamma/beta: [C1+C2] f32.  d_workspace: >= mve_groupnorm_workspace_bytes(B,HW,C,G) bytes.
  * (ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out of diffusers 0.27.2,
  * reached from lib/models/architecture/diffusers.py:86-97,139-162.) */
+/* Tensors of at most `fused_max_hw` pixels per image whose (image, lcm(C / G, 8)-channel chunk) slice fits one block's registers take the
+ * one-launch path (statistics and normalisation out of registers: one read + one write); the choice depends on (HW, C, G) only, never on
+ * the batch.  Default 1024 (MVE_GN_FUSED_MAX_HW); 0 disables; negative only queries.  Returns the previous value. */
+MVE_API int mve_groupnorm_tune(int fused_max_hw);
 MVE_API size_t mve_groupnorm_workspace_bytes(int B, int HW, int C, int G);
 MVE_API int mve_groupnorm_silu(int dtype, const void* d_x1, int C1, const void* d_x2, int C2, int B, int HW, int G,
                                float eps, const float* d_gamma, const float* d_beta, int silu, void* d_out,
@@ -816,8 +820,17 @@ MVE_API int mve_antialias_backward_pos(const float* d_color, const float* d_grad
  *                     BasicConv2d with 1xk / kx1 / dilated kernels, conv_modules.py:11-39, att_modules.py:16-41).  out = act(conv + bias)
  *                     [* mul] [+ add]; x / out / mul / add rows are ldx / ldo / ld2 channels wide (channel slices of wider tensors).
  *   seg_act         : in-place activation of a GEMM / conv3x3 output (the swish / SELU behind a BatchNorm).
+ *   seg_mconv       : small dense convolutions (stride 1, output size = input size) on the matrix cores with everything around them fused:
+ *                     out[m][n] = act(sum_{tap, c} (x[pixel(m) + tap][c] * gate[b][c]) W[n][tap][c] + bias[n]) (+ residual[m][n]); W [N][ldw]
+ *                     dtype with rows [kh][kw][Cin]; gate [B][Cin] f32 or NULL (1 x 1 only: the squeeze-and-excite scaling of
+ *                     MBConvBlock.forward, efficientnet.py:124-131, applied to the operand in registers).  The expand conv + swish (:110-113),
+ *                     the project conv + skip (:131-141), and the RFB block's 1 x 1, 1 x k, k x 1 and dilated 3 x 3 BasicConv2d layers
+ *                     (conv_modules.py / att_modules.py:23-72; Cin % 32 == 0 when the kernel has taps).
  *   seg_channel_mean: F.adaptive_avg_pool2d(x, 1) / GlobalAvgPool -> f32 [B][C].
- *   seg_se_gate     : sigmoid(_se_expand(swish(_se_reduce(pooled)))) (efficientnet.py:124-129), w1 [S][C], w2 [C][S] f32.
+ *   seg_se_gate     : sigmoid(_se_expand(swish(_se_reduce(pooled)))) (efficientnet.py:124-129), w1 [S][C], w2 [C][S] f32; pooled[b][c] = scale *
+ *                     sum_k sums[b][k][c] (nslab = 1, scale = 1: a pooled vector as it is); d_hidden: [B][S + C] f32 workspace.
+ *   seg_dwconv_pool : the MBConv block's depthwise convolution + swish (efficientnet.py:115-121) that also leaves the per-channel sums of its
+ *                     (rounded) output per pixel slab, d_sums [B][seg_dwconv_slabs(B, Ho, Wo, C, k, stride)][C] f32 -- the squeeze without a second pass.
  *   seg_scale       : x = src * A[b][c] (+ S[b][c]) -- the SE gating; UnionAttentionModule's x * att + x, BatchNorm and confidence mask.
  *   seg_resize      : bilinear F.interpolate / torchvision Resize(antialias=False) (align_corners flag); in_mode 0: NHWC dtype, 1: NHWC
  *                     f32, 2: NCHW f32; optional (x - mean[c]) / std[c] (transforms.Normalize, tracer_b7.py:39-44).
@@ -831,10 +844,16 @@ MVE_API int mve_antialias_backward_pos(const float* d_color, const float* d_grad
 MVE_API int mve_seg_conv2d(int dtype, const void* d_x, int B, int H, int W, int Cin, int ldx, const float* d_w, const float* d_bias, void* d_out,
                            int Ho, int Wo, int Cout, int ldo, int kh, int kw, int stride, int pad_t, int pad_l, int dil, int depthwise, int act,
                            const void* d_mul, const void* d_add, int ld2, int out_f32, void* stream);
+MVE_API int mve_seg_mconv(int dtype, const void* d_x, int B, int H, int W, int Cin, int ldx, const void* d_w, int ldw, int kh, int kw, int dil,
+                          int pad_t, int pad_l, const float* d_bias, const float* d_gate, const void* d_residual, int ldr, void* d_out, int N,
+                          int ldo, int act, void* stream);
 MVE_API int mve_seg_act(int dtype, void* d_x, size_t n, int act, void* stream);
 MVE_API int mve_seg_channel_mean(int dtype, const void* d_x, int B, int HW, int C, float* d_out, void* stream);
-MVE_API int mve_seg_se_gate(const float* d_pooled, int B, int C, int S, const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2,
-                            float* d_gate, void* stream);
+MVE_API int mve_seg_se_gate(const float* d_sums, int nslab, float scale, int B, int C, int S, const float* d_w1, const float* d_b1, const float* d_w2,
+                            const float* d_b2, float* d_hidden, float* d_gate, void* stream);
+MVE_API int mve_seg_dwconv_slabs(int B, int Ho, int Wo, int C, int k, int stride);
+MVE_API int mve_seg_dwconv_pool(int dtype, const void* d_x, int B, int H, int W, int C, int ldx, const float* d_w, const float* d_bias, void* d_out, int Ho,
+                                int Wo, int ldo, int kh, int kw, int stride, int pad_t, int pad_l, int act, float* d_sums, void* stream);
 MVE_API int mve_seg_scale(int dtype, void* d_x, const void* d_src, int B, int HW, int C, const float* d_A, const float* d_S, void* stream);
 MVE_API int mve_seg_resize(int dtype, const void* d_x, int B, int H, int W, int C, void* d_out, int Ho, int Wo, int align_corners, int in_mode,
                            int out_f32, const float* d_mean, const float* d_std, void* stream);

@@ -144,6 +144,163 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn_apply(GNSrc s, int nsplit, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// One-launch GroupNorm for tensors whose (image, channel chunk) slice fits the registers of one block: a chunk is lcm(C / G, 8) channels
+// (whole groups AND whole 16-byte vectors: 40 channels for the UNet's 320 / 640 / 1280-wide tensors, 120 for 960 / 1920, 80 for 2560),
+// the block loads all HW rows of it once (<= 20 vectors per thread, kept packed), takes mean and centred variance per group out of the
+// registers (two passes, fp32, fixed-order tree), and writes the normalised (+SiLU) slice: one read + one write of the tensor and one
+// launch instead of 2 reads + 1 write and three.  Which path a tensor takes depends on (HW, C, G) only -- never on the batch.
+// ---------------------------------------------------------------------------------------------------
+constexpr int GNF_MAX_GROUPS = 4;
+
+template <int NT>
+__device__ __forceinline__ void gnf_block_sum(float (&v)[GNF_MAX_GROUPS], float* red /* [NT / 64][GNF_MAX_GROUPS] */) {
+#pragma unroll
+    for (int g = 0; g < GNF_MAX_GROUPS; ++g) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[g] += __shfl_xor(v[g], d, 64);
+    }
+    __syncthreads();                                       // the previous round's readers are done with `red`
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int g = 0; g < GNF_MAX_GROUPS; ++g) red[(threadIdx.x >> 6) * GNF_MAX_GROUPS + g] = v[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GNF_MAX_GROUPS; ++g) {
+        float a = 0.f;
+        for (int w = 0; w < NT / 64; ++w) a += red[w * GNF_MAX_GROUPS + g];
+        v[g] = a;
+    }
+}
+
+template <class Tag, int NT, int MAXI>
+__global__ __launch_bounds__(NT) void k_gn_fused(GNSrc s, int G, int W8, int nchunk, int xcd_map, float eps, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, int silu, void* __restrict__ out) {
+    typedef typename Tag::T T;
+    typedef typename Tag::V8 V8;
+    __shared__ float red[(NT / 64) * GNF_MAX_GROUPS];
+    __shared__ float tab[2][128];                          // per chunk channel: scale, shift
+    const int C = s.C1 + s.C2, cpg = C / G, cg = W8 * 8 / cpg;
+    int b, chunk;
+    if (xcd_map) {                                         // the chunks of an image on ONE XCD (block id % 8), close in time: they share its rows' lines
+        const int id = blockIdx.x;
+        b = 8 * (id / (8 * nchunk)) + (id & 7);
+        chunk = (id >> 3) % nchunk;
+    } else {
+        b = blockIdx.x / nchunk;
+        chunk = blockIdx.x - b * nchunk;
+    }
+    const int total = s.HW * W8;
+    V8 raw[MAXI];
+    float acc[GNF_MAX_GROUPS] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int i = threadIdx.x + it * NT;
+        if (i < total) {
+            const int row = i / W8, c8 = i - row * W8;
+            raw[it] = *reinterpret_cast<const V8*>(gn_chunk_ptr<Tag>(s, b, row, chunk * W8 + c8));
+            const int g0 = (c8 * 8) / cpg, eb = (g0 + 1) * cpg - c8 * 8;
+            float lo = 0.f, hi = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float v = Tag::to_f32(raw[it][e]); if (e < eb) lo += v; else hi += v; }
+#pragma unroll
+            for (int g = 0; g < GNF_MAX_GROUPS; ++g) acc[g] += (g == g0 ? lo : 0.f) + (g == g0 + 1 ? hi : 0.f);
+        }
+    }
+    gnf_block_sum<NT>(acc, red);
+    const float inv_n = 1.0f / ((float)cpg * (float)s.HW);
+    float mean[GNF_MAX_GROUPS];
+#pragma unroll
+    for (int g = 0; g < GNF_MAX_GROUPS; ++g) { mean[g] = acc[g] * inv_n; acc[g] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int i = threadIdx.x + it * NT;
+        if (i < total) {
+            const int row = i / W8, c8 = i - row * W8;
+            const int g0 = (c8 * 8) / cpg, eb = (g0 + 1) * cpg - c8 * 8;
+            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < GNF_MAX_GROUPS; ++g) { m0 = g == g0 ? mean[g] : m0; m1 = g == g0 + 1 ? mean[g] : m1; }
+            float lo = 0.f, hi = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = Tag::to_f32(raw[it][e]);
+                if (e < eb) { const float d = v - m0; lo = __builtin_fmaf(d, d, lo); } else { const float d = v - m1; hi = __builtin_fmaf(d, d, hi); }
+            }
+#pragma unroll
+            for (int g = 0; g < GNF_MAX_GROUPS; ++g) acc[g] += (g == g0 ? lo : 0.f) + (g == g0 + 1 ? hi : 0.f);
+        }
+    }
+    gnf_block_sum<NT>(acc, red);
+    if ((int)threadIdx.x < W8 * 8) {
+        const int g = threadIdx.x / cpg, c = chunk * W8 * 8 + threadIdx.x;
+        float var = 0.f, m = 0.f;
+#pragma unroll
+        for (int k = 0; k < GNF_MAX_GROUPS; ++k) { var = k == g ? acc[k] : var; m = k == g ? mean[k] : m; }
+        const float sc = rsqrtf(var * inv_n + eps) * gamma[c];
+        tab[0][threadIdx.x] = sc;
+        tab[1][threadIdx.x] = beta[c] - m * sc;
+    }
+    __syncthreads();
+    (void)cg;
+    T* o = reinterpret_cast<T*>(out);
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int i = threadIdx.x + it * NT;
+        if (i < total) {
+            const int row = i / W8, c8 = i - row * W8;
+            V8 pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = __builtin_fmaf(Tag::to_f32(raw[it][e]), tab[0][c8 * 8 + e], tab[1][c8 * 8 + e]);
+                if (silu) y = y / (1.0f + __expf(-y));
+                pk[e] = Tag::from_f32(y);
+            }
+            *reinterpret_cast<V8*>(o + ((size_t)b * s.HW + row) * C + (size_t)(chunk * W8 + c8) * 8) = pk;
+        }
+    }
+}
+
+int g_gn_fused_max_hw = -1;          // -1: read MVE_GN_FUSED_MAX_HW (default 1024); 0 disables the one-launch path
+
+// -> vectors per row of a chunk (0: the tensor does not take the one-launch path), threads and vectors per thread
+int gnf_plan(int HW, int C, int G, int* nt, int* maxi) {
+    if (g_gn_fused_max_hw < 0) {
+        const char* e = getenv("MVE_GN_FUSED_MAX_HW");
+        g_gn_fused_max_hw = e ? atoi(e) : 1024;
+    }
+    if (HW > g_gn_fused_max_hw || G <= 0 || C % G) return 0;
+    const int cpg = C / G;
+    int ch = cpg;
+    while (ch % 8) ch += cpg;                              // lcm(cpg, 8)
+    if (cpg < 8 || ch > 128 || C % ch || ch / cpg > GNF_MAX_GROUPS) return 0;
+    const int W8 = ch / 8;
+    const long long total = (long long)HW * W8;
+    if (total <= 256 * 20) *nt = 256;
+    else if (total <= 1024 * 20) *nt = 1024;
+    else return 0;
+    const int per = (int)((total + *nt - 1) / *nt);
+    *maxi = per <= 4 ? 4 : (per <= 8 ? 8 : (per <= 12 ? 12 : (per <= 16 ? 16 : 20)));
+    return W8;
+}
+
+template <class Tag, int NT>
+int gnf_launch(const GNSrc& s, int G, int W8, int maxi, float eps, const float* gamma, const float* beta, int silu, void* out, hipStream_t st) {
+    const int nchunk = (s.C1 + s.C2) / (W8 * 8);
+    const int xcd = (s.B % 8 == 0) ? 1 : 0;
+    const unsigned grid = (unsigned)(s.B * nchunk);
+    switch (maxi) {
+        case 4: k_gn_fused<Tag, NT, 4><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        case 8: k_gn_fused<Tag, NT, 8><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        case 12: k_gn_fused<Tag, NT, 12><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        case 16: k_gn_fused<Tag, NT, 16><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        default: k_gn_fused<Tag, NT, 20><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+    }
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LayerNorm over the last axis (C <= 2048, C % 8 == 0): one wave per row, two passes over registers.
 // ---------------------------------------------------------------------------------------------------
 template <class Tag, int MAXC8>   // MAXC8: chunks per lane
@@ -206,11 +363,10 @@ int gn_nsplit(int B, int HW, int C) {
         const int ns = HW / 512;
         return ns < 1 ? 1 : (ns > 512 ? 512 : ns);
     }
-    const int ncolgroups = (C / 8 + 63) / 64;
-    // enough blocks to fill 256 CUs several times over, but at least 32 rows per block
-    int want = (256 * 8 + B * ncolgroups - 1) / (B * ncolgroups);
-    int maxsplit = HW / 32 > 0 ? HW / 32 : 1;
-    int ns = want < maxsplit ? want : maxsplit;
+    // a function of the rows per image only: the grouping of the fp32 partial sums -- and so the statistics' last bits -- must not
+    // depend on the batch (batch invariance); 64 rows per block, at most 64 splits: 4096 blocks at 64 images of 64 x 64
+    (void)B;
+    const int ns = HW / 64;
     return ns < 1 ? 1 : (ns > 64 ? 64 : ns);
 }
 
@@ -218,6 +374,10 @@ template <class Tag>
 int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* beta, int silu, void* out, float* ws,
            hipStream_t st) {
     const int C = s.C1 + s.C2;
+    int nt = 0, maxi = 0;
+    if (const int W8 = gnf_plan(s.HW, C, G, &nt, &maxi))
+        return nt == 256 ? gnf_launch<Tag, 256>(s, G, W8, maxi, eps, gamma, beta, silu, out, st)
+                         : gnf_launch<Tag, 1024>(s, G, W8, maxi, eps, gamma, beta, silu, out, st);
     const int tx = gn_tx(C);
     const int ncg = (C / 8 + tx - 1) / tx;
     const int ns = gn_nsplit(s.B, s.HW, C);
@@ -253,6 +413,14 @@ int ln_run(const void* x, int ldx, void* y, int ldy, int M, int C, const float* 
 }  // namespace
 
 extern "C" {
+
+int mve_groupnorm_tune(int fused_max_hw) {
+    int nt, maxi;
+    (void)gnf_plan(1, 8, 1, &nt, &maxi);                 // resolves the environment default
+    const int prev = g_gn_fused_max_hw;
+    if (fused_max_hw >= 0) g_gn_fused_max_hw = fused_max_hw;
+    return prev;
+}
 
 size_t mve_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
     if (B <= 0 || HW <= 0 || C <= 0) return 64;

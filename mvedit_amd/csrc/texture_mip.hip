@@ -73,6 +73,43 @@ __global__ __launch_bounds__(NT) void k_mip_build(const float* __restrict__ src,
     dst[t * dst_stride + ((size_t)y * w2 + x) * C + c] = 0.5f * (top + bot);
 }
 
+// up to five levels per launch: a block owns a tile of <= 32 x 32 texels of level l (th x tw of them; every extent on the way down is even or 1,
+// check_tex) and derives levels l + 1 .. l + nl of it through LDS, each from the STORED fp32 values of the one below, rows first then columns --
+// bit-identical to nl launches of k_mip_build.  src: level l ([Bt] textures src_stride apart), mips: the stack (level l + k at offs[k - 1] * C)
+struct MipTileArgs { int off[5]; };
+__global__ __launch_bounds__(NT) void k_mip_build_tile(const float* __restrict__ src, size_t src_stride, float* __restrict__ mips, size_t mip_stride,
+                                                       int h, int w, int C, int th, int tw, int nl, MipTileArgs a) {
+    extern __shared__ float tile[];                       // two buffers of th * tw * C and th * tw * C / 2 floats
+    const int tiles_x = w / tw, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const size_t t = blockIdx.y;
+    float* cur = tile;
+    float* nxt = tile + (size_t)th * tw * C;
+    const float* s = src + t * src_stride;
+    for (int i = threadIdx.x; i < th * tw * C; i += NT) {
+        const int c = i % C, x = (i / C) % tw, y = i / (C * tw);
+        cur[i] = s[((size_t)(ty * th + y) * w + tx * tw + x) * C + c];
+    }
+    __syncthreads();
+    int ch = th, cw = tw, lh = h, lw = w;                 // extents of the tile / of the whole level held in `cur`
+    for (int k = 0; k < nl; ++k) {
+        const int nh = ch > 1 ? ch >> 1 : 1, nw = cw > 1 ? cw >> 1 : 1;
+        lh = lh > 1 ? lh >> 1 : 1; lw = lw > 1 ? lw >> 1 : 1;
+        float* dst = mips + t * mip_stride + (size_t)a.off[k] * C;
+        for (int i = threadIdx.x; i < nh * nw * C; i += NT) {
+            const int c = i % C, x = (i / C) % nw, y = i / (C * nw);
+            const int y0 = ch > 1 ? 2 * y : 0, y1 = ch > 1 ? 2 * y + 1 : 0, x0 = cw > 1 ? 2 * x : 0, x1 = cw > 1 ? 2 * x + 1 : 0;
+            const float top = 0.5f * (cur[(y0 * cw + x0) * C + c] + cur[(y1 * cw + x0) * C + c]);
+            const float bot = 0.5f * (cur[(y0 * cw + x1) * C + c] + cur[(y1 * cw + x1) * C + c]);
+            const float v = 0.5f * (top + bot);
+            nxt[i] = v;
+            dst[((size_t)(ty * nh + y) * lw + tx * nw + x) * C + c] = v;
+        }
+        __syncthreads();
+        float* sw = cur; cur = nxt; nxt = sw;
+        ch = nh; cw = nw;
+    }
+}
+
 struct TexDesc {
     const float* tex0; const float* mips;       // [Bt][H*W*C], [Bt][mip_texels*C]
     size_t tex_stride, mip_stride;              // floats per texture (0: one texture shared by every sample)
@@ -185,6 +222,52 @@ __global__ __launch_bounds__(NT) void k_mip_collapse(TexDesc t, int Bt, const vo
     else reinterpret_cast<float*>(g_tex0)[i] = (float)acc;
 }
 
+// the same for even H, W: one thread per 2 x 2 quad of level 0 -- the levels above are shared by the quad, read once, and added to each of its
+// four texels in the order of k_mip_collapse (bit-identical): 2.75 reads per texel instead of 1 + max_level
+constexpr int QUAD_MAX_LEVEL = 14;
+template <bool FIXED>
+__global__ __launch_bounds__(NT) void k_mip_collapse_quad(TexDesc t, int Bt, const void* __restrict__ g_mips, void* __restrict__ g_tex0, float* __restrict__ out_f32) {
+    const int qw = t.W >> 1, qh = t.H >> 1;
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= (size_t)Bt * qh * qw) return;
+    const int qx = (int)(i % qw), qy = (int)((i / qw) % qh);
+    const size_t r = i / ((size_t)qw * qh);
+    for (int c = 0; c < t.C; ++c) {
+        double up[QUAD_MAX_LEVEL + 1];
+#pragma unroll
+        for (int l = 1; l <= QUAD_MAX_LEVEL; ++l) {
+            up[l] = 0.0;
+            if (l > t.max_level) continue;
+            const int w = tm_dim(t.W, l), h = tm_dim(t.H, l);
+            const int x = 2 * qx, y = 2 * qy;
+            const int xl = x >> l < w ? x >> l : w - 1, yl = y >> l < h ? y >> l : h - 1;
+            const size_t e = r * t.mip_stride + ((size_t)tm_mip_offset(t.H, t.W, l) + (size_t)yl * w + xl) * t.C + c;
+            const double area = (double)(t.H / h) * (double)(t.W / w);
+            if constexpr (FIXED) up[l] = (double)reinterpret_cast<const unsigned long long*>(g_mips)[e] * (1.0 / 4294967296.0) / area;
+            else up[l] = (double)reinterpret_cast<const float*>(g_mips)[e] / area;
+        }
+        for (int j = 0; j < 4; ++j) {
+            const size_t e0 = ((r * t.H + 2 * qy + (j >> 1)) * t.W + 2 * qx + (j & 1)) * t.C + c;
+            double acc;
+            if constexpr (FIXED) acc = (double)reinterpret_cast<const unsigned long long*>(g_tex0)[e0] * (1.0 / 4294967296.0);
+            else acc = (double)reinterpret_cast<const float*>(g_tex0)[e0];
+#pragma unroll
+            for (int l = 1; l <= QUAD_MAX_LEVEL; ++l)
+                if (l <= t.max_level) acc += up[l];
+            if constexpr (FIXED) out_f32[e0] = (float)acc;
+            else reinterpret_cast<float*>(g_tex0)[e0] = (float)acc;
+        }
+    }
+}
+
+template <bool FIXED>
+void launch_collapse(const TexDesc& t, int Bt, const void* g_mips, void* g_tex0, float* out_f32, hipStream_t s) {
+    if (t.H % 2 == 0 && t.W % 2 == 0 && t.max_level >= 1 && t.max_level <= QUAD_MAX_LEVEL)
+        k_mip_collapse_quad<FIXED><<<mve_cdiv((size_t)Bt * (t.H / 2) * (t.W / 2), NT), NT, 0, s>>>(t, Bt, g_mips, g_tex0, out_f32);
+    else
+        k_mip_collapse<FIXED><<<mve_cdiv((size_t)Bt * t.H * t.W * t.C, NT), NT, 0, s>>>(t, Bt, g_mips, g_tex0, out_f32);
+}
+
 // per texel of the atlas: for every view of the batch the mip-mapped fetch of (r, g, b, view weight) at the texel's projection, times
 // the texel's visibility; accum += (rgb * weight, weight)      (base_mesh_renderer.py:566-582)
 __global__ __launch_bounds__(NT) void k_bake_accumulate_mip(const float* __restrict__ tex_rast, const float* __restrict__ tex_rast_db,
@@ -199,6 +282,8 @@ __global__ __launch_bounds__(NT) void k_bake_accumulate_mip(const float* __restr
     const int id = (int)r[3] - 1;
     f32x4 acc = reinterpret_cast<f32x4*>(accum)[t];
     for (int v = 0; v < n; ++v) {
+        const float vz = vis[(size_t)v * map * map + t];
+        if (vz == 0.f) continue;                                            // weight = fetch * 0: adds exactly nothing (finite images)
         float cu = 0.f, cv = 0.f, da[4] = {0.f, 0.f, 0.f, 0.f};            // dr.interpolate gives 0 on empty texels
         if (id >= 0 && id < F) {
             const float* vi = v_img + (size_t)v * V * 2;
@@ -211,7 +296,7 @@ __global__ __launch_bounds__(NT) void k_bake_accumulate_mip(const float* __restr
         }
         float px[4];
         mip_fetch(img, (size_t)v, cu, cv, da, px);
-        const float weight = px[3] * vis[(size_t)v * map * map + t];
+        const float weight = px[3] * vz;
         acc[0] += px[0] * weight; acc[1] += px[1] * weight; acc[2] += px[2] * weight; acc[3] += weight;
     }
     reinterpret_cast<f32x4*>(accum)[t] = acc;
@@ -276,13 +361,33 @@ int mve_mip_build(const float* d_tex0, int Bt, int H, int W, int C, int max_leve
     if (max_level == 0) return MVE_OK;
     MVE_CHECK(d_tex0 && d_mips, MVE_ERR_ARG, "mip_build: null pointer");
     const size_t ms = (size_t)tm_mip_offset(H, W, max_level + 1) * C;
-    for (int l = 0; l < max_level; ++l) {
-        const int h = tm_dim(H, l), w = tm_dim(W, l), h2 = tm_dim(H, l + 1), w2 = tm_dim(W, l + 1);
+    int l = 0;
+    while (l < max_level) {
+        const int h = tm_dim(H, l), w = tm_dim(W, l);
         const float* src = l == 0 ? d_tex0 : d_mips + (size_t)tm_mip_offset(H, W, l) * C;
         const size_t ss = l == 0 ? (size_t)H * W * C : ms;
+        const int th = h % 32 == 0 ? 32 : (h <= 32 ? h : 0), tw = w % 32 == 0 ? 32 : (w <= 32 ? w : 0);
+        if (th && tw) {                                  // a tile walk: up to five levels in one launch
+            int nl = 0, eh = th, ew = tw;
+            MipTileArgs a;
+            while (nl < 5 && l + nl < max_level && (eh > 1 || ew > 1)) {
+                a.off[nl] = tm_mip_offset(H, W, l + nl + 1);
+                eh = eh > 1 ? eh >> 1 : 1; ew = ew > 1 ? ew >> 1 : 1;
+                ++nl;
+            }
+            if (nl > 0) {
+                const size_t lds = sizeof(float) * ((size_t)th * tw * C + (size_t)th * tw * C / 2 + C);
+                k_mip_build_tile<<<dim3((h / th) * (w / tw), Bt), NT, lds, (hipStream_t)stream>>>(src, ss, d_mips, ms, h, w, C, th, tw, nl, a);
+                MVE_LAUNCH_CHECK();
+                l += nl;
+                continue;
+            }
+        }
+        const int h2 = tm_dim(H, l + 1), w2 = tm_dim(W, l + 1);
         k_mip_build<<<mve_cdiv((size_t)Bt * h2 * w2 * C, NT), NT, 0, (hipStream_t)stream>>>(
             src, ss, d_mips + (size_t)tm_mip_offset(H, W, l + 1) * C, ms, Bt, h, w, C);
         MVE_LAUNCH_CHECK();
+        ++l;
     }
     return MVE_OK;
 }
@@ -317,7 +422,7 @@ int mve_texture_mip_backward(const float* d_g_out, int Bt, int H, int W, int C, 
     }
     if (max_level > 0) {
         t.mip_stride = mt;           // the collapse walks every texture, shared or not
-        k_mip_collapse<false><<<mve_cdiv((size_t)Bt * H * W * C, NT), NT, 0, s>>>(t, Bt, d_g_mips, d_g_tex0, nullptr);
+        launch_collapse<false>(t, Bt, d_g_mips, d_g_tex0, nullptr, s);
         MVE_LAUNCH_CHECK();
     }
     return MVE_OK;
@@ -342,7 +447,7 @@ int mve_visibility_mip(const float* d_texc, const float* d_texc_da, const float*
     const size_t total = (size_t)n * h * w;
     k_texture_mip_bwd<true><<<mve_cdiv(total, NT), NT, 0, s>>>(t, nullptr, d_texc, d_texc_da, d_rast, total, (size_t)h * w, g0, gm);
     MVE_LAUNCH_CHECK();
-    k_mip_collapse<true><<<mve_cdiv((size_t)n * map_size * map_size, NT), NT, 0, s>>>(t, n, gm, g0, d_vis);
+    launch_collapse<true>(t, n, gm, g0, d_vis, s);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

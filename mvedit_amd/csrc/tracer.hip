@@ -48,40 +48,164 @@ struct ConvD {
     int B, H, W, Cin, ldx, Ho, Wo, Cout, ldo, kh, kw, stride, pad_t, pad_l, dil, act, ld2;
 };
 
-// depthwise: one thread per (output pixel, 8 consecutive channels); weights [kh][kw][C] fp32
+// depthwise geometry: the 8-channel groups of an image are cut into nchunk chunks of cw groups (cw divides C / 8, cw <= 64), the pixels into
+// nslab slabs; a block = (slab, chunk, image) of pl = 256 / cw pixel lanes x cw channel lanes
+struct DwGeom { int cw, pl, nchunk, nslab, slab; };
+DwGeom dw_geom(int B, int HW, int C) {
+    DwGeom g;
+    const int c8n = C / 8;
+    g.nchunk = (c8n + 63) / 64;
+    while (c8n % g.nchunk) ++g.nchunk;
+    g.cw = c8n / g.nchunk;
+    g.pl = 256 / g.cw;
+    (void)B;                                                        // the slab cut decides the order of the SE sums: it must not depend on the batch
+    long long want = 1024 / (long long)g.nchunk;                    // >= 1024 blocks per image: 256 CUs filled several waves deep at any batch
+    want = want < 1 ? 1 : (want > 256 ? 256 : want);
+    g.slab = (int)((HW + want - 1) / want);
+    g.slab = ((g.slab + g.pl - 1) / g.pl) * g.pl;
+    g.nslab = (HW + g.slab - 1) / g.slab;
+    return g;
+}
+
+bool dw_strip(int kh, int kw, int stride, int dil) { return dil == 1 && kh == kw && (kh == 3 || kh == 5) && (stride == 1 || stride == 2); }
+
+// depthwise: thread = (pixel lane, 8 consecutive channels), walking the slab's pixels pl apart; weights [kh][kw][C] fp32.  With `sums` the block
+// also adds up its slab per channel, over the ROUNDED outputs, in a fixed order: sums[b][slab][c] -- the squeeze of squeeze-and-excite
 template <class Tag>
-__global__ __launch_bounds__(256) void k_seg_dwconv(const ConvD p) {
+__global__ __launch_bounds__(256) void k_seg_dwconv(const ConvD p, const int cw, const int pl, const int slab, float* __restrict__ sums) {
     typedef typename Tag::T T;
     typedef typename Tag::V8 V8;
-    const int c8n = p.Cin / 8;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)p.B * p.Ho * p.Wo * c8n;
-    if (idx >= total) return;
-    const int c0 = (int)(idx % c8n) * 8;
-    const long long pix = idx / c8n;
-    const int xo = (int)(pix % p.Wo), yo = (int)((pix / p.Wo) % p.Ho), b = (int)(pix / ((long long)p.Wo * p.Ho));
-    float acc[8];
+    __shared__ float red[2048];
+    const int c8l = threadIdx.x % cw, lp = threadIdx.x / cw;
+    const int b = blockIdx.z, c0 = (blockIdx.y * cw + c8l) * 8;
+    const int HW = p.Ho * p.Wo;
+    const int q0 = blockIdx.x * slab, q1 = q0 + slab < HW ? q0 + slab : HW;
+    float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lp < pl) {
+        float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = p.bias ? p.bias[c0 + e] : 0.f;
-    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.H * p.W * p.ldx + c0;
-    for (int i = 0; i < p.kh; ++i) {
-        const int yi = yo * p.stride - p.pad_t + i * p.dil;
-        if (yi < 0 || yi >= p.H) continue;
-        for (int j = 0; j < p.kw; ++j) {
-            const int xi = xo * p.stride - p.pad_l + j * p.dil;
-            if (xi < 0 || xi >= p.W) continue;
-            float v[8];
-            load8f<Tag>(xb + ((size_t)yi * p.W + xi) * p.ldx, v);
-            const float* wt = p.w + (size_t)(i * p.kw + j) * p.Cin + c0;
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
+        for (int e = 0; e < 8; ++e) bias[e] = p.bias ? p.bias[c0 + e] : 0.f;
+        const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.H * p.W * p.ldx + c0;
+        T* ob = reinterpret_cast<T*>(p.out) + (size_t)b * HW * p.ldo + c0;
+        for (int q = q0 + lp; q < q1; q += pl) {
+            const int yo = q / p.Wo, xo = q - yo * p.Wo;
+            float acc[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[e] = __builtin_fmaf(v[e], w0[e], acc[e]); acc[4 + e] = __builtin_fmaf(v[4 + e], w1[e], acc[4 + e]); }
+            for (int e = 0; e < 8; ++e) acc[e] = bias[e];
+            for (int i = 0; i < p.kh; ++i) {
+                const int yi = yo * p.stride - p.pad_t + i * p.dil;
+                if (yi < 0 || yi >= p.H) continue;
+                for (int j = 0; j < p.kw; ++j) {
+                    const int xi = xo * p.stride - p.pad_l + j * p.dil;
+                    if (xi < 0 || xi >= p.W) continue;
+                    float v[8];
+                    load8f<Tag>(xb + ((size_t)yi * p.W + xi) * p.ldx, v);
+                    const float* wt = p.w + (size_t)(i * p.kw + j) * p.Cin + c0;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[e] = __builtin_fmaf(v[e], w0[e], acc[e]); acc[4 + e] = __builtin_fmaf(v[4 + e], w1[e], acc[4 + e]); }
+                }
+            }
+            V8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = Tag::from_f32(seg_act(acc[e], p.act)); tot[e] += Tag::to_f32(o[e]); }
+            *reinterpret_cast<V8*>(ob + (size_t)q * p.ldo) = o;
         }
     }
-    V8 o;
+    if (sums == nullptr) return;
+    const int cwe = cw * 8;
+    if (lp < pl) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = Tag::from_f32(seg_act(acc[e], p.act));
-    *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out) + (size_t)pix * p.ldo + c0) = o;
+        for (int e = 0; e < 8; ++e) red[lp * cwe + c8l * 8 + e] = tot[e];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < cwe; t += 256) {
+        float a = 0.f;
+        for (int k = 0; k < pl; ++k) a += red[k * cwe + t];
+        sums[((size_t)b * gridDim.x + blockIdx.x) * p.Cin + blockIdx.y * cwe + t] = a;
+    }
+}
+
+// the same for the encoder's four (kernel, stride) pairs, four outputs along x per thread: a row segment of (3 S + K) input vectors serves the
+// four outputs and every tap's weights are fetched once per strip -- 2.25 loads per output instead of 6.75 (K = 3, S = 1).  Same arithmetic
+// per output as k_seg_dwconv (taps in the same order, zero padding skipped the same way): bit-identical outputs.
+template <class Tag, int K, int S>
+__global__ __launch_bounds__(256, 4) void k_seg_dwconv_strip(const ConvD p, const int cw, const int pl, const int slab, float* __restrict__ sums) {
+    typedef typename Tag::T T;
+    typedef typename Tag::V8 V8;
+    constexpr int XS = 4, NJ = (XS - 1) * S + K;
+    __shared__ float red[2048];
+    const int c8l = threadIdx.x % cw, lp = threadIdx.x / cw;
+    const int b = blockIdx.z, c0 = (blockIdx.y * cw + c8l) * 8;
+    const int spr = (p.Wo + XS - 1) / XS, nstrip = p.Ho * spr;            // strips per row / per image; `slab` counts strips here
+    const int q0 = blockIdx.x * slab, q1 = q0 + slab < nstrip ? q0 + slab : nstrip;
+    float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lp < pl) {
+        float bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = p.bias ? p.bias[c0 + e] : 0.f;
+        const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.H * p.W * p.ldx + c0;
+        T* ob = reinterpret_cast<T*>(p.out) + (size_t)b * p.Ho * p.Wo * p.ldo + c0;
+        for (int q = q0 + lp; q < q1; q += pl) {
+            const int yo = q / spr, xo0 = (q - yo * spr) * XS;
+            float acc[XS][8];
+#pragma unroll
+            for (int u = 0; u < XS; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[u][e] = bias[e];
+            const int xi0 = xo0 * S - p.pad_l;
+#pragma unroll 1                                          // one row segment in registers at a time: <= 128 VGPRs, four waves per SIMD
+            for (int i = 0; i < K; ++i) {
+                const int yi = yo * S - p.pad_t + i;
+                if (yi < 0 || yi >= p.H) continue;
+                V8 seg[NJ];
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int xi = xi0 + jj;
+                    if (xi >= 0 && xi < p.W) seg[jj] = *reinterpret_cast<const V8*>(xb + ((size_t)yi * p.W + xi) * p.ldx);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) seg[jj][e] = (T)0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float* wt = p.w + (size_t)(i * K + j) * p.Cin + c0;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
+#pragma unroll
+                    for (int u = 0; u < XS; ++u) {
+                        const int xi = xi0 + u * S + j;
+                        if (xi < 0 || xi >= p.W) continue;          // a padded tap: skipped, as the one-output kernel skips it
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[u][e] = __builtin_fmaf(Tag::to_f32(seg[u * S + j][e]), w0[e], acc[u][e]);
+                            acc[u][4 + e] = __builtin_fmaf(Tag::to_f32(seg[u * S + j][4 + e]), w1[e], acc[u][4 + e]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < XS; ++u) {
+                if (xo0 + u >= p.Wo) continue;
+                V8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = Tag::from_f32(seg_act(acc[u][e], p.act)); tot[e] += Tag::to_f32(o[e]); }
+                *reinterpret_cast<V8*>(ob + ((size_t)yo * p.Wo + xo0 + u) * p.ldo) = o;
+            }
+        }
+    }
+    if (sums == nullptr) return;
+    const int cwe = cw * 8;
+    if (lp < pl) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[lp * cwe + c8l * 8 + e] = tot[e];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < cwe; t += 256) {
+        float a = 0.f;
+        for (int k = 0; k < pl; ++k) a += red[k * cwe + t];
+        sums[((size_t)b * gridDim.x + blockIdx.x) * p.Cin + blockIdx.y * cwe + t] = a;
+    }
 }
 
 // small dense convolution: a wave = 64 consecutive output pixels x CO output channels (weights are wave-uniform: [Cout][kh][kw][Cin] fp32);
@@ -142,6 +266,233 @@ __global__ __launch_bounds__(256) void k_seg_conv(const ConvD p) {
     }
 }
 
+// Small dense convolutions on the matrix cores: the 1 x 1 expand / project layers of EfficientNet (K, N from 32 to 3840) and the decoder's
+// 1 x k, k x 1 and dilated 3 x 3 layers (stride 1, "same" size), all HBM- or latency-bound skinny GEMMs:
+//   out[m][n] = act(sum_{tap, c} (x[pixel(m) + tap][c] * gate[b][c]) W[n][tap][c] + bias[n]) (+ residual[m][n]).
+// A wave tile is 64 pixels x 64 output channels (4 x 4 fragments of v_mfma_f32_16x16x32).  W is the MFMA's row operand and the pixels its
+// column operand, so that a lane ends up with FOUR CONSECUTIVE CHANNELS of one pixel (8-byte stores, no LDS transpose), and both operands
+// are plain 16-byte global loads in the layout the instruction wants (lane = row l % 16, k = 8 (l / 16) .. + 7): no LDS staging.  The
+// squeeze-and-excite gate multiplies the pixel fragments in registers (rounded to the storage type, as the reference's x * gate is): the SE
+// scaling costs no pass of its own.  The next K step's fragments are loaded before the current one's MFMAs (register double buffer).
+// Block = 4 waves on ONE image (the gate is per image):
+//   SPLITK = false: 256 pixels x 64 channels, a wave per 64 pixels;
+//   SPLITK = true : 64 pixels x 64 channels, the waves take every fourth K step and the four partial tiles meet through LDS in wave order
+//                   (deterministic) -- for the deep layers, where an image has few pixels and K is in the thousands.
+// The choice depends on (K, pixels per image) only, never on the batch.  Grid (N tiles, pixel tiles x images): the channel tiles of one
+// pixel block are neighbours in launch order and find its rows in L2.
+__device__ __forceinline__ void lane_swap16(float& x, float& y) {      // x of lanes 16..31 / 48..63 <-> y of lanes 0..15 / 32..47
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void lane_swap32(float& x, float& y) {      // x of lanes 32..63 <-> y of lanes 0..31
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+
+struct PwD {
+    const void* x; const void* w; const float* bias; const float* gate; const void* res; void* out;
+    int B, HW, K, N, ldx, ldw, ldo, ldr, act;
+    int H, W, Cin, kh, kw, dil, pad_t, pad_l;             // taps (kh * kw > 1): K = kh * kw * Cin, Cin % 32 == 0
+};
+
+template <class Tag, bool SPLITK, bool TAPS>
+__global__ __launch_bounds__(256, SPLITK ? 2 : 4) void k_seg_mconv(const PwD p) {
+    typedef typename Tag::T T;
+    typedef typename Tag::V8 V8;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    extern __shared__ f32x4 red[];                        // SPLITK: [4 waves][16 fragments][64 lanes]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kg = lane >> 4;
+    constexpr int PXB = SPLITK ? 64 : 256;
+    const int tiles = (p.HW + PXB - 1) / PXB;
+    const int b = blockIdx.y / tiles, px0 = (blockIdx.y - b * tiles) * PXB + (SPLITK ? 0 : wave * 64);
+    if (!SPLITK && px0 >= p.HW) return;
+    const int n0 = blockIdx.x * 64;
+    const int nfv = (p.N - n0 + 15) / 16 < 4 ? (p.N - n0 + 15) / 16 : 4;
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.HW * p.ldx + kg * 8;
+    int pxl[4], py[4], pxx[4];
+    const T* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int px = px0 + i * 16 + r16;
+        px = px < p.HW ? px : p.HW - 1;
+        pxl[i] = px;
+        if (TAPS) { py[i] = px / p.W; pxx[i] = px - py[i] * p.W; }
+        int n = n0 + i * 16 + r16;
+        n = n < p.N ? n : p.N - 1;
+        wp[i] = reinterpret_cast<const T*>(p.w) + (size_t)n * p.ldw + kg * 8;
+    }
+    const float* gp = p.gate ? p.gate + (size_t)b * p.K + kg * 8 : nullptr;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int KSTEP = SPLITK ? 128 : 32;
+    auto load = [&](int k0, V8 (&xf)[4], V8 (&wf)[4]) {
+        const bool kv = k0 + kg * 8 + 8 <= p.K;            // K % 8 == 0: a lane's eight k are in or out together
+        int dy = 0, dx = 0, kin = k0;
+        if (TAPS) {
+            const int t = k0 / p.Cin;
+            kin = k0 - t * p.Cin;
+            const int ty = t / p.kw;
+            dy = ty * p.dil - p.pad_t;
+            dx = (t - ty * p.kw) * p.dil - p.pad_l;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xf[i][e] = (T)0.f; wf[i][e] = (T)0.f; }
+            if (kv) {
+                if (TAPS) {
+                    const int yy = py[i] + dy, xx = pxx[i] + dx;
+                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) xf[i] = *reinterpret_cast<const V8*>(xb + ((size_t)yy * p.W + xx) * p.ldx + kin);
+                } else {
+                    xf[i] = *reinterpret_cast<const V8*>(xb + (size_t)pxl[i] * p.ldx + k0);
+                }
+                if (i < nfv) wf[i] = *reinterpret_cast<const V8*>(wp[i] + k0);
+            }
+        }
+        if (gp && kv) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + k0), g1 = *reinterpret_cast<const f32x4*>(gp + k0 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xf[i][e] = Tag::from_f32(Tag::to_f32(xf[i][e]) * g0[e]);
+                    xf[i][4 + e] = Tag::from_f32(Tag::to_f32(xf[i][4 + e]) * g1[e]);
+                }
+        }
+    };
+    auto mma = [&](const V8 (&xf)[4], const V8 (&wf)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < nfv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = Tag::mfma16(wf[j], xf[i], acc[i][j]);
+            }
+        }
+    };
+    if constexpr (SPLITK) {                               // long K, few waves: the next step's fragments fly while this one's MFMAs run
+        V8 xa[4], wa[4], xc[4], wc[4];
+        int k0 = wave * 32;
+        if (k0 < p.K) load(k0, xa, wa);
+        while (k0 < p.K) {
+            if (k0 + KSTEP < p.K) load(k0 + KSTEP, xc, wc);
+            mma(xa, wa);
+            k0 += KSTEP;
+            if (k0 >= p.K) break;
+            if (k0 + KSTEP < p.K) load(k0 + KSTEP, xa, wa);
+            mma(xc, wc);
+            k0 += KSTEP;
+        }
+    } else {                                              // streaming shapes: <= 128 registers, four waves per SIMD hide the latency instead
+        V8 xa[4], wa[4];
+        for (int k0 = 0; k0 < p.K; k0 += KSTEP) {
+            load(k0, xa, wa);
+            mma(xa, wa);
+        }
+    }
+    if (SPLITK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(wave * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+        __syncthreads();
+        // wave w finishes pixel fragment w of the tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = red[(0 * 16 + wave * 4 + j) * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) v += red[(ww * 16 + wave * 4 + j) * 64 + lane];
+            acc[0][j] = v;
+        }
+    }
+    // a lane holds, per pixel fragment i, channels n0 + 16 j + 4 kg .. + 3 of pixel 16 i + r16 (j = 0 .. 3).  Bias and activation go on in this
+    // layout; then the four lanes of a pixel (kg = 0 .. 3) transpose their 4 x 4 block of f32x4 with v_permlane16_swap / v_permlane32_swap so
+    // that lane kg owns the SIXTEEN consecutive channels of fragment j = kg: residual and output move as 32 contiguous bytes per lane, 128 per
+    // pixel -- whole cache lines instead of 32-byte pieces
+    const bool wide = (p.ldo & 7) == 0 && (!p.res || (p.ldr & 7) == 0);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        if (SPLITK && ii > 0) break;
+        const int i = SPLITK ? wave : ii;
+        const int px = px0 + i * 16 + r16;
+        float v[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            f32x4 t = acc[ii][jj];
+            const int n = n0 + jj * 16 + kg * 4;
+            if (p.bias && jj < nfv && n < p.N) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n); t += b4; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[jj][e] = seg_act(t[e], p.act);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lane_swap16(v[0][e], v[1][e]); lane_swap16(v[2][e], v[3][e]);
+            lane_swap32(v[0][e], v[2][e]); lane_swap32(v[1][e], v[3][e]);
+        }
+        if (px >= p.HW || kg >= nfv) continue;
+        const size_t row = (size_t)b * p.HW + px;
+        const int nb = n0 + kg * 16;                       // v[q][e]: channel nb + 4 q + e
+        T* op = reinterpret_cast<T*>(p.out) + row * p.ldo + nb;
+        const T* rp = p.res ? reinterpret_cast<const T*>(p.res) + row * p.ldr + nb : nullptr;
+        if (wide && nb + 16 <= p.N) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                V8 o;
+                if (rp) {
+                    const V8 r8 = *reinterpret_cast<const V8*>(rp + 8 * h);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = Tag::from_f32(v[2 * h + (e >> 2)][e & 3] + Tag::to_f32(r8[e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = Tag::from_f32(v[2 * h + (e >> 2)][e & 3]);
+                }
+                *reinterpret_cast<V8*>(op + 8 * h) = o;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (nb + 4 * q >= p.N) continue;           // N % 4 == 0
+                T4 o;
+                if (rp) {
+                    const T4 r4 = *reinterpret_cast<const T4*>(rp + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = Tag::from_f32(v[q][e] + Tag::to_f32(r4[e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = Tag::from_f32(v[q][e]);
+                }
+                *reinterpret_cast<T4*>(op + 4 * q) = o;
+            }
+        }
+    }
+}
+
+template <class Tag>
+int mconv_run(const PwD& p, hipStream_t s) {
+    const bool taps = p.kh * p.kw > 1;
+    const bool splitk = p.K >= 256 && p.HW <= 6400;       // a function of the layer, never of the batch
+    const dim3 grid(mve_cdiv(p.N, 64), (unsigned)(mve_cdiv(p.HW, splitk ? 64 : 256) * p.B));
+    const size_t lds = splitk ? 4 * 16 * 64 * sizeof(f32x4) : 0;
+    if (splitk) {
+        static bool configured[64] = {};
+        int dev = 0;
+        MVE_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !configured[dev]) {
+            MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_mconv<Tag, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_mconv<Tag, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured[dev] = true;
+        }
+        if (taps) k_seg_mconv<Tag, true, true><<<grid, 256, lds, s>>>(p); else k_seg_mconv<Tag, true, false><<<grid, 256, lds, s>>>(p);
+    } else {
+        if (taps) k_seg_mconv<Tag, false, true><<<grid, 256, 0, s>>>(p); else k_seg_mconv<Tag, false, false><<<grid, 256, 0, s>>>(p);
+    }
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
 template <class Tag>
 __global__ __launch_bounds__(256) void k_seg_act(void* x, size_t n8, int act) {
     typedef typename Tag::V8 V8;
@@ -181,23 +532,49 @@ __global__ __launch_bounds__(256) void k_seg_channel_mean(const void* x, int HW,
     if (threadIdx.x < 8) out[(size_t)b * C + c0 + threadIdx.x] = red[0][threadIdx.x] / (float)HW;
 }
 
-// gate[b][c] = sigmoid(W2[c][:] . swish(W1 pooled[b] + b1) + b2[c]); one block per image
-__global__ __launch_bounds__(256) void k_seg_se_gate(const float* pooled, int C, int S, const float* w1, const float* b1, const float* w2, const float* b2,
-                                                     float* gate) {
-    extern __shared__ float sh[];          // S hidden values
-    const int b = blockIdx.x;
-    const float* pv = pooled + (size_t)b * C;
-    for (int s = threadIdx.x; s < S; s += 256) {
-        float a = b1[s];
-        for (int c = 0; c < C; ++c) a = __builtin_fmaf(w1[(size_t)s * C + c], pv[c], a);
-        sh[s] = a / (1.0f + __expf(-a));
-    }
+// squeeze-and-excite gate in two launches, a wave per output so that every weight row is read once, coalesced:
+//   hidden[b][s] = swish(b1[s] + W1[s][:] . pooled[b])                                                 (grid (S / 4, B))
+//   gate[b][c]   = sigmoid(b2[c] + W2[c][:] . hidden[b])                                               (grid (C / 4, B))
+// the lane-strided partial sums meet in a fixed xor butterfly: deterministic
+__device__ __forceinline__ float wave_sum(float a) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    return a;
+}
+
+// pooled[b][c] = scale * sum_k sums[b][k][c]: block = (64 channels, image); wave w adds up the slabs k = w, w + 4, ... (lanes = channels:
+// coalesced), the four partial sums meet in wave order -- fixed order, deterministic
+__global__ __launch_bounds__(256) void k_seg_pool_finalize(const float* __restrict__ sums, int nslab, float scale, int C, float* __restrict__ pooled) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float a = 0.f;
+    if (c < C)
+        for (int k = w; k < nslab; k += 4) a += sums[((size_t)b * nslab + k) * C + c];
+    part[w][threadIdx.x & 63] = a;
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = b2[c];
-        for (int s = 0; s < S; ++s) a = __builtin_fmaf(w2[(size_t)c * S + s], sh[s], a);
-        gate[(size_t)b * C + c] = 1.0f / (1.0f + __expf(-a));
-    }
+    if (w == 0 && c < C) pooled[(size_t)b * C + c] = (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) * scale;
+}
+
+__global__ __launch_bounds__(256) void k_seg_se_hidden(const float* __restrict__ pooled, int C, int S, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, float* __restrict__ hidden) {
+    const int b = blockIdx.y;
+    const float* pv = pooled + (size_t)b * C;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= S) return;
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = __builtin_fmaf(w1[(size_t)s * C + c], pv[c], a);
+    a = wave_sum(a) + b1[s];
+    if (lane == 0) hidden[(size_t)b * S + s] = a / (1.0f + __expf(-a));
+}
+
+__global__ __launch_bounds__(256) void k_seg_se_out(const float* __restrict__ hidden, int C, int S, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                    float* __restrict__ gate) {
+    const int b = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int s = lane; s < S; s += 64) a = __builtin_fmaf(w2[(size_t)c * S + s], hidden[(size_t)b * S + s], a);
+    a = wave_sum(a) + b2[c];
+    if (lane == 0) gate[(size_t)b * C + c] = 1.0f / (1.0f + __expf(-a));
 }
 
 // x[b, p, c] = x * A[b, c] (+ S[b, c])
@@ -432,10 +809,16 @@ __global__ __launch_bounds__(256) void k_seg_post_apply(const float* m, int B, i
 }
 
 template <class Tag>
-int conv2d_run(const ConvD& p, int depthwise, int out_f32, hipStream_t s) {
+int conv2d_run(const ConvD& p, int depthwise, int out_f32, hipStream_t s, float* sums = nullptr) {
     if (depthwise) {
-        const long long total = (long long)p.B * p.Ho * p.Wo * (p.Cin / 8);
-        k_seg_dwconv<Tag><<<mve_cdiv(total, 256), 256, 0, s>>>(p);
+        const bool strip = dw_strip(p.kh, p.kw, p.stride, p.dil);
+        const DwGeom g = dw_geom(p.B, strip ? p.Ho * ((p.Wo + 3) / 4) : p.Ho * p.Wo, p.Cin);
+        const dim3 grid(g.nslab, g.nchunk, p.B);
+        if (!strip) k_seg_dwconv<Tag><<<grid, 256, 0, s>>>(p, g.cw, g.pl, g.slab, sums);
+        else if (p.kh == 3 && p.stride == 1) k_seg_dwconv_strip<Tag, 3, 1><<<grid, 256, 0, s>>>(p, g.cw, g.pl, g.slab, sums);
+        else if (p.kh == 3) k_seg_dwconv_strip<Tag, 3, 2><<<grid, 256, 0, s>>>(p, g.cw, g.pl, g.slab, sums);
+        else if (p.stride == 1) k_seg_dwconv_strip<Tag, 5, 1><<<grid, 256, 0, s>>>(p, g.cw, g.pl, g.slab, sums);
+        else k_seg_dwconv_strip<Tag, 5, 2><<<grid, 256, 0, s>>>(p, g.cw, g.pl, g.slab, sums);
     } else {
         const long long npix = (long long)p.B * p.Ho * p.Wo;
         const int CO = p.Cout >= 8 ? 8 : 4;
@@ -486,6 +869,25 @@ int mve_seg_conv2d(int dtype, const void* x, int B, int H, int W, int Cin, int l
     return MVE_ERR_ARG;
 }
 
+int mve_seg_mconv(int dtype, const void* x, int B, int H, int W, int Cin, int ldx, const void* w, int ldw, int kh, int kw, int dil, int pad_t,
+                  int pad_l, const float* bias, const float* gate, const void* residual, int ldr, void* out, int N, int ldo, int act, void* stream) {
+    if (B == 0 || H == 0 || W == 0) return MVE_OK;
+    const int taps = kh * kw;
+    MVE_CHECK(x && w && out && Cin > 0 && N > 0 && kh > 0 && kw > 0 && dil > 0 && Cin % 8 == 0 && N % 4 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0 &&
+                  (!residual || ldr % 4 == 0), MVE_ERR_ARG, "seg_mconv: Cin, ldx, ldw must be multiples of 8, N, ldo, ldr of 4");
+    MVE_CHECK(taps == 1 || Cin % 32 == 0, MVE_ERR_ARG, "seg_mconv: a kernel with taps needs Cin %% 32 == 0 (got %d)", Cin);
+    MVE_CHECK(taps == 1 || !gate, MVE_ERR_ARG, "seg_mconv: the input gate goes with 1 x 1 kernels only");
+    MVE_CHECK(act >= 0 && act <= 4, MVE_ERR_ARG, "seg_mconv: act in 0..4");
+    PwD p;
+    p.x = x; p.w = w; p.bias = bias; p.gate = gate; p.res = residual; p.out = out;
+    p.B = B; p.HW = H * W; p.K = taps * Cin; p.N = N; p.ldx = ldx; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.act = act;
+    p.H = H; p.W = W; p.Cin = Cin; p.kh = kh; p.kw = kw; p.dil = dil; p.pad_t = pad_t; p.pad_l = pad_l;
+    if (dtype == MVE_F16) return mconv_run<F16Tag>(p, (hipStream_t)stream);
+    if (dtype == MVE_BF16) return mconv_run<BF16Tag>(p, (hipStream_t)stream);
+    mve_set_error("seg_mconv: unsupported dtype %d", dtype);
+    return MVE_ERR_ARG;
+}
+
 int mve_seg_act(int dtype, void* x, size_t n, int act, void* stream) {
     if (n == 0) return MVE_OK;
     MVE_CHECK(x && n % 8 == 0 && act >= 0 && act <= 4, MVE_ERR_ARG, "seg_act: n must be a multiple of 8, act in 0..4");
@@ -508,13 +910,42 @@ int mve_seg_channel_mean(int dtype, const void* x, int B, int HW, int C, float* 
     return MVE_OK;
 }
 
-int mve_seg_se_gate(const float* pooled, int B, int C, int S, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
-                    void* stream) {
+int mve_seg_se_gate(const float* sums, int nslab, float scale, int B, int C, int S, const float* w1, const float* b1, const float* w2, const float* b2,
+                    float* hidden, float* gate, void* stream) {
     if (B == 0) return MVE_OK;
-    MVE_CHECK(pooled && w1 && b1 && w2 && b2 && gate && S > 0 && S <= 4096, MVE_ERR_ARG, "seg_se_gate: bad arguments");
-    k_seg_se_gate<<<B, 256, S * sizeof(float), (hipStream_t)stream>>>(pooled, C, S, w1, b1, w2, b2, gate);
+    MVE_CHECK(sums && w1 && b1 && w2 && b2 && hidden && gate && nslab > 0 && C > 0 && C <= 8192 && S > 0, MVE_ERR_ARG, "seg_se_gate: bad arguments");
+    const float* pooled = sums;
+    if (nslab != 1 || scale != 1.0f) {                     // hidden: [B][S] followed by [B][C] for the pooled vector
+        float* pl = hidden + (size_t)B * S;
+        k_seg_pool_finalize<<<dim3(mve_cdiv(C, 64), B), 256, 0, (hipStream_t)stream>>>(sums, nslab, scale, C, pl);
+        MVE_LAUNCH_CHECK();
+        pooled = pl;
+    }
+    k_seg_se_hidden<<<dim3(mve_cdiv(S, 4), B), 256, 0, (hipStream_t)stream>>>(pooled, C, S, w1, b1, hidden);
+    MVE_LAUNCH_CHECK();
+    k_seg_se_out<<<dim3(mve_cdiv(C, 4), B), 256, 0, (hipStream_t)stream>>>(hidden, C, S, w2, b2, gate);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
+}
+
+int mve_seg_dwconv_slabs(int B, int Ho, int Wo, int C, int k, int stride) {
+    if (B <= 0 || Ho <= 0 || Wo <= 0 || C < 8) return 0;
+    return dw_geom(B, dw_strip(k, k, stride, 1) ? Ho * ((Wo + 3) / 4) : Ho * Wo, C).nslab;
+}
+
+int mve_seg_dwconv_pool(int dtype, const void* x, int B, int H, int W, int C, int ldx, const float* w, const float* bias, void* out, int Ho, int Wo,
+                        int ldo, int kh, int kw, int stride, int pad_t, int pad_l, int act, float* sums, void* stream) {
+    if (B == 0) return MVE_OK;
+    MVE_CHECK(x && w && out && sums && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && kh > 0 && kw > 0 && stride > 0, MVE_ERR_ARG,
+              "seg_dwconv_pool: channel count / strides must be multiples of 8");
+    ConvD p;
+    p.x = x; p.w = w; p.bias = bias; p.out = out; p.add = nullptr; p.mul = nullptr;
+    p.B = B; p.H = H; p.W = W; p.Cin = C; p.ldx = ldx; p.Ho = Ho; p.Wo = Wo; p.Cout = C; p.ldo = ldo; p.kh = kh; p.kw = kw;
+    p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.dil = 1; p.act = act; p.ld2 = 0;
+    if (dtype == MVE_F16) return conv2d_run<F16Tag>(p, 1, 0, (hipStream_t)stream, sums);
+    if (dtype == MVE_BF16) return conv2d_run<BF16Tag>(p, 1, 0, (hipStream_t)stream, sums);
+    mve_set_error("seg_dwconv_pool: unsupported dtype %d", dtype);
+    return MVE_ERR_ARG;
 }
 
 int mve_seg_scale(int dtype, void* x, const void* src, int B, int HW, int C, const float* A, const float* S, void* stream) {

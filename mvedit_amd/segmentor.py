@@ -107,19 +107,21 @@ class TracerUniversalB7Engine:
             blk['project'] = (mat16(w), f32(b))
             P[pre] = blk
 
-        def basic(name, conv3x3_mfma=False):
+        def basic(name, conv3x3_mfma=False, mconv=False):
             w, b = fold(sd[f'{name}.conv.weight'], f'{name}.bn', BN_EPS_DEC)
             if conv3x3_mfma:
                 return (w.permute(0, 2, 3, 1).contiguous().to(dev, dt16), f32(b))            # mve_conv3x3: [O][3][3][I], 16-bit
+            if mconv:
+                return (w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(dev, dt16), f32(b))   # mve_seg_mconv: [O][kh * kw * I], 16-bit
             return (dense(w), f32(b))
 
         for name in ('rfb2', 'rfb3', 'rfb4'):
-            P[f'{name}.branch0.0'] = basic(f'{name}.branch0.0')
+            P[f'{name}.branch0.0'] = basic(f'{name}.branch0.0', mconv=True)
             for br in (1, 2, 3):
                 for i in range(4):
-                    P[f'{name}.branch{br}.{i}'] = basic(f'{name}.branch{br}.{i}')
+                    P[f'{name}.branch{br}.{i}'] = basic(f'{name}.branch{br}.{i}', mconv=True)
             P[f'{name}.conv_cat'] = basic(f'{name}.conv_cat', True)
-            P[f'{name}.conv_res'] = basic(f'{name}.conv_res')
+            P[f'{name}.conv_res'] = basic(f'{name}.conv_res', mconv=True)
         for n in ('conv_upsample1', 'conv_upsample2', 'conv_upsample3', 'conv_upsample4', 'conv_upsample5', 'conv_concat2', 'conv_concat3'):
             P[f'agg.{n}'] = basic(f'agg.{n}', True)
         u = 'agg.UAM'
@@ -165,6 +167,35 @@ class TracerUniversalB7Engine:
                       _lib.ptr(out), Ho, Wo, Cout, ldo, kh, kw, stride, pt, pl, dil, int(depthwise), act, _lib.ptr(mul), _lib.ptr(add), ld2,
                       int(out_f32), _lib.stream_ptr(self.device))
         return out, Ho, Wo
+
+    def _dwconv_pool(self, x, B, H, W, C, wb, k, stride, pad):
+        """depthwise k x k + swish of an MBConv block, with the per-slab channel sums the squeeze needs -> (out, Ho, Wo, sums, nslab)"""
+        Ho = (H + pad[0] + pad[1] - k) // stride + 1
+        Wo = (W + pad[0] + pad[1] - k) // stride + 1
+        out = torch.empty(B * Ho * Wo, C, dtype=self.dtype, device=self.device)
+        nslab = _lib.raw('mve_seg_dwconv_slabs')(B, Ho, Wo, C, k, stride)
+        sums = torch.empty(B, nslab, C, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.call('mve_seg_dwconv_pool', _dt(self.dtype), _lib.ptr(x), B, H, W, C, C, _lib.ptr(wb[0]), _lib.ptr(wb[1]), _lib.ptr(out), Ho, Wo, C,
+                      k, k, stride, pad[0], pad[0], ACT_SWISH, _lib.ptr(sums), _lib.stream_ptr(self.device))
+        return out, Ho, Wo, sums, nslab
+
+    def _pw(self, x, B, HW, wb, act=ACT_NONE, gate=None, residual=None):
+        """1 x 1 convolution on the matrix cores with bias, activation, the squeeze-and-excite gate on its input and the skip fused"""
+        return self._mconv(x, B, HW, 1, wb, act=act, gate=gate, residual=residual)
+
+    def _mconv(self, x, B, H, W, wb, k=(1, 1), pad=(0, 0), dil=1, act=ACT_NONE, gate=None, residual=None, out=None, ldo=None, ldx=None):
+        """mve_seg_mconv: stride-1 'same' convolution, weight [N][kh * kw * Cin] 16-bit -> out [B*H*W, N] (or a channel slice of `out`)"""
+        w, bias = wb
+        N = w.shape[0]
+        Cin = w.shape[1] // (k[0] * k[1])
+        if out is None:
+            out = torch.empty(B * H * W, N, dtype=self.dtype, device=self.device)
+            ldo = N
+        with torch.cuda.device(self.device):
+            _lib.call('mve_seg_mconv', _dt(self.dtype), _lib.ptr(x), B, H, W, Cin, ldx if ldx is not None else Cin, _lib.ptr(w), w.shape[1], k[0], k[1], dil,
+                      pad[0], pad[1], _lib.ptr(bias), _lib.ptr(gate), _lib.ptr(residual), N, _lib.ptr(out), N, ldo, act, _lib.stream_ptr(self.device))
+        return out
 
     def _act(self, x, act):
         with torch.cuda.device(self.device):
@@ -212,34 +243,35 @@ class TracerUniversalB7Engine:
             inp = x
             mid = cin * e
             if e != 1:
-                x = self._act(self._gemm(x, blk['expand']), ACT_SWISH)
-            x, H2, W2 = self._conv(x, B, H, W, mid, blk['dw'], mid, k=(k, k), stride=st, pad=pad, depthwise=True, act=ACT_SWISH)
-            pooled = self._mean(x, B, H2 * W2, mid)
+                x = self._pw(x, B, H * W, blk['expand'], act=ACT_SWISH)
+            x, H2, W2, sums, nslab = self._dwconv_pool(x, B, H, W, mid, blk['dw'], k, st, pad)
             gate = torch.empty(B, mid, dtype=torch.float32, device=self.device)
+            hidden = torch.empty(B * (se + mid), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 w1, b1, w2, b2 = blk['se']
-                _lib.call('mve_seg_se_gate', _lib.ptr(pooled), B, mid, se, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(gate), s(self.device))
-                _lib.call('mve_seg_scale', _dt(self.dtype), _lib.ptr(x), _lib.ptr(x), B, H2 * W2, mid, _lib.ptr(gate), None, s(self.device))
-            x = self._gemm(x, blk['project'], residual=inp if (st == 1 and cin == cout) else None)
+                _lib.call('mve_seg_se_gate', _lib.ptr(sums), nslab, 1.0 / (H2 * W2), B, mid, se, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
+                          _lib.ptr(hidden), _lib.ptr(gate), s(self.device))
+            x = self._pw(x, B, H2 * W2, blk['project'], gate=gate, residual=inp if (st == 1 and cin == cout) else None)
             H, W, C = H2, W2, cout
             if n in FEATURE_BLOCKS:
                 feats.append((x, H, W, C))
         return feats
 
     def _rfb(self, name, feat, B):
+        """RFB_Block (att_modules.py:23-72): four branches of 1 x 1 / 1 x k / k x 1 / dilated 3 x 3 BasicConv2d layers, all on the matrix cores"""
         x, H, W, Cin = feat
         P = self.p
         c = P[f'{name}.branch0.0'][0].shape[0]
         M = B * H * W
         cat = torch.empty(M, 4 * c, dtype=self.dtype, device=self.device)
-        self._conv(x, B, H, W, Cin, P[f'{name}.branch0.0'], c, act=ACT_SELU, out=cat, ldo=4 * c)
+        self._mconv(x, B, H, W, P[f'{name}.branch0.0'], act=ACT_SELU, out=cat, ldo=4 * c)
         for br, kk in ((1, 3), (2, 5), (3, 7)):
-            y, _, _ = self._conv(x, B, H, W, Cin, P[f'{name}.branch{br}.0'], c, act=ACT_SELU)
-            y, _, _ = self._conv(y, B, H, W, c, P[f'{name}.branch{br}.1'], c, k=(1, kk), pad=PadHW(0, 0, kk // 2, kk // 2), act=ACT_SELU)
-            y, _, _ = self._conv(y, B, H, W, c, P[f'{name}.branch{br}.2'], c, k=(kk, 1), pad=PadHW(kk // 2, kk // 2, 0, 0), act=ACT_SELU)
-            self._conv(y, B, H, W, c, P[f'{name}.branch{br}.3'], c, k=(3, 3), pad=(kk, kk), dil=kk, act=ACT_SELU, out=cat[:, br * c:], ldo=4 * c)
+            y = self._mconv(x, B, H, W, P[f'{name}.branch{br}.0'], act=ACT_SELU)
+            y = self._mconv(y, B, H, W, P[f'{name}.branch{br}.1'], k=(1, kk), pad=(0, kk // 2), act=ACT_SELU)
+            y = self._mconv(y, B, H, W, P[f'{name}.branch{br}.2'], k=(kk, 1), pad=(kk // 2, 0), act=ACT_SELU)
+            self._mconv(y, B, H, W, P[f'{name}.branch{br}.3'], k=(3, 3), pad=(kk, kk), dil=kk, act=ACT_SELU, out=cat[:, br * c:], ldo=4 * c)
         cc = self._act(self._conv3x3(cat, B, H, W, P[f'{name}.conv_cat']), ACT_SELU)
-        out, _, _ = self._conv(x, B, H, W, Cin, P[f'{name}.conv_res'], c, act=ACT_SELU, add=cc, ld2=c)
+        out = self._mconv(x, B, H, W, P[f'{name}.conv_res'], act=ACT_SELU, residual=cc)
         return self._act(out, ACT_RELU), H, W, c
 
     def _aggregation(self, e4, e3, e2, B):

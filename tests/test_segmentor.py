@@ -105,6 +105,61 @@ def test_engine_batch_chunks_and_shapes(lib):
     assert torch.equal(a, b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('B,H,W,Cin,N,k,pad,dil,gate,res,act', [
+    (2, 40, 40, 64, 32, (1, 1), (0, 0), 1, True, True, 0),       # project: SE gate on the operand, skip, two of four channel fragments
+    (3, 23, 17, 48, 288, (1, 1), (0, 0), 1, False, False, 1),    # expand + swish: K tail (48 = 32 + 16), ragged pixel tile
+    (2, 20, 20, 2304, 384, (1, 1), (0, 0), 1, True, True, 0),    # deep project: the split-K path (K >= 256, <= 6400 pixels per image)
+    (1, 20, 20, 640, 644, (1, 1), (0, 0), 1, False, False, 2),   # N % 64 = 4: the narrow store path
+    (2, 20, 20, 128, 128, (1, 7), (0, 3), 1, False, False, 2),   # RFB 1 x 7 (split-K: K = 896)
+    (2, 20, 20, 128, 128, (7, 1), (3, 0), 1, False, False, 2),   # RFB 7 x 1
+    (2, 40, 40, 64, 64, (3, 3), (5, 5), 5, False, True, 2),      # RFB dilated 3 x 3 with a residual
+    (1, 80, 80, 32, 32, (1, 3), (0, 1), 1, False, False, 2),     # RFB 1 x 3 at 80^2: no split (K = 96)
+])
+def test_mconv_vs_torch(lib, dtype, B, H, W, Cin, N, k, pad, dil, gate, res, act):
+    """mve_seg_mconv (matrix-core convolution with taps, SE gate, bias, activation, residual fused) against torch fp32 on the same 16-bit
+    operands; and an image's result must not depend on the batch it is launched with (bitwise)."""
+    import torch.nn.functional as F
+    from mvedit_amd import _lib
+    from mvedit_amd.ops import dt as _dt
+    g = torch.Generator().manual_seed(B * 1000 + N + Cin + k[0] * 7 + k[1])
+    dev = torch.device('cuda:0')
+    x = torch.randn(B, H, W, Cin, generator=g).to(dtype)
+    w = (torch.randn(N, k[0], k[1], Cin, generator=g) * (k[0] * k[1] * Cin) ** -0.5).to(dtype)
+    bias = torch.randn(N, generator=g) * 0.3
+    gt = torch.rand(B, Cin, generator=g) if gate else None
+    rs = torch.randn(B, H, W, N, generator=g).to(dtype) if res else None
+    xs = x.float() * gt[:, None, None, :] if gate else x.float()
+    xs = xs.to(dtype).float()                                  # the gated operand is rounded to the storage type, as x * gate is in the reference
+    ref = F.conv2d(xs.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), bias.double(), padding=pad, dilation=dil).permute(0, 2, 3, 1)
+    ref = {0: lambda t: t, 1: F.silu, 2: F.selu}[act](ref)
+    if res:
+        ref = ref + rs.double()
+
+    def run(xb, gb, rb, nb):
+        out = torch.empty(nb * H * W, N + 8, dtype=dtype, device=dev)[:, 4:4 + N] if N % 8 else torch.empty(nb * H * W, N, dtype=dtype, device=dev)
+        ldo = out.stride(0)
+        with torch.cuda.device(dev):
+            _lib.call('mve_seg_mconv', _dt(dtype), _lib.ptr(xb), nb, H, W, Cin, Cin, _lib.ptr(wd), k[0] * k[1] * Cin, k[0], k[1], dil, pad[0], pad[1],
+                      _lib.ptr(bd), _lib.ptr(gb), _lib.ptr(rb), N, _lib.ptr(out), N, ldo, act, _lib.stream_ptr(dev))
+        return out
+
+    wd, bd = w.reshape(N, -1).contiguous().to(dev), bias.to(dev)
+    xd = x.reshape(B * H * W, Cin).to(dev)
+    gd = gt.to(dev) if gate else None
+    rd = rs.reshape(B * H * W, N).to(dev) if res else None
+    out = run(xd, gd, rd, B)
+    torch.cuda.synchronize()
+    err = (out.double().cpu() - ref.reshape(B * H * W, N)).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= (1.2e-2 if dtype == torch.bfloat16 else 1.6e-3) * max(scale, 1.0), (err, scale)
+    b0 = B - 1                                                   # the last image alone
+    sl = slice(b0 * H * W, B * H * W)
+    one = run(xd[sl].contiguous(), gd[b0:].contiguous() if gate else None, rd[sl].contiguous() if res else None, 1)
+    assert torch.equal(one, out[sl])
+
+
 def test_do_segmentation_host_logic_equals_reference_function():
     """mvedit_amd.pipelines.utils.do_segmentation / Adapter3DMixin.get_tgt_masks against the reference's own functions EXECUTED
     (lib/pipelines/utils.py:73-107, adapter3d_mixin.py:14-19, cut out with ast) over a stand-in segmentor; skipped where /root/reference is absent."""

@@ -147,6 +147,8 @@ def test_conv3x3_resblock_epilogue(lib):
 @pytest.mark.parametrize('B,HW,C1,C2,silu,eps', [(2, 64 * 64, 320, 0, True, 1e-5), (3, 16 * 16, 1280, 640, True, 1e-5),
                                                   (2, 8 * 8, 2560, 0, True, 1e-5), (2, 32 * 32, 640, 0, False, 1e-6),
                                                   (1, 33, 640, 320, True, 1e-5),
+                                                  # one-launch path on 1024 threads, XCD-grouped block order (B % 8 == 0)
+                                                  (8, 32 * 32, 640, 320, True, 1e-5), (8, 32 * 32, 1280, 1280, True, 1e-5),
                                                   # the VAE's narrow tensors (16- and 32-lane layouts, many row splits)
                                                   (2, 96 * 96, 128, 0, True, 1e-6), (1, 64 * 64, 256, 0, False, 1e-6),
                                                   (2, 700, 64, 64, True, 1e-6), (3, 231, 32, 0, True, 1e-6)])
@@ -164,6 +166,31 @@ def test_groupnorm(lib, dtype, B, HW, C1, C2, silu, eps):
     ref = ref.permute(0, 2, 1).reshape(B * HW, C)
     out = ops.groupnorm(x1.cuda(), B, HW, gamma.cuda(), beta.cuda(), 32, eps, silu, x2.cuda() if C2 else None)
     check('groupnorm', out, ref, dtype, f'{(B, HW, C1, C2, silu)}')
+
+
+@pytest.mark.parametrize('HW,C1,C2,fused_max_hw', [(32 * 32, 640, 0, 1024), (16 * 16, 1280, 640, 1024), (64 * 64, 320, 0, 1024),
+                                                     (64 * 64, 320, 320, 1024), (64 * 64, 320, 0, 4096), (64 * 64, 320, 320, 4096)])
+def test_groupnorm_batch_invariance_and_paths(lib, HW, C1, C2, fused_max_hw):
+    """An image's GroupNorm output must not depend on how many images share the launch (bitwise), on either path; and the one-launch
+    path (statistics out of registers) agrees with the three-launch path to rounding."""
+    from mvedit_amd import ops, _lib
+    dtype, B = torch.float16, 16
+    C = C1 + C2
+    x1 = (rnd((B * HW, C1), dtype, 1) + 0.5).cuda()
+    x2 = (rnd((B * HW, C2), dtype, 2) * 2 - 1).to(dtype).cuda() if C2 else None
+    gamma, beta = (1 + 0.2 * rnd((C,), torch.float32, 3)).cuda(), (0.2 * rnd((C,), torch.float32, 4)).cuda()
+    prev = _lib.raw('mve_groupnorm_tune')(fused_max_hw)
+    try:
+        full = ops.groupnorm(x1, B, HW, gamma, beta, 32, 1e-5, True, x2)
+        for b0, nb in ((0, 1), (5, 3), (8, 8)):
+            sl = slice(b0 * HW, (b0 + nb) * HW)
+            part = ops.groupnorm(x1[sl].contiguous(), nb, HW, gamma, beta, 32, 1e-5, True, x2[sl].contiguous() if C2 else None)
+            assert torch.equal(part, full[sl]), f'images {b0}..{b0 + nb} differ between a {nb}-image and a {B}-image launch'
+        _lib.raw('mve_groupnorm_tune')(0)
+        three = ops.groupnorm(x1, B, HW, gamma, beta, 32, 1e-5, True, x2)
+    finally:
+        _lib.raw('mve_groupnorm_tune')(prev)
+    assert (full.float() - three.float()).abs().max().item() <= 4e-3
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
