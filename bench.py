@@ -226,8 +226,17 @@ def secondary(dev):
     cfg = dict(return_rgba=True, compute_normal=True, dt_gamma_scale=0.0)
     t = timed(lambda: nr.render(dec, None, bits[None], S, S, intr[None], poses[None], cfg=cfg))
     nbytes = ro.shape[0] * 52 + samples * (56 + 768)
+    # The renderer is bound by the rate at which a CU's texture path resolves lane addresses, not by HBM bytes: a sample is 12 levels x 8 corner
+    # fetches of 8 bytes from a ~30 MB table.  tools/probe/gather_probe.hip (profiles/r03_gather_probe.log) measures what the chip sustains on
+    # UNRELATED 8-byte fetches -- 268 G/s from a 2 MiB (L2-resident) table, 80 G/s from 16 MiB (LLC), 56 G/s from HBM, independent of occupancy
+    # and of the fetches in flight per lane (a throughput limit: ~0.5 lane addresses per CU per clock).  The renderer's fetches are not unrelated
+    # (corner pairs share a line, neighbouring rays share cells), which is the only reason it can exceed those figures.
+    fetches = samples * 96
     out['nerf_render'] = dict(views_per_s=round(nv / t, 1), ms=round(t * 1e3, 2), rays=ro.shape[0], samples=samples,
-                              algorithmic_GBps=round(nbytes / t / 1e9, 1), frac_of_hbm_peak=round(nbytes / t / 8e12, 4))
+                              algorithmic_GBps=round(nbytes / t / 1e9, 1),
+                              fetch_model=dict(fetches_per_sample=96, fetch_rate_G_per_s=round(fetches / t / 1e9, 1),
+                                               random_fetch_rate_G_per_s=dict(l2_2MiB=268.0, llc_16MiB=80.0, hbm_1GiB=56.0),
+                                               vs_random_llc=round(fetches / t / 80e9, 2), source='profiles/r03_gather_probe.log'))
     # ---- mesh: rasterise + full MeshRenderer.forward -------------------------------------------------------------------------
     v, fc = icosphere(6, 0.6)
     vt, ft = face_atlas(fc)
@@ -251,7 +260,8 @@ def secondary(dev):
     t = timed(lambda: mr.bake_multiview([mesh], images, alphas, poses32[None], intr32[None], map_size=1024, render_bs=8), it=2)
     tb = V * 1024 * 1024 * 36
     out['bake_multiview'] = dict(texel_views_per_s=round(V * 1024 * 1024 / t / 1e9, 3), unit='G texel-views/s', ms=round(t * 1e3, 2),
-                                 algorithmic_GBps=round(tb / t / 1e9, 1), frac_of_hbm_peak=round(tb / t / 8e12, 4))
+                                 algorithmic_GBps=round(tb / t / 1e9, 1),
+                                 note='atomic- and gather-rate bound (64-bit visibility atomics, mip-mapped fetches): not priced against HBM bytes')
     # ---- one SD-1.5 ControlNet over the 64 images of a step (0.28 TFLOP per image incl. the 512^2 embedding) ----
     from mvedit_amd.controlnet import ControlNetEngine
     from mvedit_amd.unet import SD15_CONFIG

@@ -117,6 +117,7 @@ struct Param {   // one engine-owned packed tensor (or a slice view of one)
     size_t off = 0;       // byte offset in the weight slab
     size_t bytes = 0;
     bool f32 = false;
+    float q_fold = 0.f;   // > 0: a to_q weight whose rows carry head_dim^-1/2 * log2(e) (the attention kernel then takes Q as it comes)
 };
 
 enum OpClass { OC_CONV = 0, OC_LINEAR = 1, OC_ATTN = 2, OC_NORM = 3, OC_OTHER = 4, OC_COUNT = 5 };

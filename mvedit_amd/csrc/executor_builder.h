@@ -92,9 +92,20 @@ struct Builder {
             return mve_layernorm(d, r.p(x), C, r.p(y), C, M, C, (const float*)r.p(g), (const float*)r.p(b), 1e-5f, r.stream);
         });
     }
-    void attn(Ref q, int ldq, Ref k, int ldk, Ref v, int ldv, Ref o, int ldo, int Bn, int Lq, int Lk, int heads, int hd,
+    // Q as mve_attention_prescaled wants it: the output of a GEMM over a to_q weight slot that carries the softmax scale.  The only way to get one
+    // is prescaled(): a caller that projects Q with unfolded weights cannot reach attn() by accident.
+    struct PrescaledQ { Ref q; };
+    PrescaledQ prescaled(Ref q, const std::string& weight_slot, int hd) {
+        auto it = u.params.find(weight_slot);
+        const float want = 1.4426950408889634f / sqrtf((float)hd);
+        if (it == u.params.end() || !(fabsf(it->second.q_fold - want) <= 1e-6f * want))
+            u.err = "attention: Q is not produced by a to_q slot folded with head_dim^-1/2 * log2(e) (" + weight_slot + ")";
+        return PrescaledQ{q};
+    }
+    void attn(PrescaledQ pq, int ldq, Ref k, int ldk, Ref v, int ldv, Ref o, int ldo, int Bn, int Lq, int Lk, int heads, int hd,
               Ref k2 = Ref(), int ldk2 = 0, Ref v2 = Ref(), int ldv2 = 0, int Lk2 = 0, const char* what = "attention") {
         const int d = dt;
+        const Ref q = pq.q;
         if (Bn <= 0) return;
         live(q, what); live(k, what); live(v, what); live(o, what);
         op(OC_ATTN, 4.0 * Bn * heads * (double)Lq * (Lk + Lk2) * hd, what, [=](const Run& r) {
@@ -194,7 +205,7 @@ struct Builder {
             Ref a = ws((size_t)M * C * e);
             const AttnOpts& ao = pl.ao;
             if (ao.ref_mode == 0) {
-                attn(qkv, 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, nb, L, L, heads, hd);
+                attn(prescaled(qkv, b + ".qkv.w", hd), 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, nb, L, L, heads, hd);
             } else {
                 // reference attention: the store holds, per self-attention layer in execution order, the keys|values
                 // [B - ref_skip][Lref][2C] of the pass that ran in 'w' mode (to_k / to_v act per token, so K(cat[x, ref]) =
@@ -205,13 +216,13 @@ struct Builder {
                 Ref st; st.kind = Ref::REFSTORE; st.off = ref_off;
                 ref_off += (size_t)nr * Lref * 2 * C * e;
                 if (ao.ref_mode == 1) {
-                    attn(qkv, 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, nb, L, L, heads, hd);
+                    attn(prescaled(qkv, b + ".qkv.w", hd), 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, nb, L, L, heads, hd);
                     copy2d(st, (size_t)2 * C * e, at(qkv, ((size_t)skip * L * 3 * C + C) * e), (size_t)3 * C * e, (size_t)2 * C * e,
                            (size_t)nr * L, "reference K,V -> store");
                 } else {
-                    attn(qkv, 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, skip, L, L, heads, hd);
+                    attn(prescaled(qkv, b + ".qkv.w", hd), 3 * C, at(qkv, (size_t)C * e), 3 * C, at(qkv, (size_t)2 * C * e), 3 * C, a, C, skip, L, L, heads, hd);
                     const size_t o = (size_t)skip * L * 3 * C * e;
-                    attn(at(qkv, o), 3 * C, at(qkv, o + (size_t)C * e), 3 * C, at(qkv, o + (size_t)2 * C * e), 3 * C,
+                    attn(prescaled(at(qkv, o), b + ".qkv.w", hd), 3 * C, at(qkv, o + (size_t)C * e), 3 * C, at(qkv, o + (size_t)2 * C * e), 3 * C,
                          at(a, (size_t)skip * L * C * e), C, nr, L, L, heads, hd, st, 2 * C, at(st, (size_t)C * e), 2 * C, Lref,
                          "attention (+reference tokens)");
                 }
@@ -228,10 +239,10 @@ struct Builder {
             rel(n2);
             Ref a2 = ws((size_t)M * C * e);
             const size_t ko = (size_t)u.kv_off[b] * e;
-            attn(q, C, at(ctxkv, ko), ld_kv, at(ctxkv, ko + (size_t)C * e), ld_kv, a2, C, nb, L, Lt, heads, hd);
+            attn(prescaled(q, b + ".q2.w", hd), C, at(ctxkv, ko), ld_kv, at(ctxkv, ko + (size_t)C * e), ld_kv, a2, C, nb, L, Lt, heads, hd);
             if (ao.ip_tokens > 0) {     // hidden_states + scale * SDPA(q, to_k_ip(ip), to_v_ip(ip))  (attention_processor.py:366-383)
                 Ref aip = ws((size_t)M * C * e);
-                attn(q, C, at(ipkv, ko), ld_kv, at(ipkv, ko + (size_t)C * e), ld_kv, aip, C, nb, L, ao.ip_tokens, heads, hd, Ref(), 0, Ref(), 0,
+                attn(prescaled(q, b + ".q2.w", hd), C, at(ipkv, ko), ld_kv, at(ipkv, ko + (size_t)C * e), ld_kv, aip, C, nb, L, ao.ip_tokens, heads, hd, Ref(), 0, Ref(), 0,
                      0, "attention (ip tokens)");
                 const int d = dt;
                 const float sc = ao.ip_scale;

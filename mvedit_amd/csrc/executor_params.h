@@ -10,9 +10,9 @@ namespace {
 struct SlabBuilder {
     Unet& u;
     size_t top = 0;
-    void add(const std::string& name, size_t elems, bool f32) {
+    void add(const std::string& name, size_t elems, bool f32, float q_fold = 0.f) {
         Param p;
-        p.off = top; p.f32 = f32; p.bytes = elems * (f32 ? 4 : 2);
+        p.off = top; p.f32 = f32; p.bytes = elems * (f32 ? 4 : 2); p.q_fold = q_fold;
         top += (p.bytes + 255) & ~(size_t)255;
         u.params[name] = p;
     }
@@ -158,11 +158,13 @@ void layout_params(Unet& u) {
                 sb.add(b + "." + nn + ".g", C, true); need(b + "." + nn + ".weight");
                 sb.add(b + "." + nn + ".b", C, true); need(b + "." + nn + ".bias");
             }
-            sb.add(b + ".qkv.w", 3 * C * C, false);
+            // to_q rows carry softmax_scale * log2(e) = head_dim^-1/2 * log2(e): recorded on the slot, applied by load_param, required by Builder::attn
+            const float qf = 1.4426950408889634f / sqrtf((float)(C / x.heads));
+            sb.add(b + ".qkv.w", 3 * C * C, false, qf);
             need(b + ".attn1.to_q.weight"); need(b + ".attn1.to_k.weight"); need(b + ".attn1.to_v.weight");
             sb.add(b + ".o1.w", C * C, false); need(b + ".attn1.to_out.0.weight");
             sb.add(b + ".o1.b", C, true); need(b + ".attn1.to_out.0.bias");
-            sb.add(b + ".q2.w", C * C, false); need(b + ".attn2.to_q.weight");
+            sb.add(b + ".q2.w", C * C, false, qf); need(b + ".attn2.to_q.weight");
             need(b + ".attn2.to_k.weight"); need(b + ".attn2.to_v.weight");
             sb.add(b + ".o2.w", C * C, false); need(b + ".attn2.to_out.0.weight");
             sb.add(b + ".o2.b", C, true); need(b + ".attn2.to_out.0.bias");
@@ -253,12 +255,10 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
     };
     // to_q rows carry softmax_scale * log2(e) = head_dim^-1/2 * log2(e): the attention kernel then works in log2 units without a multiply per
     // logit (mve_attention_prescaled).  One rounding either way: the factor is applied in fp32 before the weight is rounded to 16 bits.
-    auto q_fold = [&](const std::string& block) -> float {
-        std::vector<ResnetDesc> rs; std::vector<XfDesc> xs;
-        enumerate(c, rs, xs);
-        for (const XfDesc& x : xs)
-            if (block.compare(0, x.name.size() + 1, x.name + ".") == 0) return 1.4426950408889634f / sqrtf((float)(x.c / x.heads));
-        return 0.f;
+    // The factor lives on the destination slot (layout_params): no second walk over the configuration per tensor.
+    auto q_fold = [&](const std::string& slot) -> float {
+        auto it = u.params.find(slot);
+        return it == u.params.end() ? 0.f : it->second.q_fold;
     };
     long long conv_row = 0;    // destination row length of the conv packer when the row also holds a fused shortcut (0: 9 * I)
     auto conv = [&](Param* p, long long O, long long I, long long Opad, long long Ipad) -> int {   // OIHW -> [O][3][3][Ipad]
@@ -423,7 +423,7 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         const int which = name[name.size() - 8] == 'q' ? 0 : (name[name.size() - 8] == 'k' ? 1 : 2);
         const std::string b = name.substr(0, name.size() - std::string(".attn1.to_q.weight").size());
         const long long C = shape[0];
-        const float fold = which == 0 ? q_fold(b) : 1.0f;
+        const float fold = which == 0 ? q_fold(b + ".qkv.w") : 1.0f;
         MVE_CHECK(fold > 0.f, MVE_ERR_ARG, "load_param: %s is not in a known transformer block", name.c_str());
         rc = mat(P(b + ".qkv.w"), (size_t)which * C * C, C, C, C, fold);
     } else if (ends_with(name, ".attn2.to_k.weight") || ends_with(name, ".attn2.to_v.weight")) {
@@ -440,7 +440,7 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
         rc = mat(P("ip_kv.w"), ((size_t)u.kv_off[b] + (size_t)which * C) * c.ctx_dim, C, c.ctx_dim, c.ctx_dim);
         if (rc == MVE_OK && !u.loaded.count(name)) ++u.n_ip_loaded;
     } else if (ends_with(name, ".attn2.to_q.weight")) {
-        const float fold = q_fold(strip(name, ".attn2.to_q.weight"));
+        const float fold = q_fold(strip(name, ".attn2.to_q.weight") + ".q2.w");
         MVE_CHECK(fold > 0.f, MVE_ERR_ARG, "load_param: %s is not in a known transformer block", name.c_str());
         rc = mat(P(strip(name, ".attn2.to_q.weight") + ".q2.w"), 0, shape[0], shape[1], shape[1], fold);
     }
