@@ -727,7 +727,7 @@ MVE_API int mve_antialias_backward(const float* d_grad_out, int B, int H, int W,
                                    const int32_t* d_tri, int F, const int32_t* d_opp, float* d_grad_color, void* stream);
 
 /* Tri-plane radiance decoders: `TriPlaneDecoder.point_decode` (lib/models/decoders/triplane_decoder.py:135-199)
- * and `TriPlaneiNGPDecoder.point_decode` (lib/models/decoders/triplane_ingp_decoder.py:142-212) for one scene, forward only:
+ * and `TriPlaneiNGPDecoder.point_decode` (lib/models/decoders/triplane_ingp_decoder.py:142-212) for one scene, forward (backward below):
  *   feature k = c * 3 + p of a point = bilinear F.grid_sample(padding_mode='border', align_corners=False) of channel c of plane p at the
  *   point's two coordinates for that plane (plane_cfg; flip_z negates z);  base_x = base_net(features) [+ ingp_base_net(hash-grid encoding
  *   of (xyz + bound) / (2 bound), tiny-cuda-nn HashGrid with Smoothstep interpolation)];  sigma = sigma_activation(density_net(act(base_x)));
@@ -758,6 +758,23 @@ typedef struct MveTriplaneDesc {
     float *d_sigmas, *d_rgbs;                        /* [N], [N,3] (d_rgbs unused when d_dirs is NULL) */
 } MveTriplaneDesc;
 MVE_API int mve_triplane_decode(const MveTriplaneDesc* desc, void* stream);
+/* Backward of mve_triplane_decode: gradients of sum(d_grad_sigmas * sigma) + sum(d_grad_rgbs * rgb) (d_grad_rgbs NULL: density only) -- what
+ * autograd supplies when nerf_optim optimises a TriPlaneiNGPDecoder scene (lib/pipelines/mvedit_3d_pipeline.py:507-633 through
+ * triplane_ingp_decoder.py:142-212; trunc_exp backward as lib/ops/activation.py:17-20).  Weight gradients come in the torch layout of the
+ * reference modules ([out][in], OVERWRITTEN, reduced in a fixed order); d_code [3][h][w][C] and d_table [rows][2] are ACCUMULATED into
+ * (float atomics, like F.grid_sample's / tiny-cuda-nn's backward; either may be NULL).  The forward is recomputed: desc's outputs are not
+ * read or written. */
+typedef struct MveTriplaneGrads {
+    float *d_code, *d_table;
+    float *d_base_w, *d_base_b;                      /* [hidden][3C], [hidden] */
+    float *d_ingp_w, *d_ingp_b;                      /* [hidden][2 n_levels], [hidden] (NULL without a hash branch) */
+    float *d_dens_w, *d_dens_b;                      /* [1][hidden], [1] */
+    float *d_col1_w, *d_col1_b;                      /* [hidden2][hidden + 16], [hidden2] */
+    float *d_col2_w, *d_col2_b;                      /* [3][hidden2], [3] */
+} MveTriplaneGrads;
+MVE_API size_t mve_triplane_backward_workspace_bytes(int N, int C, int hidden, int hidden2, int n_levels);
+MVE_API int mve_triplane_backward(const MveTriplaneDesc* desc, const float* d_grad_sigmas, const float* d_grad_rgbs, const MveTriplaneGrads* grads,
+                                  void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Mip-mapped texture path: what the reference gets from nvdiffrast with MeshRenderer(texture_filter='linear-mipmap-linear') -- its default
  * (lib/models/decoders/mesh_renderer/base_mesh_renderer.py:196) -- in forward (:241, :260-264, :357-361), get_cam_weights_uv (:442, :466-475,

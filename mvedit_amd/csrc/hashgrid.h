@@ -84,4 +84,45 @@ __device__ __forceinline__ void hash_encode(const DecoderParams& p, float x, flo
     }
 }
 
+// transpose of hash_encode: g_table[row(corner)] += corner weight * denc[2 l .. 2 l + 1] (float atomics, as tiny-cuda-nn's backward)
+template <int NL>
+__device__ __forceinline__ void hash_scatter(const DecoderParams& p, float x, float y, float z, const float (&denc)[2 * NL], float* __restrict__ g_table) {
+    const float inv = 1.0f / (2.0f * p.bound);
+    const float u[3] = {(x + p.bound) * inv, (y + p.bound) * inv, (z + p.bound) * inv};
+#pragma unroll 1
+    for (int l = 0; l < NL; ++l) {
+        const float scale = p.g.scale[l];
+        const uint32_t res = p.g.res[l], size = p.g.size[l];
+        uint32_t cell[3];
+        float w[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float pos = fmaf(scale, u[d], 0.5f);
+            const float fl = floorf(pos);
+            cell[d] = (uint32_t)(int)fl;
+            const float fr = pos - fl;
+            w[d] = fr * fr * (3.0f - 2.0f * fr);
+        }
+        const bool s1 = res <= size;
+        const bool s2 = s1 && (uint64_t)res * res <= size;
+        const uint64_t stride3 = (uint64_t)res * res * (s2 ? res : 1u);
+        const bool hashed = s2 ? (size < stride3) : true;
+        float* gt = g_table + 2ull * p.g.off[l];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            float wt = 1.0f;
+            uint32_t c[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (corner & (1 << d)) { wt = wt * w[d]; c[d] = cell[d] + 1u; }
+                else { wt = wt * (1.0f - w[d]); c[d] = cell[d]; }
+            }
+            uint32_t idx = hashed ? ((c[0] * 1u) ^ (c[1] * 2654435761u) ^ (c[2] * 805459861u)) : (c[0] + c[1] * res + c[2] * res * res);
+            idx %= size;
+            atomicAdd(gt + 2ull * idx, wt * denc[2 * l]);
+            atomicAdd(gt + 2ull * idx + 1, wt * denc[2 * l + 1]);
+        }
+    }
+}
+
 }  // namespace

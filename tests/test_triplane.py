@@ -103,3 +103,78 @@ def test_hip_large_batch_vs_oracle_and_timing(lib):
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 5
     print(f'tri-plane decode: {N} points in {ms:.3f} ms = {N / ms / 1e6:.2f} G points/s, {N * 31.2e3 * 2 / ms / 1e9:.1f} TFLOP/s fp32')
+
+
+_ONAME = {'base_net.0.weight': 'base_w', 'base_net.0.bias': 'base_b', 'density_net.0.weight': 'dens_w', 'density_net.0.bias': 'dens_b',
+          'color_net.0.weight': 'col1_w', 'color_net.0.bias': 'col1_b', 'color_net.2.weight': 'col2_w', 'color_net.2.bias': 'col2_b',
+          'ingp_base_net.0.weight': 'ingp_w', 'ingp_base_net.0.bias': 'ingp_b'}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('density_only', [False, True], ids=['sigma+rgb', 'sigma'])
+@pytest.mark.parametrize('tag', list(CASES))
+def test_hip_backward_vs_oracle_autograd(lib, tag, density_only):
+    """mve_triplane_backward (behind point_decode_autograd) against torch autograd over the float64 oracle: gradients of a random linear
+    functional of (sigma, rgb) w.r.t. the code planes and every Linear; the hash-table gradient (the oracle's encoder is numpy) through a
+    directional finite difference of the oracle along a random table direction (sigma and rgb are smooth in the table)."""
+    c = CASES[tag]
+    eng = _engine(tag)
+    g = torch.Generator().manual_seed(11)
+    N = 3000
+    xyz = torch.rand(N, 3, generator=g) * 2.2 - 1.1                       # some points outside the planes: border padding
+    dirs = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    code = torch.from_numpy(G[f'{tag}_code']).clone()
+    g_sig = torch.randn(N, generator=g) * 0.1
+    g_rgb = torch.randn(N, 3, generator=g)
+
+    def oracle_loss(w64, code64, table):
+        hash_ = dict(HASH, table=table) if c['ingp'] else None
+        so, ro = TO.point_decode(xyz.double(), None if density_only else dirs.double(), code64, w64, c['plane_cfg'], c['flip_z'], c['activation'],
+                                 hash=hash_, density_only=density_only)
+        loss = (so * g_sig.double()).sum()
+        return loss if density_only else loss + (ro * g_rgb.double()).sum()
+
+    w64 = {k: v.clone().requires_grad_(True) for k, v in weights(tag, torch.float64).items()}
+    code64 = code[0].double().clone().requires_grad_(True)
+    table = G[f'{tag}_table'] if c['ingp'] else None
+    oracle_loss(w64, code64, table).backward()
+
+    for p in eng.parameters().values():
+        p.requires_grad_(True)
+    code_d = code.cuda().requires_grad_(True)
+    sig, rgb, n = eng.point_decode_autograd([xyz.cuda()], [dirs.cuda()], code_d, density_only=density_only)
+    assert n == [N] and (rgb is None) == density_only
+    loss = (sig * g_sig.cuda()).sum()
+    if not density_only:
+        loss = loss + (rgb * g_rgb.cuda()).sum()
+    loss.backward()
+
+    def close(got, want, what):
+        want = want.float()
+        scale = want.abs().max().item()
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-6, f'{tag} {what}: max |d| {err:.3e} against a gradient of magnitude {scale:.3e}'
+
+    close(code_d.grad[0], code64.grad, 'code planes')
+    colour = ('color_net.0.weight', 'color_net.0.bias', 'color_net.2.weight', 'color_net.2.bias')
+    for name, p in eng.parameters().items():
+        if name == 'encoder.params':
+            continue
+        if density_only and name in colour:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+            continue
+        close(p.grad.reshape(w64[_ONAME[name]].shape), w64[_ONAME[name]].grad, name)
+    if c['ingp']:
+        gt = eng.parameters()['encoder.params'].grad.cpu().reshape(-1, 2)
+        rng = np.random.default_rng(3)
+        D = rng.standard_normal(table.shape).astype(np.float32)
+        eps = 1e-2
+        w0 = {k: v.detach() for k, v in w64.items()}
+        with torch.no_grad():
+            fd = (oracle_loss(w0, code64.detach(), table + eps * D) - oracle_loss(w0, code64.detach(), table - eps * D)).item() / (2 * eps)
+        an = float((gt.double() * torch.from_numpy(D).double()).sum())
+        assert abs(fd - an) <= 2e-3 * max(abs(fd), abs(an)) + 1e-4, (fd, an)
+    # repeated backward passes accumulate like any autograd leaf; the forward of point_decode_autograd equals point_decode
+    with torch.no_grad():
+        s2, r2, _ = eng.point_decode([xyz.cuda()], None if density_only else [dirs.cuda()], code.cuda(), density_only=density_only)
+    assert torch.equal(s2, sig.detach()) and (density_only or torch.equal(r2, rgb.detach()))

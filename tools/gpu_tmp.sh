@@ -1,4 +1,3 @@
 #!/bin/bash
-timeout 300 ./tools/probe/gather_probe > gpurun_out/r03_gather_probe.log 2>&1
-cat gpurun_out/r03_gather_probe.log
-timeout 900 python -m pytest tests/test_unet.py -x -q -m gpu 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_triplane.py -x -q -m gpu > gpurun_out/r03_pytest_triplane.log 2>&1
+tail -30 gpurun_out/r03_pytest_triplane.log
