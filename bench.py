@@ -306,7 +306,8 @@ def secondary(dev):
         fl = enh.plan(VIEWS, side, side, torch.float16)['flops']['conv']
         out[f'image_enhancer_{side}'] = dict(ms=round(t * 1e3, 2), views=VIEWS, ms_per_view=round(t * 1e3 / VIEWS, 3), tflops_per_s=round(fl / t / 1e12, 1))
     del enh
-    # ---- TRACER-B7 foreground masks of the V denoised views (adapter3d_mixin.py:14-19 -> tracer_b7.py:56-73; 640^2 input, chunks of 8, bf16) ----
+    # ---- TRACER-B7 foreground masks of the V denoised views (adapter3d_mixin.py:14-19 -> tracer_b7.py:56-73; 640^2 input, bf16; the reference's
+    # batch_size = 8 is honoured as a lower bound: the engine walks chunks of 32 views, bitwise the same masks) ----
     from mvedit_amd.segmentor import TracerUniversalB7Engine
     seg = TracerUniversalB7Engine(input_image_size=640, batch_size=8, torch_dtype='bfloat16', erosion=1, device=dev).load_state_dict(SY.make_tracer_state_dict(3))
     views = torch.rand(VIEWS, 3, 8 * LATENT, 8 * LATENT, device=dev)

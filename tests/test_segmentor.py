@@ -99,10 +99,11 @@ def test_engine_batch_chunks_and_shapes(lib):
     from mvedit_amd import synthetic as S
     sd = S.make_tracer_state_dict(5)
     x = torch.rand(3, 3, 100, 140, generator=torch.Generator().manual_seed(1))
-    a = TracerUniversalB7Engine(input_image_size=128, batch_size=8, torch_dtype='bfloat16').load_state_dict(sd)(x.cuda())
-    b = TracerUniversalB7Engine(input_image_size=128, batch_size=2, torch_dtype='bfloat16').load_state_dict(sd)(x.cuda())
+    a = TracerUniversalB7Engine(input_image_size=128, batch_size=8, torch_dtype='bfloat16').load_state_dict(sd)(x.cuda())                 # one chunk of 3
+    b = TracerUniversalB7Engine(input_image_size=128, batch_size=2, torch_dtype='bfloat16', min_chunk=1).load_state_dict(sd)(x.cuda())    # chunks of 2 + 1
+    c = TracerUniversalB7Engine(input_image_size=128, batch_size=1, torch_dtype='bfloat16', min_chunk=1).load_state_dict(sd)(x.cuda())    # one view at a time
     assert a.shape == (3, 1, 100, 140) and a.dtype == torch.bfloat16
-    assert torch.equal(a, b)
+    assert torch.equal(a, b) and torch.equal(a, c)           # the engine's larger internal chunks (min_chunk = 32) rest on this
 
 
 @pytest.mark.gpu

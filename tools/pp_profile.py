@@ -42,12 +42,15 @@ def report(name, f, nblocks, nsteps, flops):
           f'group1 L {g1[0]:.0f} (reads {g1[4]:.0f} prep {g1[5]:.0f}) waitL {g1[1]:.0f} M {g1[2]:.0f} waitM {g1[3]:.0f} sum {tot1:.0f} | MFMA floor 640 per section', flush=True)
 
 
-for (H, C1, Cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280)]:
+for (H, C1, Cout) in ([] if (len(sys.argv) > 1 and sys.argv[1] == 'deep') else [(64, 320, 320), (32, 640, 640), (16, 1280, 1280)]):
     x = torch.randn(B * H * H, C1, device=dev, dtype=dt)
     w = torch.randn(Cout, C1 // 64, 3, 3, 64, device=dev, dtype=dt) * (9 * C1) ** -0.5
     f = lambda: ops.conv3x3(x, w, B, H, H, flags=ops.W_CHUNK64, splitk=False)
     report(f'conv H={H} {C1}->{Cout}', f, (B * H * H // 256) * (Cout // 320), 9 * C1 // 32, 2 * B * H * H * Cout * 9 * C1)
-for (M, N, K, fl) in [(B * 4096, 2560, 320, 1), (B * 4096, 320, 1280, 0), (B * 1024, 640, 2560, 0), (B * 256, 3840, 1280, 0)]:
+shapes = [(B * 4096, 2560, 320, 1), (B * 4096, 320, 1280, 0), (B * 1024, 640, 2560, 0), (B * 256, 3840, 1280, 0), (B * 256, 1280, 1280, 0), (B * 1024, 640, 640, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == 'deep':
+    shapes = shapes[-2:]
+for (M, N, K, fl) in shapes:
     a = torch.randn(M, K, device=dev, dtype=dt)
     w = torch.randn(N, K, device=dev, dtype=dt) * K ** -0.5
     f = lambda: ops.gemm(a, w, flags=ops.GEGLU if fl else 0, rows_per_image=0)

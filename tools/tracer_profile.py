@@ -14,7 +14,8 @@ dev = torch.device('cuda:0')
 dtype = sys.argv[1] if len(sys.argv) > 1 else 'bfloat16'
 seg = TracerUniversalB7Engine(input_image_size=640, batch_size=8, torch_dtype=dtype, erosion=1, device=dev).load_state_dict(SY.make_tracer_state_dict(3))
 g = torch.Generator(device='cpu').manual_seed(5)
-x = torch.rand(8, 3, 512, 512, generator=g).to(dev)
+NV = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+x = torch.rand(NV, 3, 512, 512, generator=g).to(dev)
 for _ in range(2):
     m = seg(x)
 torch.cuda.synchronize()
@@ -24,4 +25,4 @@ for _ in range(n):
     m = seg(x)
 torch.cuda.synchronize()
 t = (time.perf_counter() - t0) / n
-print(f'tracer_b7 8 views 512^2 -> 640^2 {dtype}: {t * 1e3:.2f} ms per chunk = {t * 1e3 / 8:.2f} ms per view; mask mean {float(m.mean()):.4f}')
+print(f'tracer_b7 {NV} views 512^2 -> 640^2 {dtype}: {t * 1e3:.2f} ms per call = {t * 1e3 / NV:.2f} ms per view; mask mean {float(m.mean()):.4f}')
