@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))          # tests/ may use the oracle (tools/ may not)
 from oracle import unet_oracle as UO
 from mvedit_amd.unet import SD15_CONFIG
 
