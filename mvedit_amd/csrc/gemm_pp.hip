@@ -477,6 +477,7 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
             if (k + 1 == fold_at) {
                 pp_mfma_settle();
                 pp_wait_vm<0>();
+                asm volatile("; pp_fold_begin");          // tools/check_pp_isa.py: compiler-generated memory traffic is legal only up to pp_fold_end
                 // (the offset passes through an opaque asm so that the 40 slot addresses are formed here, not hoisted out of the K loop
                 // into 80 registers that would be spilled -- scratch reloads on the hot path would drain vmcnt)
                 size_t tot_off = (size_t)tile * (PBM * BN2 / 4) + (size_t)wid * (NF * MF * 64) + lane;
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
                         else { *slot = t; acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                asm volatile("; pp_fold_end");
                 pp_wait_vm<0>();
                 ++sl_idx;
                 fold_at = 2 * __builtin_amdgcn_readfirstlane((int)((long long)nk_all * (sl_idx + 1) / SQ));

@@ -33,3 +33,16 @@ def test_pingpong_gemm_loop_has_no_compiler_generated_waits_or_m0_users():
     bad.insert(at, '\ts_mov_b32 m0, s5')
     found = mod.check(bad)
     assert any('vmcnt' in e for e in found) and any('m0' in e for e in found)
+    # sequential split-K kernels: compiler memory traffic is legal ONLY inside the marked fold; a load hoisted out of it must be flagged
+    seq_name, seq_body = next((n, b) for n, b in fns.items() if 'Lb1ELi320' in n)
+    n_seq, n_fold = mod.fold_regions(lines)
+    assert n_seq >= 4 and n_fold >= 2 * n_seq
+    a, _ = mod.k_loops(seq_body)[0]
+    marker = next(ln for ln, in_asm in seq_body[a:] if 'v_mfma' in ln)
+    start = next(i for i, ln in enumerate(lines) if ln.startswith(seq_name + ':'))
+    bad = list(lines)
+    at = bad.index(marker, start)
+    while ';;#ASMSTART' not in bad[at]:
+        at -= 1
+    bad.insert(at, '\tglobal_load_dwordx4 v[0:3], v[4:5], off')
+    assert any('vector memory instruction' in e for e in mod.check(bad))

@@ -6,8 +6,9 @@ Both are only correct if hipcc adds nothing of its own to the loop:
      pp_m0_take() and pp_m0_give();
   2. inside the K loops (the loops that contain MFMAs) there is no scratch access (a spill reload is a vector memory operation: it
      joins the in-order queue behind the LDS-DMA pieces and the compiler waits for it with vmcnt(0)), no compiler-generated
-     `s_waitcnt vmcnt` and no vector memory instruction outside the asm -- except in the sequential split-K variants (SEQ), whose
-     slice fold is ordinary code fenced by vmcnt(0) on both sides;
+     `s_waitcnt vmcnt` and no vector memory instruction outside the asm -- except, in the sequential split-K variants (SEQ), between
+     the pp_fold_begin / pp_fold_end markers: the slice fold is ordinary code fenced by vmcnt(0) on both sides, and ONLY there may the
+     compiler move data (a load hoisted out of the fold would shift the counted waits: it is flagged like anywhere else);
   3. every MFMA of the loop is in place (destination == C operand): the accumulators stay put.
   4. no kernel spills inside a K loop at all (ScratchSize may be non-zero only through the epilogue).
 
@@ -95,7 +96,12 @@ def check(lines):
             if 'v_mfma' in ln and j not in inside:
                 errs.append(f'{short}: MFMA outside the marked K loops: {ln.strip()}')
         for a, b in loops:
+            in_fold, folds = False, 0
             for ln, in_asm in body[a:b + 1]:
+                if in_asm and 'pp_fold_begin' in ln:
+                    in_fold, folds = True, folds + 1
+                elif in_asm and 'pp_fold_end' in ln:
+                    in_fold = False
                 code = ln.split(';')[0].strip()
                 if not code:
                     continue
@@ -105,7 +111,7 @@ def check(lines):
                     m = re.match(r'v_mfma\S+\s+(\S+),\s*\S+,\s*\S+,\s*(\S+)', code)
                     if not m or m.group(1) != m.group(2):
                         errs.append(f'{short}: MFMA not in place: {code}')
-                if in_asm or seq:
+                if in_asm or (seq and in_fold):
                     continue
                 if re.match(r's_waitcnt\b.*vmcnt', code):
                     errs.append(f'{short}: compiler-generated vmcnt wait inside a K loop: {code}')
@@ -114,10 +120,24 @@ def check(lines):
     return errs
 
 
+def fold_regions(lines):
+    """(SEQ kernels, fold regions found in their K loops): the exemption must actually be anchored somewhere"""
+    n_seq = n_fold = 0
+    for name, body in functions(lines).items():
+        if 'Lb1ELi320' not in name:
+            continue
+        n_seq += 1
+        n_fold += sum(1 for ln, in_asm in body if in_asm and 'pp_fold_begin' in ln)
+    return n_seq, n_fold
+
+
 def main():
     lines = device_asm()
     errs = check(lines)
     n = len(functions(lines))
+    n_seq, n_fold = fold_regions(lines)
+    if n_seq and n_fold < 2 * n_seq:
+        errs.append(f'{n_seq} SEQ kernels but only {n_fold} marked fold regions (one per role expected)')
     if errs:
         print('\n'.join(errs[:40]))
         print(f'{len(errs)} violation(s) in {n} kernels')
