@@ -335,6 +335,9 @@ class MeshRenderer:
 
     def __init__(self, near=0.1, far=10, ssaa=1, texture_filter='linear-mipmap-linear'):
         assert texture_filter in ('linear', 'linear-mipmap-linear')
+        # `render_bs` of get_cam_weights_uv / bake_multiview is the reference's memory knob for a 24 GB card; views are independent and the atlas
+        # accumulates them in view order whatever the chunking (bitwise the same result), so chunks of at least this many views are walked
+        self.min_render_bs = 32
         self.near, self.far, self.ssaa, self.texture_filter = near, far, ssaa, texture_filter
 
     def project(self, v, poses, intrinsics, h, w):
@@ -506,6 +509,7 @@ class MeshRenderer:
         mip = self.texture_filter == 'linear-mipmap-linear'
         tex_rast_db = rasterize_db(vt_clip[None], ft, tex_rast) if mip else None
         out = []
+        render_bs = max(int(render_bs), int(self.min_render_bs))
         for i0 in range(0, n, render_bs):
             sl = slice(i0, min(i0 + render_bs, n))
             bs = sl.stop - sl.start
@@ -543,6 +547,7 @@ class MeshRenderer:
         accum = torch.zeros(map_size, map_size, 4, dtype=torch.float32, device=dev)
         debug = dict(vis=[], wimg=[], tex_rast=tex_rast)
 
+        render_bs = max(int(render_bs), int(self.min_render_bs))
         for i0 in range(0, n, render_bs):
             sl = slice(i0, min(i0 + render_bs, n))
             bs = sl.stop - sl.start
