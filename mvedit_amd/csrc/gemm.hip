@@ -359,19 +359,24 @@ bool gemm_pp_on() {
     }
     return g_gemm_pp != 0;
 }
-// The two-blocks-per-CU 256 x 160 tile (gemm_pp.hip, NSL = 3) for dense GEMMs: mve_gemm_tune bit 26 / MVE_GEMM_PP2 (A/B; bit-identical results)
+// The two-blocks-per-CU 256 x 160 tile (gemm_pp.hip, NSL = 3) for dense GEMMs, bit-identical results.  2 (default): taken where the dispatcher
+// asks for the narrow tile because 320-wide tiles would leave CUs idle (small batches: the per-wave epilogue and the second resident block are
+// what those short launches lack); 1: wherever it is eligible (A/B: slower at 64 images); 0: never.  MVE_GEMM_PP2 / mve_gemm_tune.
 int g_gemm_pp2 = -1;
 int g_old_swizzle = 0;
-bool gemm_pp2_on() {
+
+int gemm_pp2_mode() {
     if (g_gemm_pp2 < 0) {
         const char* e = getenv("MVE_GEMM_PP2");
-        g_gemm_pp2 = e ? atoi(e) : 0;
+        g_gemm_pp2 = e ? atoi(e) : 2;
+        if (g_gemm_pp2 < 0 || g_gemm_pp2 > 2) g_gemm_pp2 = 2;
     }
-    return g_gemm_pp2 != 0;
+    return g_gemm_pp2;
 }
 // MVE_OK after a launch, 1 when neither loop takes the problem (the caller falls back to the 128-row kernel), < 0 on error
 int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
-    if (gemm_pp_on() && gemm_pp2_on() && mode == 0 && q->tile_n == 0 && q->splitk <= 1 && q->splitk_seq <= 1) {
+    const int pp2 = gemm_pp2_mode();
+    if (gemm_pp_on() && mode == 0 && q->splitk <= 1 && q->splitk_seq <= 1 && ((pp2 == 1 && q->tile_n == 0) || (pp2 == 2 && q->tile_n == 160))) {
         GemmParams r = *q;
         r.tile_n = 161;
         const int rc = mve_gemm_pp_launch(dtype, mode, &r, s);
@@ -451,15 +456,15 @@ extern "C" {
 
 int mve_gemm_tune(int big_min_blocks) {
     // the whole previous word comes back (threshold + option bits), so that old = tune(x); ...; tune(old) restores every switch
-    const int old = gemm_big_min_blocks() | (g_seq_splitk ? 0 : (1 << 29)) | (gemm_pp_on() ? 0 : (1 << 27)) | (gemm_pp2_on() ? (1 << 26) : 0) |
+    const int old = gemm_big_min_blocks() | (g_seq_splitk ? 0 : (1 << 29)) | (gemm_pp_on() ? 0 : (1 << 27)) | (gemm_pp2_mode() == 1 ? (1 << 26) : 0) | (gemm_pp2_mode() == 0 ? (1 << 28) : 0) |
                     (g_old_swizzle ? (1 << 25) : 0);
     if (big_min_blocks >= 0) {
         g_seq_splitk = (big_min_blocks & (1 << 29)) ? 0 : 1;
         g_gemm_pp = (big_min_blocks & (1 << 27)) ? 0 : 1;
-        g_gemm_pp2 = (big_min_blocks & (1 << 26)) ? 1 : 0;
+        g_gemm_pp2 = (big_min_blocks & (1 << 26)) ? 1 : ((big_min_blocks & (1 << 28)) ? 0 : 2);
         g_old_swizzle = (big_min_blocks >> 25) & 1;
         mve_gemm_pp_old_swizzle(g_old_swizzle);
-        g_big_min_blocks = big_min_blocks & ~((3 << 28) | (1 << 27) | (1 << 26) | (1 << 25));
+        g_big_min_blocks = big_min_blocks & ~((3 << 28) | (1 << 27) | (1 << 26) | (1 << 25));       // (3 << 28): bits 28 and 29
     }
     return old;
 }

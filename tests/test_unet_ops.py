@@ -676,3 +676,28 @@ def test_pingpong_160_wide_tile_for_small_batches(lib, dtype):
                 assert torch.equal(out, ref), (B, H, C1, C2, Cout, stride, ups, rep, int((out != ref).sum()))
     finally:
         tune(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K,geglu,res', [(8 * 4096, 320, 320, False, True), (8 * 4096, 960, 320, False, False), (8 * 4096, 2560, 320, True, False),
+                                              (8 * 4096, 320, 1280, False, True), (16 * 1024, 640, 640, False, True)])
+def test_gemm_narrow_launches_on_the_two_block_tile_are_bit_identical(lib, dtype, M, N, K, geglu, res):
+    """Launches too small to fill the chip with 320-wide tiles take the two-blocks-per-CU 256 x 160 three-slot tile by default
+    (mve_gemm_tune: bit 28 turns it off, bit 26 forces it everywhere): same bits as the four-slot tile and as the 128-row kernel."""
+    from mvedit_amd import ops, _lib
+    a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    bias = rnd((N,), torch.float32, 3)
+    r = rnd((M, N // 2 if geglu else N), dtype, 4) if res else None
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        outs = []
+        for word in (256, 256 | (1 << 28), 256 | (1 << 26), 0):          # default (narrow launches only) / never / everywhere / 128-row kernel
+            tune(word)
+            outs.append(ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=r.cuda() if res else None, flags=ops.GEGLU if geglu else 0))
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        tune(256 | (1 << 28))
+        assert tune(-1) == 256 | (1 << 28)                       # the whole word comes back: old = tune(x); ...; tune(old) restores every switch
+    finally:
+        tune(old)
