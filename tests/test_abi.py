@@ -90,3 +90,33 @@ def test_every_python_call_site_passes_the_declared_number_of_arguments():
             elif len(_lib.PROTOS[name][1]) != nargs:
                 problems.append(f'{path}:{node.lineno} {name}: passes {nargs} arguments, the header declares {len(_lib.PROTOS[name][1])}')
     assert checked > 100 and not problems, problems
+
+
+def test_host_side_dispatch_knobs_round_trip_and_do_not_depend_on_the_batch():
+    """Pure host logic behind the C ABI, no GPU: the tuning words come back whole (old = tune(x); ...; tune(old) restores every switch), and
+    the cuts that decide a reduction's summation order -- the depthwise kernel's pixel slabs, GroupNorm's row split -- are functions of
+    the layer only, never of the batch (batch / chunk invariance by construction)."""
+    from mvedit_amd import _lib
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        for word in (256, 1, 0, 256 | (1 << 26), 256 | (1 << 28), 64 | (1 << 27) | (1 << 29), 256 | (1 << 25)):
+            tune(word)
+            assert tune(-1) == word, hex(word)
+    finally:
+        tune(old)
+    assert tune(-1) == old
+    gn = _lib.raw('mve_groupnorm_tune')
+    prev = gn(-1)
+    try:
+        assert gn(0) == prev and gn(-1) == 0 and gn(4096) == 0 and gn(-1) == 4096
+    finally:
+        gn(prev)
+    slabs = _lib.raw('mve_seg_dwconv_slabs')
+    for (ho, c, k, st) in ((320, 64, 3, 1), (160, 192, 3, 2), (160, 288, 3, 1), (80, 480, 5, 1), (40, 960, 3, 1), (40, 1344, 5, 1), (20, 2304, 5, 1), (20, 3840, 3, 1)):
+        n = [slabs(b, ho, ho, c, k, st) for b in (1, 2, 8, 32)]
+        assert len(set(n)) == 1 and 1 <= n[0] <= 256, (ho, c, k, st, n)
+    ws = _lib.raw('mve_groupnorm_workspace_bytes')
+    for (hw, c) in ((4096, 320), (4096, 960), (1024, 640), (256, 1280), (64, 2560), (262144, 128)):
+        per_image = [(ws(b, hw, c, 32) - 64) // b for b in (1, 2, 8, 64)]      # partials + statistics scale with the batch and with nothing else
+        assert max(per_image) - min(per_image) <= 64, (hw, c, per_image)
