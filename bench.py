@@ -118,7 +118,7 @@ class PowerSampler:
             return None
         n = len(self.samples)
         return dict(avg_w=round(sum(s[0] for s in self.samples) / n, 1), max_w=round(max(s[0] for s in self.samples), 1),
-                    avg_sclk_mhz=round(sum(s[1] for s in self.samples) / n), samples=n, source='rocm-smi --showpower --showclocks during the timed steps')
+                    avg_sclk_mhz=round(sum(s[1] for s in self.samples) / n), samples=n, source='rocm-smi --showpower --showclocks over ~2.5 s of extra untimed steps right after the timed region')
 
 
 def pmc_traffic(cls):
@@ -436,9 +436,6 @@ def main():
     torch.cuda.synchronize()
     per_op = None
     n_prof = 0
-    sampler = PowerSampler() if rank == 0 else None
-    if sampler is not None:
-        sampler.__enter__()
     t0 = time.perf_counter()
     # per-op HIP events cost ~1 ms of host time per step: on every timed step at N = 1 (~65 ms steps), on the last timed step
     # only at N > 1 where a rank's step is ~10 ms and the events would distort the scaling measurement
@@ -453,6 +450,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # socket power / clock: sampled over EXTRA untimed steps right after the timed region (rocm-smi queries the SMU; nothing that is not the
+    # workload runs next to the timed steps).  Every rank runs the extra steps (they contain the step's collective); rank 0 samples.
+    sampler = PowerSampler() if rank == 0 else None
+    if sampler is not None:
+        sampler.__enter__()
+    t_extra = time.perf_counter()
+    while True:
+        step(False)
+        torch.cuda.synchronize()
+        more = torch.tensor([1.0 if time.perf_counter() - t_extra < 2.5 else 0.0], device=dev)
+        if use_dist:
+            dist.all_reduce(more, op=dist.ReduceOp.MIN)        # all ranks leave the loop on the same step
+        if float(more.item()) == 0.0:
+            break
     if sampler is not None:
         sampler.__exit__()
     if use_dist:
