@@ -843,7 +843,8 @@ MVE_API int mve_antialias_backward_pos(const float* d_color, const float* d_grad
  *                     dtype with rows [kh][kw][Cin]; gate [B][Cin] f32 or NULL (1 x 1 only: the squeeze-and-excite scaling of
  *                     MBConvBlock.forward, efficientnet.py:124-131, applied to the operand in registers).  The expand conv + swish (:110-113),
  *                     the project conv + skip (:131-141), and the RFB block's 1 x 1, 1 x k, k x 1 and dilated 3 x 3 BasicConv2d layers
- *                     (conv_modules.py / att_modules.py:23-72; Cin % 32 == 0 when the kernel has taps).
+ *                     (conv_modules.py / att_modules.py:23-72; Cin % 32 == 0 when the kernel has taps).  Alignment: d_x, d_w 16 bytes;
+ *                     d_out / d_residual 8 bytes, and 16 when ldo / ldr are multiples of 8 (rows are then stored 32 bytes per lane).
  *   seg_channel_mean: F.adaptive_avg_pool2d(x, 1) / GlobalAvgPool -> f32 [B][C].
  *   seg_se_gate     : sigmoid(_se_expand(swish(_se_reduce(pooled)))) (efficientnet.py:124-129), w1 [S][C], w2 [C][S] f32; pooled[b][c] = scale *
  *                     sum_k sums[b][k][c] (nslab = 1, scale = 1: a pooled vector as it is); d_hidden: [B][S + C] f32 workspace.
