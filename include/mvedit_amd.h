@@ -182,11 +182,13 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int l
 /* Tuning knob: GEMM / conv launches whose 256 x 320 tiling yields at least `big_min_blocks` (bits 0..24) blocks use the 256-row tile
  * (bit-identical results, so the choice never affects parity or batch invariance).  0 disables it, a negative value only queries.
  * Bit 27 set: the 256-row tile runs the two-stage main loop (csrc/gemm_big.hip) instead of the ping-pong loop (csrc/gemm_pp.hip);
- * bit 29 set: real split-K + reducer instead of the sequential emulation; the two-blocks-per-CU 256 x 160 three-slot tile for dense
+ * bit 30 set (MVE_GEMM_STRICT_SPLITK=1): a launch that fills the chip un-split emulates the K slices of the slice rule inside one block
+ * (bitwise equal to split-K + reducer, i.e. to the same rows in a small batch) instead of accumulating K in one chain (the default since
+ * round 4: same value up to fp32 summation order, 3.8 ms per 68 ms step faster); bit 29 set: real split-K + reducer there; the two-blocks-per-CU 256 x 160 three-slot tile for dense
  * GEMMs: by default where the dispatcher asks for the narrow tile (launches too small to fill the chip with 320-wide tiles), bit 26 set:
  * wherever it is eligible, bit 28 set: never; bit 25 set: round 2's LDS ring swizzle (A/B aid).  Returns the WHOLE previous word
  * (threshold and option bits), so `old = tune(x); ...; tune(old)` restores every switch.  The defaults come from the environment
- * variables MVE_GEMM_BIG, MVE_GEMM_PP and MVE_GEMM_PP2 (0 never / 1 wherever eligible / 2 narrow launches only). */
+ * variables MVE_GEMM_BIG, MVE_GEMM_PP, MVE_GEMM_PP2 (0 never / 1 wherever eligible / 2 narrow launches only) and MVE_GEMM_STRICT_SPLITK. */
 MVE_API int mve_gemm_tune(int big_min_blocks);
 
 /* Development aid for csrc/gemm_pp.hip: with `d_buf` (device, 64 uint64 per launched block) set, fp16 320-wide launches of the

@@ -307,8 +307,13 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
 // Split K at the deep UNet levels, where one image contributes only a few output tiles (8x8 / 16x16 latents) but K is
 // 9*1280..9*2560.  The slice count is a function of (rows per image, N, K) ONLY -- never of the batch -- so that a view gets
 // bit-identical results whether it is denoised alone, in a chunk, or on another GPU (batch / partition invariance).
+int g_splitk_policy = -1;      // MVE_GEMM_SPLITK: 1 (default) = the rule below; 0 = never split (A/B: what the slices cost at a given batch)
 int choose_splitk(int rows_per_image, int N, int K) {
-    if (rows_per_image <= 0) return 1;
+    if (g_splitk_policy < 0) {
+        const char* e = getenv("MVE_GEMM_SPLITK");
+        g_splitk_policy = e ? atoi(e) : 1;
+    }
+    if (rows_per_image <= 0 || g_splitk_policy == 0) return 1;
     const int bn = (N % 160 == 0) ? 160 : (N % 128 == 0 ? 128 : (N <= 64 ? 64 : 128));
     const long long t1 = (long long)mve_cdiv(rows_per_image, BM) * mve_cdiv(N, bn);      // tiles of ONE image
     const int nk = (K + BK - 1) / BK;
@@ -336,6 +341,25 @@ int launch_v(const GemmParams& p, hipStream_t s) {
         MVE_LAUNCH_CHECK();
     }
     return MVE_OK;
+}
+
+// What a launch does when the slice rule (choose_splitk) asks for S > 1 slices but the un-split launch already fills the chip (>= one 256 x 320
+// tile per CU: 64 images on one GPU at the 32 x 32 and 16 x 16 levels).
+//   0 (default, round 4): one block per tile walks all of K in ONE accumulation chain.  The result differs from the sliced sum (what the same
+//     image gets in a small batch, where the slices run as separate blocks + reducer) by fp32 summation order only -- well inside the 16-bit output
+//     rounding, see tests/test_unet_ops.py::test_unsplit_chain_vs_sliced_sum -- so bitwise batch invariance holds among launches that take the
+//     same decision (all small batches; all chip-filling batches), not across the two.
+//   1 (MVE_GEMM_STRICT_SPLITK=1 / mve_gemm_tune bit 30): the block emulates the slices (GemmParams::splitk_seq: accumulators folded into an fp32
+//     running total at every slice boundary), bitwise equal to split-K + reducer at any batch.  Measured cost at 64 images: the fold drains
+//     the DMA ring and moves 160 fp32 registers per lane through HBM per slice: level-1 / level-2 convs 1 080 -> 1 310-1 400 TFLOP/s without it,
+//     the N = K GEMMs of level 2 550 -> 900, ff.out 750 -> 1 240; 3.8 ms of a 68 ms step (profiles/r04_oplist_*.log).
+int g_strict_splitk = -1;
+int gemm_strict_splitk() {
+    if (g_strict_splitk < 0) {
+        const char* e = getenv("MVE_GEMM_STRICT_SPLITK");
+        g_strict_splitk = e ? (atoi(e) != 0) : 0;
+    }
+    return g_strict_splitk;
 }
 
 // minimum number of 256 x 320 blocks for which the big-tile kernel is used (0 disables it); MVE_GEMM_BIG overrides
@@ -414,7 +438,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     if (gemm_big_min_blocks() > 0 && p.splitk > 1 && p.N % 320 == 0 && g_seq_splitk && tile256_blocks(p.M, p.N, 1) >= gemm_big_min_blocks() &&
         (size_t)tile256_blocks(p.M, p.N, 1) * 256 * 320 <= (size_t)p.splitk * p.M * p.N) {
         GemmParams q = p;
-        q.splitk_seq = p.splitk;
+        q.splitk_seq = gemm_strict_splitk() ? p.splitk : 0;      // default: ONE accumulation chain over all of K (see gemm_strict_splitk)
         q.splitk = 1;
         return launch_tile256(Tag::dtype, MODE, &q, s);
     }
@@ -457,14 +481,15 @@ extern "C" {
 int mve_gemm_tune(int big_min_blocks) {
     // the whole previous word comes back (threshold + option bits), so that old = tune(x); ...; tune(old) restores every switch
     const int old = gemm_big_min_blocks() | (g_seq_splitk ? 0 : (1 << 29)) | (gemm_pp_on() ? 0 : (1 << 27)) | (gemm_pp2_mode() == 1 ? (1 << 26) : 0) | (gemm_pp2_mode() == 0 ? (1 << 28) : 0) |
-                    (g_old_swizzle ? (1 << 25) : 0);
+                    (g_old_swizzle ? (1 << 25) : 0) | (gemm_strict_splitk() ? (1 << 30) : 0);
     if (big_min_blocks >= 0) {
+        g_strict_splitk = (big_min_blocks >> 30) & 1;
         g_seq_splitk = (big_min_blocks & (1 << 29)) ? 0 : 1;
         g_gemm_pp = (big_min_blocks & (1 << 27)) ? 0 : 1;
         g_gemm_pp2 = (big_min_blocks & (1 << 26)) ? 1 : ((big_min_blocks & (1 << 28)) ? 0 : 2);
         g_old_swizzle = (big_min_blocks >> 25) & 1;
         mve_gemm_pp_old_swizzle(g_old_swizzle);
-        g_big_min_blocks = big_min_blocks & ~((3 << 28) | (1 << 27) | (1 << 26) | (1 << 25));       // (3 << 28): bits 28 and 29
+        g_big_min_blocks = big_min_blocks & ~((7 << 28) | (1 << 27) | (1 << 26) | (1 << 25));       // (7 << 28): bits 28, 29 and 30
     }
     return old;
 }

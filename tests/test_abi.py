@@ -100,7 +100,7 @@ def test_host_side_dispatch_knobs_round_trip_and_do_not_depend_on_the_batch():
     tune = _lib.raw('mve_gemm_tune')
     old = tune(-1)
     try:
-        for word in (256, 1, 0, 256 | (1 << 26), 256 | (1 << 28), 64 | (1 << 27) | (1 << 29), 256 | (1 << 25)):
+        for word in (256, 1, 0, 256 | (1 << 26), 256 | (1 << 28), 64 | (1 << 27) | (1 << 29), 256 | (1 << 25), 256 | (1 << 30), 1 | (1 << 30) | (1 << 27)):
             tune(word)
             assert tune(-1) == word, hex(word)
     finally:

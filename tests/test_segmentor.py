@@ -92,6 +92,71 @@ def test_engine_vs_oracle(lib, dtype):
     assert float(near.float().mean()) < 0.5
 
 
+def _views(n, side, seed):
+    """Synthetic 'rendered views': a few soft blobs over a gradient background plus fine noise, in [0, 1] (what do_segmentation hands over)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(n, 3, 10, 10, generator=g)
+    x = F.interpolate(low, size=(side, side), mode='bicubic', align_corners=False)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, side), torch.linspace(-1, 1, side), indexing='ij')
+    blob = torch.exp(-((xx * 1.4) ** 2 + (yy * 1.1) ** 2) * 3.0)[None, None]
+    x = 0.55 * x + 0.35 * blob + 0.1 * torch.rand(n, 3, side, side, generator=g)
+    return x.clamp(0, 1)
+
+
+_FP32_640 = {}
+
+
+def _oracle_fp32_640(sd, x, size):
+    """fp32 oracle outputs at 640^2, computed once for both dtypes (20 s of host time each)."""
+    if 'v' not in _FP32_640:
+        with torch.no_grad():
+            raw32 = T.model({k: v.float() for k, v in sd.items()}, _img(sd, x, size))
+            mask32 = T.forward(sd, x, input_image_size=size, erosion=1, batch_size=2)
+            pre32 = T.forward(sd, x, input_image_size=size, erosion=1, batch_size=2, failure_rule=False)
+        _FP32_640['v'] = (raw32, mask32, pre32)
+    return _FP32_640['v']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_engine_vs_oracle_at_640(lib, dtype):
+    """The configuration the pipelines and bench.py run (tracer_b7.py:21 input_image_size=640, bf16, 512^2 views): encoder stages at 160^2 / 80^2 /
+    40^2 / 20^2 and the split-K choices that go with them -- none of which the 192^2 case above reaches.  Same statement as there with tighter
+    factors and the excluded pixels counted: the raw map is at least as close to the fp32 oracle as the 16-bit-emulated reference module
+    (mean within 1.25x, max within 2x), and the final masks (resize -> failure rule at 0.8 -> erosion) agree with the oracle's on every pixel
+    that is not within 0.02 of the rule's threshold (at most 10 % of the pixels may be excused; the seeded network has ~0.02 % there)."""
+    from mvedit_amd.segmentor import TracerUniversalB7Engine
+    from mvedit_amd import synthetic as S
+    size = 640
+    sd = S.make_tracer_state_dict(11)
+    x = _views(2, 512, seed=3)
+    q = lambda t: t.to(dtype).float()
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    raw32, mask32, pre32 = _oracle_fp32_640(sd, x, size)
+    with torch.no_grad():
+        raw16 = T.model({k: v.to(dtype).float() for k, v in sd.items()}, _img(sd, x, size), q)
+    eng = TracerUniversalB7Engine(input_image_size=size, batch_size=8, torch_dtype=dtype, erosion=1).load_state_dict(sd)
+    raw = eng.raw_mask(x.cuda()).float().cpu()[:, None]
+    assert raw.shape == raw32.shape == (2, 1, size, size) and torch.isfinite(raw).all()
+    e_eng, e_emu = float((raw - raw32).abs().max()), float((raw16 - raw32).abs().max())
+    m_eng, m_emu = float((raw - raw32).abs().mean()), float((raw16 - raw32).abs().mean())
+    masks = eng(x.cuda()).float().cpu()
+    assert masks.shape == mask32.shape == (2, 1, 512, 512)
+    near = (pre32 - 0.8).abs() < 0.02
+    diff = (masks - mask32).abs()
+    frac_near = float(near.float().mean())
+    agree = float((diff <= 3 * e_emu + 3e-2).float().mean())
+    print(f'640^2 {dtype}: raw map mean|engine - fp32| {m_eng:.2e} (emulated module {m_emu:.2e}); max {e_eng:.2e} ({e_emu:.2e}); '
+          f'pixels within 0.02 of the failure threshold {frac_near:.4f}; masks agreeing overall {agree:.4f}; spread of the raw map {float(raw32.max() - raw32.min()):.3f}')
+    assert float(raw32.max() - raw32.min()) > 0.2, 'the seeded network must not collapse to a constant map'
+    assert m_eng <= 1.25 * m_emu + 5e-4, (m_eng, m_emu)
+    assert e_eng <= 2 * e_emu + 1e-2, (e_eng, e_emu)
+    assert float(diff[~near].max()) <= 3 * e_emu + 3e-2, float(diff[~near].max())
+    assert frac_near < 0.10, frac_near                       # at most 10 % of the pixels are excused
+    assert agree > 0.98, agree
+
+
 @pytest.mark.gpu
 def test_engine_batch_chunks_and_shapes(lib):
     """batch_size chunking (tracer_b7.py:63) gives the same masks as one chunk; non-square callers' sizes are restored."""

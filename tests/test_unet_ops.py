@@ -14,7 +14,8 @@ import torch
 
 # mve_gemm_tune settings under which every GEMM / conv result must be bit-identical: the 128-row kernel only, the 256-row tile from one
 # block up (ping-pong main loop where eligible, csrc/gemm_pp.hip), the same with the ping-pong loop disabled (two-stage loop, gemm_big.hip)
-TILE_MODES = (0, 1, 1 | (1 << 27))
+STRICT = 1 << 30          # mve_gemm_tune bit 30: chip-filling launches emulate the K slices (bitwise equal to split-K + reducer) instead of one accumulation chain
+TILE_MODES = (0, 1 | STRICT, 1 | (1 << 27) | STRICT)
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -606,8 +607,9 @@ def test_pingpong_main_loop_is_bit_identical_and_race_free(lib, dtype):
     from mvedit_amd import ops, _lib
     tune = _lib.raw('mve_gemm_tune')
     old = tune(-1)
-    PP, BIG = 1, 1 | (1 << 27)
     try:
+      for strict in (0, STRICT):          # one accumulation chain (default) / emulated K slices: the two loops agree bitwise under either rule
+        PP, BIG = 1 | strict, 1 | (1 << 27) | strict
         for (M, N, K, rpi, fl) in [(70000, 320, 320, 0, 0), (33000, 960, 64, 0, 0), (20000, 2560, 320, 0, ops.GEGLU), (16384, 320, 1280, 0, 0),
                                    (9000, 1280, 5120, 0, 0), (1024, 1280, 11520, 64, 0), (777, 512, 640, 0, 0), (4096, 256, 4608, 0, 0),
                                    (20000, 128, 1152, 0, 0), (5000, 384, 640, 0, 0)]:      # 128-wide tile (4 x 2 waves)
@@ -636,6 +638,41 @@ def test_pingpong_main_loop_is_bit_identical_and_race_free(lib, dtype):
                 for rep in range(3):
                     out = ops.conv3x3(x1, w_k, B, H, H, x2=x2, stride=stride, upsample=ups, flags=wflag, splitk=sk)[0]
                     assert torch.equal(out, ref), (B, H, C1, C2, Cout, stride, ups, sk, rep, int((out != ref).sum()))
+    finally:
+        tune(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_unsplit_chain_vs_sliced_sum(lib, dtype):
+    """Round 4: a launch that fills the chip un-split accumulates K in ONE chain by default instead of emulating the K slices of the slice rule
+    (csrc/gemm.hip gemm_strict_splitk).  The two differ by fp32 summation order only: every element within one rounding step of the
+    16-bit output of the other, a small fraction of elements differing at all, and both inside the kernel bar against the fp32 reference.
+    (mve_gemm_tune threshold 1 makes a test-sized launch 'fill the chip'; bit 30 selects the emulated slices.)"""
+    from mvedit_amd import ops, _lib
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    try:
+        for (M, N, K, rpi) in [(1024, 1280, 11520, 64), (2048, 640, 2560, 1024), (1024, 1280, 5120, 256)]:
+            a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+            bias, res = rnd((N,), torch.float32, 3), rnd((M, N), dtype, 4)
+            assert _lib.raw('mve_gemm_workspace_bytes')(M, N, K, rpi) > 0, 'the slice rule must ask for slices here'
+            tune(1)
+            chain = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), rows_per_image=rpi)
+            tune(1 | STRICT)
+            sliced = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), rows_per_image=rpi)
+            tune(0)
+            small = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=res.cuda(), rows_per_image=rpi)      # 128-row kernel: real split-K + reducer
+            assert torch.equal(sliced, small), 'the emulated slices equal split-K + reducer bitwise'
+            d = (chain.float() - sliced.float()).abs()
+            bound = ulp * torch.maximum(chain.float().abs(), sliced.float().abs()) + 1e-6
+            frac = float((d > 0).float().mean())
+            print(f'{dtype} M={M} N={N} K={K}: {frac * 100:.2f} % of the elements differ between one chain and the sliced sum, max {float((d / bound).max()):.2f} output roundings')
+            assert bool((d <= bound).all()) and frac < 0.2, (M, N, K, frac)
+            ref = a.float() @ w.float().t() + bias + res.float()
+            check('gemm, one chain', chain, ref, dtype)
+            check('gemm, sliced', sliced, ref, dtype)
     finally:
         tune(old)
 
