@@ -50,6 +50,9 @@ def parse():
                          'reference-view pairing of adapter3d_mixin.py:86-94 ([b, 4, 128, 64] latents = 4V forwards, self-attention over 2 x 4096 '
                          'tokens); zero123pp: BASELINE config 2, one Zero123++ denoise step (SD-2.1 on the 120x80 latent of six 320^2 views, '
                          'reference-only attention written by a 40x40 condition pass, CFG pair)')
+    ap.add_argument('--residual-pair', action='store_true', help='time the headline with the residual stream carried as an unrounded (hi, lo) pair '
+                    '(UNet2DConditionEngine.set_residual_pair: end-to-end error below north_star\'s 1e-3); by default that mode is reported as an extra workload')
+    ap.add_argument('--no-extra', action='store_true', help='skip the compact extra workloads (use_reference, zero123pp, bf16, residual pair) and the outer-step figures')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the NeRF / raster / back-projection figures')
     ap.add_argument('--no-op-timing', action='store_true', help='time the steps without per-op HIP events')
@@ -58,22 +61,24 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, dtype=torch.float16, latent_hw=(LATENT, LATENT)):
+def cpu_baseline(cfg, dtype=torch.float16, latent_hw=(LATENT, LATENT), B=1, n_img=1, repeats=3):
     """Oracle (kind "port") on the host cores: one forward of one image, fp32 arithmetic over the engine's (16-bit rounded) weights.
-    Returns the baseline record and (x, ctx, out) so that the same forward can be compared with the HIP engine (the oracle as checker)."""
+    Returns the baseline record and (x, ctx, out) so that the same forward can be compared with the HIP engine (the oracle as checker).
+    The ONLY function of this file that touches oracle/ (tests/test_abi.py).  B / n_img / repeats = 1: the checker leg of the extra workloads
+    (one forward of a CFG pair, or of a (reference, view) pair under cross-image attention), not a baseline figure."""
     from oracle import unet_oracle as U
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     sd = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=1234).items()}
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(1, 4, *latent_hw, generator=g).to(dtype).float()
-    ctx = torch.randn(1, CTX_LEN, cfg['cross_attention_dim'], generator=g).to(dtype).float()
+    x = torch.randn(B, 4, *latent_hw, generator=g).to(dtype).float()
+    ctx = torch.randn(B, CTX_LEN, cfg['cross_attention_dim'], generator=g).to(dtype).float()
     dts = []
     with torch.no_grad():
-        for _ in range(3):                       # ~10 s of host work in total: a bounded sample, not the full step
+        for _ in range(repeats):                 # ~10 s of host work in total: a bounded sample, not the full step
             t0 = time.perf_counter()
-            out = U.unet_forward(sd, cfg, x, 499, ctx)
+            out = U.unet_forward(sd, cfg, x, 499, ctx, n_img)
             dts.append(time.perf_counter() - t0)
     dt = min(dts)
     rec = dict(value=None, unit='denoise-steps/s', cores=threads, kind='port', seconds_per_forward=round(dt, 3),
@@ -316,46 +321,9 @@ def secondary(dev):
     return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    # MVE_BENCH_FORCE_DIST=1 runs the RCCL code path (init, barrier, all-gather, all-reduce) with a single rank, so that it can
-    # be exercised on a 1-GPU box under `torch.distributed.run --nproc-per-node 1`
-    use_dist = world > 1 or os.environ.get('MVE_BENCH_FORCE_DIST') == '1'
-    if use_dist:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists for the HIP path)'
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
-    if args.secondary_only:
-        print(json.dumps({'secondary': secondary(dev)}), flush=True)
-        return
-
-    from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG, SD21_CONFIG
-    from mvedit_amd import ops
-    from mvedit_amd.parallel import partition_views
-    from mvedit_amd import synthetic as U   # seeded random weights in diffusers layout (the oracle is used by cpu_baseline only)
-
-    dtype = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
-    wl = args.workload
-    cfg = dict(SD21_CONFIG if wl == 'zero123pp' else SD15_CONFIG)
-    V = args.views
-    lo, hi = partition_views(V, world, rank)
-    v_loc = hi - lo
-
-    # ---- weights + synthetic inputs, resident in HBM -------------------------------------------------------
-    sd = U.make_state_dict(cfg, seed=1234, dtype=dtype)
-    eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype, dev)
-    del sd
-    if os.environ.get('MVE_BENCH_GRAPH') == '1':          # experiment: hipGraph replay of the forward (off by default)
-        eng.enable_graph(True)
-        side = torch.cuda.Stream(dev)                      # stream capture is not allowed on the legacy default stream
-        side.wait_stream(torch.cuda.current_stream(dev))
-        torch.cuda.set_stream(side)
+def make_passes(wl, cfg, V, lo, hi, v_loc, world, dev, dtype):
+    """Synthetic inputs of one step of workload `wl`, resident in HBM -> (passes, forwards, metric, workload, v_loc, lo, hi); a pass is
+    (sample, timesteps, context, num_cross_attn_imgs, cross_attention_kwargs or None)."""
     g = torch.Generator().manual_seed(0)
     cdim = cfg['cross_attention_dim']
     # passes of one step: (sample, timesteps, context, num_cross_attn_imgs, cross_attention_kwargs or None)
@@ -396,6 +364,300 @@ def main():
         metric = 'multi-view denoise-steps/sec (32 views, 512^2)' + (' with reference-view pairing' if wl == 'use_reference' else '')
         workload = (f'{V}-view 512x512 get_noise_pred: {forwards * world} SD-1.5 UNet forwards (64x64 latents, ctx 77x768) + CFG per step; ControlNet residuals zero'
                     + ('; use_reference: (reference, view) pairs share one 2 x 4096-token self-attention per level-0 block' if wl == 'use_reference' else ''))
+    return passes, forwards, metric, workload, v_loc, lo, hi
+
+
+def measure_workload(dev, wl, dtype, residual_pair, steps=3, warmup=1, parity_ref=None):
+    """A compact line for one more workload / mode on this GPU (N = 1): the same step the headline times (make_passes + per-op HIP events), `steps`
+    timed steps.  parity_ref = (x, ctx, fp32 output) of a single oracle forward to compare the engine with, or None."""
+    from mvedit_amd import ops, synthetic as U
+    from mvedit_amd.unet import SD15_CONFIG, SD21_CONFIG, UNet2DConditionEngine
+    cfg = dict(SD21_CONFIG if wl == 'zero123pp' else SD15_CONFIG)
+    eng = UNet2DConditionEngine.from_state_dict(U.make_state_dict(cfg, seed=1234, dtype=dtype), cfg, dtype, dev)
+    eng.set_residual_pair(residual_pair)
+    passes, forwards, metric, workload, _, _, _ = make_passes(wl, cfg, VIEWS, 0, VIEWS, VIEWS, 1, dev, dtype)
+    optabs = [None] * len(passes)
+
+    def step(profile):
+        mss, out = [], None
+        for pi, (x_, t_, c_, n_, kw_) in enumerate(passes):
+            eng._set_attention(kw_, x_.shape[0], x_.shape[2], x_.shape[3])
+            eng.plan(x_.shape[0], x_.shape[2], x_.shape[3], CTX_LEN, n_, False, dtype)
+            if profile:
+                out, ms = eng._run(0, x_, t_, c_, n_, None, None, None, profile=True)
+                if optabs[pi] is None:
+                    optabs[pi] = eng.op_table()
+                mss.append(ms)
+            else:
+                out = eng._run(0, x_, t_, c_, n_, None, None, None)
+        if wl == 'use_reference':
+            out = out.view(-1, 2, *out.shape[1:])[:, 1]
+        half = out.shape[0] // 2
+        ops.cfg_combine(out[:half].float().contiguous(), out[half:].float().contiguous(), GUIDANCE)
+        return mss
+    for _ in range(max(warmup, 1)):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(False)
+    torch.cuda.synchronize()
+    ms_per_step = (time.perf_counter() - t0) / steps * 1e3
+    per_op = step(True)                                    # one more, untimed, step with per-op events for the class breakdown
+    cls_ms, cls_fl = {}, {}
+    for optab, ms_list in zip(optabs, per_op):
+        for (ph, cls, fl, lab), m in zip(optab, ms_list):
+            cls_ms[cls] = cls_ms.get(cls, 0.0) + m
+            cls_fl[cls] = cls_fl.get(cls, 0.0) + fl
+    gemm_ms = cls_ms.get('conv3x3', 0.0) + cls_ms.get('linear', 0.0)
+    gemm_fl = cls_fl.get('conv3x3', 0.0) + cls_fl.get('linear', 0.0)
+    dom = 'gemm' if gemm_ms >= cls_ms.get('attention', 0.0) else 'attention'
+    ach = (gemm_fl / gemm_ms if dom == 'gemm' else cls_fl['attention'] / cls_ms['attention']) / 1e9
+    total_fl = sum(cls_fl.values())
+    rec = dict(workload=wl + (' + residual pair' if residual_pair else ''), dtype='f16' if dtype == torch.float16 else 'bf16', steps=steps,
+               ms_per_step=round(ms_per_step, 3), value=round(1e3 / ms_per_step, 4), unit='denoise-steps/s', forwards_per_step=forwards,
+               model_tflops_per_s=round(total_fl / ms_per_step / 1e9, 1),
+               roofline=dict(bound='mfma', kernel='k_gemm_pp (conv3x3 + linear)' if dom == 'gemm' else 'k_attention3 / k_attention2', achieved=round(ach, 1),
+                             peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(ach / PEAK_TFLOPS_F16, 4),
+                             per_class_ms={k: round(v, 3) for k, v in cls_ms.items()}))
+    if parity_ref is not None:
+        try:
+            bx, bctx, bout, n_img = parity_ref
+            eng._set_attention(dict(num_cross_attn_imgs=n_img) if n_img > 1 else None, bx.shape[0], bx.shape[2], bx.shape[3])
+            got = eng._run(0, bx.to(dev, dtype), torch.full((bx.shape[0],), 499.0, device=dev), bctx.to(dev, dtype), n_img, None, None, None).float().cpu()
+            rec['parity'] = dict(rel_l2_vs_fp32_oracle=round(float((got - bout).norm() / bout.norm()), 6), shape=list(bx.shape), north_star_bar=1e-3)
+        except Exception as e:
+            rec['parity'] = {'error': repr(e)[:200]}
+    del eng
+    torch.cuda.empty_cache()
+    return rec
+
+
+def outer_step(dev, n_optim_timed=6):
+    """One iteration of the reference's outer loop at V = 32 (lib/pipelines/mvedit_3d_pipeline.py:1141-1479; defaults of lib/core/webui/parameters.py and
+    tab_3d_to_3d.py:14: diff_bs 6, render_bs 6, patch_size 128, patch_bs_nerf 1, patch_bs 8, n_inverse_steps 96), composed from the engine's
+    own objects the way `__call__` composes the reference's, each stage timed with HIP events on the launch stream:
+      noise   : Adapter3DMixin.get_noise_pred over all 2 V images with TWO ControlNets (tile + depth; :1246-1249 -> adapter3d_mixin.py:68-135)
+      decode  : x0 prediction, vae.decode of the V latents, (x / 2 + 0.5).clamp, NHWC (:1252-1263)
+      masks   : get_tgt_masks = TRACER-B7 at 640^2 (:1266)
+      optim   : `n_inverse_steps` iterations of nerf_optim (:507-633; 128^2 rays: march -> decode -> composite -> losses + LPIPS patch -> backward -> Adam),
+                or of mesh_optim once DMTet has taken over (:716-847; render_bs views at 512^2, patch_bs LPIPS patches, regularisers) -- both timed
+      render  : BaseNeRF.render of the V views in render_bs batches + shading / tone mapping (:1341-1389)
+      encode  : vae.encode of the V rendered views (:1439-1443)
+    Synthetic scene and weights; the figures are per-stage wall times, not a quality run.  Everything but `optim` is per view (shards with the
+    views); `optim` is the replicated 3D update every rank repeats."""
+    import math
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests'))
+    from scene import icosphere, sphere_density_grid
+    from mvedit_amd import nerf, raymarching as rm, synthetic as SY
+    from mvedit_amd.controlnet import ControlNetEngine, MultiControlNetEngine
+    from mvedit_amd.lpips import LPIPSEngine
+    from mvedit_amd.mesh_ops import Mesh, MeshRenderer, mesh_regularizers
+    from mvedit_amd.pipelines import Adapter3DMixin
+    from mvedit_amd.pipelines.diffusion import predict_x0
+    from mvedit_amd.recon_loss import mesh_optim_loss, nerf_optim_loss
+    from mvedit_amd.segmentor import TracerUniversalB7Engine
+    from mvedit_amd.tonemapping import Tonemapping, make_shading_fun, shade_views
+    from mvedit_amd.unet import SD15_CONFIG, UNet2DConditionEngine
+    from mvedit_amd.vae import AutoencoderKLEngine, SD_VAE_CONFIG
+
+    V, S, f16 = VIEWS, 8 * LATENT, torch.float16
+    g = torch.Generator().manual_seed(11)
+
+    def timed(fn, it=2, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(it):
+            out = fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / it, out
+
+    out = {}
+    # ---- the networks of the step ----------------------------------------------------------------------------------------------------
+    class Pipe(Adapter3DMixin):
+        pass
+    pipe = Pipe()
+    cfg = dict(SD15_CONFIG)
+    pipe.unet = UNet2DConditionEngine.from_state_dict(SY.make_state_dict(cfg, seed=1234, dtype=f16), cfg, f16, dev)
+    cn_sd = SY.make_controlnet_state_dict(cfg, dtype=f16)
+    pipe.controlnet = MultiControlNetEngine([ControlNetEngine.from_state_dict(cn_sd, cfg, f16, dev) for _ in range(2)])
+    del cn_sd
+    pipe.segmentation = TracerUniversalB7Engine(input_image_size=640, batch_size=8, torch_dtype='bfloat16', erosion=1, device=dev).load_state_dict(SY.make_tracer_state_dict(3))
+    pipe.bg_color = 1.0
+    vae = AutoencoderKLEngine.from_state_dict(SY.make_vae_state_dict(dict(SD_VAE_CONFIG), dtype=f16), dict(SD_VAE_CONFIG), f16, dev)
+    lat = torch.randn(V, 4, LATENT, LATENT, generator=g).to(dev, f16)
+    ctx = torch.randn(2 * V, CTX_LEN, cfg['cross_attention_dim'], generator=g).to(dev, f16)
+    ctrl_img = torch.rand(V, 3, S, S, generator=g).to(dev, f16)
+    ctrl_dep = torch.rand(V, 3, S, S, generator=g).to(dev, f16)
+    two = lambda x: torch.cat([x, x], 0)
+    t_step = torch.full((2 * V,), 499.0, device=dev)
+    ms, noise = timed(lambda: pipe.get_noise_pred([two(lat)], [ctx], [two(ctrl_img)], [two(ctrl_dep)], t_step, 1.0, 1.0, GUIDANCE))
+    out['noise_pred_unet_2_controlnets_ms'] = round(ms, 2)
+
+    def decode():
+        x0 = predict_x0(lat, noise, 0.6, 0.8) / 0.18215
+        img = torch.cat([vae.decode(x0[i:i + 8].to(f16), return_dict=False)[0] for i in range(0, V, 8)])
+        return (img / 2 + 0.5).clamp(min=0, max=1).permute(0, 2, 3, 1)[None].to(torch.float32)
+    ms, tgt_images = timed(decode)
+    out['x0_vae_decode_ms'] = round(ms, 2)
+    ms, tgt_masks = timed(lambda: pipe.get_tgt_masks(tgt_images, 0))
+    out['tracer_masks_ms'] = round(ms, 2)
+    ms, _ = timed(lambda: torch.cat([vae.encode(tgt_images[0, i:i + 8].permute(0, 3, 1, 2).to(f16) * 2 - 1, return_dict=False)[0].mean for i in range(0, V, 8)]))
+    out['vae_encode_ms'] = round(ms, 2)
+    del pipe, vae, noise
+    torch.cuda.empty_cache()
+
+    # ---- NeRF side: one nerf_optim iteration (128^2 rays of one view) and the render of the V views ----------------------------------
+    meta, rows = nerf.grid_meta(12, 16, 320)
+    table = (torch.rand(rows, 2, generator=g) * 2 - 1) * 0.1
+    w1 = (torch.rand(64, 24, generator=g) * 2 - 1) * math.sqrt(6 / (64 + 24))
+    w2 = (torch.rand(4, 64, generator=g) * 2 - 1) * math.sqrt(6 / (4 + 64))
+    dec = nerf.INGPDecoderParams(table, w1, torch.zeros(64), w2, torch.tensor([2.0, 0.0, 0.0, 0.0]), 12, 320, device=dev)
+    bits = rm.packbits(torch.from_numpy(sphere_density_grid(128, radius=0.5)).to(dev), 0.5)
+    fl = S / (2 * math.tan(math.radians(15)))
+    intr = torch.tensor([[fl, fl, S / 2, S / 2]] * V, device=dev)
+    poses = surround_poses(V).to(dev)
+    tm = Tonemapping(device=dev)
+    lights = torch.nn.functional.normalize(torch.tensor([[0.3, -0.5, -1.0]] * V, device=dev), dim=-1)
+    nr = nerf.NeRFRenderer(grid_size=128)
+    rcfg = dict(return_rgba=True, compute_normal=True, dt_gamma_scale=0.0)
+
+    def render():
+        imgs = []
+        for i in range(0, V, 6):                                           # render_bs = 6
+            rgba, depth, normal, normal_fg = nr.render(dec, None, bits[None], S, S, intr[None, i:i + 6], poses[None, i:i + 6], cfg=rcfg)
+            imgs.append(shade_views(rgba, normal_fg, lights[i:i + 6], 0.2, 1.0, tm))
+        return imgs
+    with torch.no_grad():
+        ms, _ = timed(render)
+    out['nerf_render_32_views_512_ms'] = round(ms, 2)
+
+    ps, P = 128, 1                                                         # patch_size, patch_bs_nerf: n_inverse_rays = 128^2
+    ro, rd, _ = nerf.camera_rays(intr[:P] * (ps / S), poses[:P], ps, ps)   # one whole view at patch resolution stands in for the sampled patch
+    ys, xs = torch.meshgrid(torch.arange(ps, dtype=torch.float32), torch.arange(ps, dtype=torch.float32), indexing='ij')
+    flp = ps / (2 * math.tan(math.radians(15)))
+    dirs = torch.stack([(xs + 0.5 - ps / 2) / flp, (ys + 0.5 - ps / 2) / flp, torch.ones_like(xs)], -1)[None].repeat(P, 1, 1, 1).to(dev)
+    for t in dec.parameters().values():
+        t.requires_grad_(True)
+    dec.max_steps = 512
+    vr = nerf.VolumeRenderer(dec)
+    vr.training = True
+    tgt_m = torch.rand(P, ps, ps, 1, generator=g).to(dev)
+    tgt_rgb = torch.rand(P, ps, ps, 3, generator=g).to(dev)
+    lp = LPIPSEngine.from_state_dict({k: v.to(torch.bfloat16).float() for k, v in SY.make_lpips_state_dict().items()}, torch.bfloat16, device=dev)
+    opt = torch.optim.Adam(list(dec.parameters().values()), lr=1e-2, eps=1e-15)
+
+    def nerf_iter():
+        opt.zero_grad()
+        o = vr.forward(ro, rd, bits, 128, dt_gamma=0.0)
+        res = nerf_optim_loss(o['image'], o['weights_sum'], o['depth'], o['weights'], o['ts'][0], tgt_rgb, tgt_m, dirs, torch.ones(P, device=dev),
+                              lights[:P], tonemapping=tm, shaded=True, normal_reg_weight=0.5, entropy_weight=0.2)
+        loss = res['loss']
+        if lp is not None:
+            loss = loss + 0.3 * lp(res['out_rgbs'].permute(0, 3, 1, 2), tgt_rgb.permute(0, 3, 1, 2)).mean()
+        loss.backward()
+        opt.step()
+    ms, _ = timed(nerf_iter, it=n_optim_timed, warm=2)
+    out['nerf_optim_iter_ms'] = round(ms, 3)
+    if lp is not None:
+        a = torch.rand(8, 3, 128, 128, device=dev, requires_grad=True)
+        b = torch.rand(8, 3, 128, 128, device=dev)
+
+        def lp_fb():
+            a.grad = None
+            lp(a, b).mean().backward()
+        ms, _ = timed(lp_fb, it=3)
+        out['lpips_ms'] = round(ms, 3)                                      # 8 patches of 128^2, forward + backward w.r.t. the prediction (patch_bs = 8)
+
+    # ---- mesh side: one mesh_optim iteration (render_bs = 6 views at 512^2, 8 LPIPS patches, regularisers, Adam on the vertices) --------
+    v0, fc = icosphere(6, 0.6)
+    faces = torch.from_numpy(fc).to(dev)
+    mr = MeshRenderer(near=0.01, far=100)
+    nvm = 6
+    shade = make_shading_fun(lights[:nvm, None, None, :].expand(nvm, S, S, 3).contiguous(), 0.2, tm)
+    verts = torch.from_numpy(v0).to(dev).requires_grad_(True)
+    mopt = torch.optim.Adam([verts], lr=1e-3)
+    tgt_rgb6 = torch.rand(nvm, S, S, 3, generator=g).to(dev)
+    tgt_m6 = (torch.rand(nvm, S, S, 1, generator=g) > 0.5).float().to(dev)
+    erode = -torch.nn.functional.max_pool2d(-tgt_m6.permute(0, 3, 1, 2), 5, stride=1, padding=2).permute(0, 2, 3, 1).contiguous()
+    ysf, xsf = torch.meshgrid(torch.arange(S, dtype=torch.float32), torch.arange(S, dtype=torch.float32), indexing='ij')
+    dirs6 = torch.stack([(xsf + 0.5 - S / 2) / fl, (ysf + 0.5 - S / 2) / fl, torch.ones_like(xsf)], -1)[None].repeat(nvm, 1, 1, 1).to(dev)
+    normal_t = torch.rand(nvm, S, S, 3, generator=g).to(dev)
+
+    def mesh_iter():
+        mopt.zero_grad()
+        m = Mesh(verts, faces, vc=torch.cat([torch.full_like(verts, 0.7), torch.ones_like(verts[:, :1])], -1))
+        m.auto_normal()
+        o = mr([m], poses[None, :nvm], intr[None, :nvm], S, S, shading_fun=shade, normal_bg=[0.5, 0.5, 1.0])
+        res = mesh_optim_loss(o['rgba'][0], o['normal'][0], o['depth'][0].detach(), tgt_rgb6, erode, tgt_m6, dirs6, torch.ones(nvm, device=dev),
+                              target_n=normal_t, normal_reg_weight=1.0)
+        lap, nc = mesh_regularizers(verts, faces, m.face_normals)
+        loss = res['loss'] + 5.0 * (lap + nc)
+        if lp is not None:                                                   # patch_bs = 8 patches of 128^2 cut from the rendered views
+            cut = lambda x: torch.stack([x[i % nvm, 128 * (i // nvm):128 * (i // nvm) + 128, 64:192] for i in range(8)]).permute(0, 3, 1, 2)
+            loss = loss + 0.3 * lp(cut(res['out_rgbs']), cut(tgt_rgb6)).mean()
+        loss.backward()
+        mopt.step()
+    ms, _ = timed(mesh_iter, it=n_optim_timed, warm=2)
+    out['mesh_optim_iter_ms'] = round(ms, 3)
+
+    n_inv = 96
+    per_view = out['noise_pred_unet_2_controlnets_ms'] + out['x0_vae_decode_ms'] + out['tracer_masks_ms'] + out['nerf_render_32_views_512_ms'] + out['vae_encode_ms']
+    rep = n_inv * out['nerf_optim_iter_ms']
+    out['outer_step_ms'] = dict(n_inverse_steps=n_inv, sharded_per_view_stages=round(per_view, 1), replicated_nerf_optim=round(rep, 1),
+                                total_nerf_stage=round(per_view + rep, 1), total_mesh_stage=round(per_view + n_inv * out['mesh_optim_iter_ms'], 1),
+                                amdahl_speedup_at_8_gpus=round((per_view + rep) / (per_view / 8 + rep), 2),
+                                note='sharded stages divide by the rank count (views partition); the optimiser iterations are replicated on every rank')
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    # MVE_BENCH_FORCE_DIST=1 runs the RCCL code path (init, barrier, all-gather, all-reduce) with a single rank, so that it can
+    # be exercised on a 1-GPU box under `torch.distributed.run --nproc-per-node 1`
+    use_dist = world > 1 or os.environ.get('MVE_BENCH_FORCE_DIST') == '1'
+    if use_dist:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists for the HIP path)'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if args.secondary_only:
+        print(json.dumps({'secondary': secondary(dev)}), flush=True)
+        return
+
+    from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG, SD21_CONFIG
+    from mvedit_amd import ops
+    from mvedit_amd.parallel import partition_views
+    from mvedit_amd import synthetic as U   # seeded random weights in diffusers layout (the oracle is used by cpu_baseline only)
+
+    dtype = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
+    wl = args.workload
+    cfg = dict(SD21_CONFIG if wl == 'zero123pp' else SD15_CONFIG)
+    V = args.views
+    lo, hi = partition_views(V, world, rank)
+    v_loc = hi - lo
+
+    # ---- weights + synthetic inputs, resident in HBM -------------------------------------------------------
+    sd = U.make_state_dict(cfg, seed=1234, dtype=dtype)
+    eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype, dev)
+    del sd
+    eng.set_residual_pair(bool(args.residual_pair))
+    if os.environ.get('MVE_BENCH_GRAPH') == '1':          # experiment: hipGraph replay of the forward (off by default)
+        eng.enable_graph(True)
+        side = torch.cuda.Stream(dev)                      # stream capture is not allowed on the legacy default stream
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(side)
+    passes, forwards, metric, workload, v_loc, lo, hi = make_passes(wl, cfg, V, lo, hi, v_loc, world, dev, dtype)
     infos = [None] * len(passes)      # filled by the first (warm-up) step: the plan depends on the attention mode set per pass
     # The one collective of a pipeline step (SURVEY section 8(e), BASELINE north_star): every rank contributes the rendered / decoded
     # RGB + alpha + depth + normal maps of ITS views (8 channels x 512^2 fp16 = 4 MiB per view) and receives all V of them before
@@ -576,6 +838,32 @@ def main():
                                            'tests/test_unet.py holds the per-kernel 1e-3 bar and the end-to-end comparison against the 16-bit-emulating oracle')
             except Exception as e:
                 line['parity'] = {'error': repr(e)[:300]}
+        line['config']['residual_stream'] = 'unrounded (hi, lo) pair' if args.residual_pair else '16-bit (as the reference)'
+        if world == 1 and not args.no_extra and wl == 'mvedit32' and dtype == torch.float16 and not args.residual_pair:
+            # the other configurations BASELINE.json names, and the two other numeric modes, as compact driver-visible lines (3 steps each)
+            del eng
+            torch.cuda.empty_cache()
+            extras = []
+            head_ref = (bx, bctx, bout, 1) if (not args.no_cpu_baseline and 'parity' in line and 'error' not in line['parity']) else None
+            for (wl2, dt2, pair2) in (('mvedit32', torch.float16, True), ('use_reference', torch.float16, False), ('zero123pp', torch.float16, False),
+                                      ('mvedit32', torch.bfloat16, False)):
+                try:
+                    ref = None
+                    if not args.no_cpu_baseline:
+                        if wl2 == 'mvedit32' and dt2 == torch.float16:
+                            ref = head_ref
+                        elif wl2 == 'mvedit32':
+                            ref = cpu_baseline(dict(SD15_CONFIG), dt2, (LATENT, LATENT), repeats=1)[1] + (1,)
+                        elif wl2 == 'use_reference':
+                            ref = cpu_baseline(dict(SD15_CONFIG), dt2, (LATENT, LATENT), B=2, n_img=2, repeats=1)[1] + (2,)
+                    extras.append(measure_workload(dev, wl2, dt2, pair2, parity_ref=ref))
+                except Exception as e:
+                    extras.append({'workload': wl2, 'error': repr(e)[:300]})
+            line['extra_workloads'] = extras
+            try:
+                line['outer_step'] = outer_step(dev)
+            except Exception as e:
+                line['outer_step'] = {'error': repr(e)[:300]}
         if world == 1 and not args.no_secondary and wl == 'mvedit32':
             try:
                 line['secondary'] = secondary(dev)

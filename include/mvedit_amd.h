@@ -224,6 +224,37 @@ MVE_API int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* 
                                  const void* residual, int ldr, int flags, float out_scale, void* d_workspace,
                                  size_t workspace_bytes, void* stream);
 
+/* ---- residual stream as an unrounded pair (round 4; the executor's `residual_pair` mode, mve_unet_set_residual_mode) -----------------------------
+ * The reference's half-precision modules round the residual stream x + f(x) of ResnetBlock2D / BasicTransformerBlock / Transformer2DModel
+ * (diffusers 0.27.2, driven from lib/models/architecture/diffusers.py:57-164) to 16 bits after every block: ~30 % of the end-to-end error against
+ * fp32 arithmetic (tests/rounding_budget_experiment.py).  In pair mode a stream tensor is stored as hi = round16(x) -- what every MFMA operand
+ * read sees, in the tensor's usual place -- and lo = round16(x - hi) in a companion tensor of the same shape: ~22 mantissa bits together.
+ * The *_pair entry points are the plain ones plus the companions:
+ *   d_residual_lo : low half of the residual ([M][ldr], NULL = the residual is `d_residual` alone); needs a residual added before the scale;
+ *   d_out_lo      : receives round16(v - round16(v)) next to d_out = round16(v) ([M][ldc], NULL = not wanted); 16-bit non-GEGLU outputs only;
+ *   d_x*_lo       : low halves of the normalised inputs (NULL = the input is the 16-bit tensor alone); statistics and the normalisation use hi + lo.
+ * With both companions NULL every *_pair call IS the plain call.  The 256-row tile starts its accumulators from the residual pair (one fp32
+ * addition order differs from the other kernels' (sum + bias) + residual), so in pair mode the 128-row and 256-row kernels agree to fp32 rounding,
+ * not bitwise. */
+MVE_API int mve_gemm_pair(int dtype, const void* d_A, int lda, const void* d_W, int ldw, void* d_out, int ldc,
+                          int M, int N, int K, const float* d_bias, const float* d_rowvec, int ldrv, int rows_per_vec,
+                          const void* d_residual, int ldr, int flags, float out_scale, void* d_workspace,
+                          size_t workspace_bytes, int rows_per_image, const void* d_residual_lo, void* d_out_lo, void* stream);
+MVE_API int mve_conv3x3_pair(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int Hs, int Ws, int stride,
+                             int upsample, const void* W, int Cout, void* out, int ldc, const float* bias, const float* rowvec,
+                             int ldrv, const void* residual, int ldr, int flags, float out_scale, void* d_workspace,
+                             size_t workspace_bytes, const void* d_residual_lo, void* d_out_lo, void* stream);
+MVE_API int mve_conv3x3_shortcut_pair(int dtype, const void* x1, int C1, const void* x3, int C3, const void* x4, int C4, int B, int Hs,
+                                      int Ws, const void* W, int Cout, void* out, int ldc, const float* bias, const float* bias2,
+                                      int flags, float out_scale, void* d_workspace, size_t workspace_bytes, void* d_out_lo, void* stream);
+MVE_API int mve_groupnorm_silu_pair(int dtype, const void* d_x1, int C1, const void* d_x2, int C2, int B, int HW, int G,
+                                    float eps, const float* d_gamma, const float* d_beta, int silu, void* d_out,
+                                    void* d_workspace, const void* d_x1_lo, const void* d_x2_lo, void* stream);
+MVE_API int mve_layernorm_pair(int dtype, const void* d_x, int ldx, void* d_y, int ldy, int M, int C,
+                               const float* d_gamma, const float* d_beta, float eps, const void* d_x_lo, void* stream);
+/* (hi, lo) = pair of ((a_hi + a_lo) + alpha * b): the ControlNet residual added to a skip tensor of the stream (diffusers.py:110-121) */
+MVE_API int mve_axpy_pair(int dtype, const void* d_a, const void* d_a_lo, const void* d_b, float alpha, void* d_y, void* d_y_lo, size_t n, void* stream);
+
 /* Scaled-dot-product attention over packed projections (no head permutes):
  *   Q row (b,i) at d_Q + (b*Lq+i)*ldq, head h at column h*head_dim; same for K/V with Lk, O with Lq.
  *   Optional second KV segment (K2,V2,Lk2) is logically concatenated after the first along the key
@@ -241,11 +272,12 @@ MVE_API int mve_attention(int dtype, const void* d_Q, int ldq, const void* d_K, 
  * that also spreads the transposing stores over the LDS banks (single KV segment, any head_dim; bit-identical results); 6 = 2 + 4;
  * 8..11 = for head_dim 40 the kernel with 32x32x16 Q K^T, LDS-DMA-staged row-major V read through the LDS transpose read and
  * v_permlane16_swap for P (8: 4 waves / 2 LDS stages, 9: 8 waves / 2, 10: 4 waves / 3, 11: 8 waves / 3 stages); other head dims keep 0.
- * Negative: query only.  Returns the previous value.  tools/ab_attention.py measures them on one box. */
+ * Negative: query only.  Returns the previous value (MVE_ERR_ARG for values >= 256 in a release build).  tools/ab_attention.py measures them on one box. */
 MVE_API int mve_attention_tune(int variant);
-/* Development aid (tools/ab_attention_ablate.py): bits 8-19 of mve_attention_tune's argument select a timing-only ablation of the
- * head_dim 40 kernel (results are wrong by construction); those launches add per-wave shader-clock and 100 MHz durations to a device
- * accumulator which this call reads into out4 = {shader cycles, 10 ns ticks, waves, 0} and resets. */
+/* Development aid (tools/ab_attention_ablate.py), DEVELOPMENT BUILDS ONLY (MVE_ATTN_LAB=1 python -m mvedit_amd.build): bits 8-19 of
+ * mve_attention_tune's argument select a timing-only ablation of the head_dim 40 kernel (results are wrong by construction); those launches add
+ * per-wave shader-clock and 100 MHz durations to a device accumulator which this call reads into out4 = {shader cycles, 10 ns ticks, waves, 0}
+ * and resets.  A release build carries none of those kernels: this call returns MVE_ERR_STATE and mve_attention_tune rejects the bits. */
 MVE_API int mve_attention_profile(unsigned long long* out4);
 /* The same attention with Q ALREADY multiplied by softmax_scale * log2(e) (= head_dim^-1/2 * 1.442695...): the logits are in log2 units
  * and no per-logit multiply remains.  This is how the UNet / ControlNet executors call it: they fold the factor into the to_q rows when the
@@ -571,6 +603,13 @@ MVE_API int mve_unet_graph(void* handle, int enable);
  *                   mve_unet_ref_store_bytes(B, ref_H, ref_W, ref_skip) bytes that must stay valid between the two passes. */
 MVE_API int mve_unet_set_attention(void* handle, int ip_tokens, float ip_scale, int ref_mode, int ref_H, int ref_W, int ref_skip,
                                    void* d_ref_store, size_t ref_store_bytes);
+/* Residual stream of the UNet / ControlNet executor (no reference counterpart: the reference's half modules round it after every block).
+ * pair = 1: x + f(x) of ResnetBlock2D / BasicTransformerBlock / Transformer2DModel is carried as an unrounded (hi, lo) pair of 16-bit tensors -- the
+ * residual adds, GroupNorm and LayerNorm read and write the pair, every MFMA operand reads `hi` -- which brings the end-to-end error of one SD-1.5
+ * forward at 64 x 64 against fp32 arithmetic from 1.23e-3 to below north_star's 1e-3 (tests/rounding_budget_experiment.py predicts 7.0e-4) for
+ * 4 more bytes per stream element and pass.  pair = 0 (default): the single 16-bit tensors of rounds 1-3.  Negative: query.  Returns the previous
+ * mode; the mode is part of the plan key. */
+MVE_API int mve_unet_set_residual_mode(void* handle, int pair);
 MVE_API size_t mve_unet_ref_store_bytes(void* handle, int B, int ref_H, int ref_W, int ref_skip);
 
 /* (No reference counterpart: executor introspection, the source of bench.py's per-kernel roofline figures.)

@@ -43,6 +43,10 @@ EXTRA_FLAGS = {
 }
 
 
+if os.environ.get('MVE_ATTN_LAB') == '1':        # development build: the timing-only ablation instantiations of k_attention3 (tools/ab_attention_ablate.py)
+    EXTRA_FLAGS['attention.hip'] = EXTRA_FLAGS['attention.hip'] + ['-DMVE_ATTN_LAB']
+
+
 def _hipcc():
     for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if cand and os.path.exists(cand):

@@ -890,6 +890,7 @@ int launch(const AttnParams& p, hipStream_t s) {
 #define MVE_A3(NW_, NST_, WPS_, PIPE_) do { \
                 if (p.Lk2 > 0) { if (p.prescaled && !PIPE_) MVE_A3P(true, NW_, NST_, WPS_, (!PIPE_), PIPE_); else MVE_A3P(true, NW_, NST_, WPS_, false, PIPE_); } \
                 else { if (p.prescaled && !PIPE_) MVE_A3P(false, NW_, NST_, WPS_, (!PIPE_), PIPE_); else MVE_A3P(false, NW_, NST_, WPS_, false, PIPE_); } } while (0)
+#ifdef MVE_ATTN_LAB                 // (development builds only: `python -m mvedit_amd.build` with MVE_ATTN_LAB=1 in the environment)
             if (g_attn_ablate != 0) {       // timing-only ablations of the default configuration (fp16, single segment, pre-scaled Q)
                 if constexpr (std::is_same<Tag, F16Tag>::value) {
                     if (p.Lk2 == 0 && p.prescaled) {
@@ -906,6 +907,7 @@ int launch(const AttnParams& p, hipStream_t s) {
                     }
                 }
             }
+#endif
             switch (var) {
                 case 8: MVE_A3(4, 2, 4, false); break;
                 case 9: MVE_A3(8, 2, 4, false); break;
@@ -970,6 +972,10 @@ int dispatch_d(const AttnParams& p, int d, hipStream_t s) {
 // development aid: sums over the waves of the profiled (ablation) launches since the last call: {shader cycles, 10 ns ticks, waves, 0}; resets them
 extern "C" int mve_attention_profile(unsigned long long* out4) {
     MVE_CHECK(out4, MVE_ERR_ARG, "attention_profile: null pointer");
+#ifndef MVE_ATTN_LAB
+    mve_set_error("attention_profile: the timing-only ablation kernels are compiled into development builds only (MVE_ATTN_LAB=1 python -m mvedit_amd.build)");
+    return MVE_ERR_STATE;
+#endif
     MVE_HIP(hipDeviceSynchronize());
     MVE_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_attn_prof), 4 * sizeof(unsigned long long)));
     const unsigned long long z[4] = {0ull, 0ull, 0ull, 0ull};
@@ -979,6 +985,10 @@ extern "C" int mve_attention_profile(unsigned long long* out4) {
 
 extern "C" int mve_attention_tune(int variant) {
     const int old = g_attn_variant | (g_attn_ablate << 8);
+#ifndef MVE_ATTN_LAB
+    // release builds carry no ablation kernels: a word with bits 8-19 set would otherwise select nothing silently
+    if (variant >= 256) { mve_set_error("attention_tune: ablation bits (8-19) need a development build (MVE_ATTN_LAB=1)"); return MVE_ERR_ARG; }
+#endif
     if (variant >= 0) { g_attn_variant = variant & 255; g_attn_ablate = (variant >> 8) & 4095; }
     return old;
 }

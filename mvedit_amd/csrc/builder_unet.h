@@ -103,7 +103,7 @@ int Builder::build(int B_, int H, int W, int n_img, int has_res, int io_dtype, i
     // ---- conv_in + down path ---------------------------------------------------------------------------
     struct Skip { Ref r; int C, H, W; };
     std::vector<Skip> skips;
-    Ref x = ws((size_t)M0 * c.ch[0] * e);
+    Ref x = ws_stream((size_t)M0 * c.ch[0] * e);
     if (c.controlnet) {
         // controlnet_cond_embedding on the 8H x 8W conditioning image, added to conv_in(sample)
         const int Hc = 8 * H, Wc = 8 * W, cc = c.cond_ch;
@@ -153,7 +153,7 @@ int Builder::build(int B_, int H, int W, int n_img, int has_res, int io_dtype, i
         }
         if (i + 1 < n) {
             const std::string dn = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
-            Ref y = ws((size_t)Bb * (h / 2) * (w / 2) * cin * e);
+            Ref y = ws_stream((size_t)Bb * (h / 2) * (w / 2) * cin * e);
             conv(x, cin, Bb, h, w, 2, 0, wt(dn + ".w"), cin, y, wt(dn + ".b"), Ref(), 0, Ref(), 0, "downsample");
             h /= 2; w /= 2;
             x = y;
@@ -182,15 +182,16 @@ int Builder::build(int B_, int H, int W, int n_img, int has_res, int io_dtype, i
             Skip& sk = skips[i];
             const size_t elems = (size_t)Bb * sk.H * sk.W * sk.C;
             Ref src; src.kind = Ref::DOWNRES; src.idx = (int)i;
-            Ref sum = ws(elems * e);
+            Ref sum = ws_stream(elems * e);
             Ref a = sk.r;
+            const Ref a_lo = lo(a), sum_lo = lo(sum);
             const int C = sk.C, sh = sk.H, sw = sk.W;
             if (res_nhwc) {
-                op(OC_OTHER, 0, "skip += controlnet residual", [=](const Run& r) { return mve_axpy(d, r.p(a), r.p(src), 1.0f, r.p(sum), elems, r.stream); });
+                op(OC_OTHER, 0, "skip += controlnet residual", [=](const Run& r) { return mve_axpy_pair(d, r.p(a), r.p(a_lo), r.p(src), 1.0f, r.p(sum), r.p(sum_lo), elems, r.stream); });
             } else {
                 Ref tmp = ws(elems * e);
                 op(OC_OTHER, 0, "residual nchw->nhwc", [=](const Run& r) { return mve_nchw_to_nhwc(d, io_dtype, r.p(src), Bb, C, sh, sw, C, r.p(tmp), r.stream); });
-                op(OC_OTHER, 0, "skip += controlnet residual", [=](const Run& r) { return mve_axpy(d, r.p(a), r.p(tmp), 1.0f, r.p(sum), elems, r.stream); });
+                op(OC_OTHER, 0, "skip += controlnet residual", [=](const Run& r) { return mve_axpy_pair(d, r.p(a), r.p(a_lo), r.p(tmp), 1.0f, r.p(sum), r.p(sum_lo), elems, r.stream); });
                 rel(tmp);
             }
             sk.r = sum;    // the un-summed skip stays allocated: unet_enc state must survive unet_dec
@@ -208,14 +209,15 @@ int Builder::build(int B_, int H, int W, int n_img, int has_res, int io_dtype, i
         if (has_res) {
             const size_t elems = (size_t)Bb * h * w * C;
             Ref src; src.kind = Ref::MIDRES;
-            Ref sum = ws(elems * e);
+            Ref sum = ws_stream(elems * e);
+            const Ref m_lo = lo(m), sum_lo = lo(sum);
             const int hh = h, ww = w;
             if (res_nhwc) {
-                op(OC_OTHER, 0, "mid += controlnet residual", [=](const Run& r) { return mve_axpy(d, r.p(m), r.p(src), 1.0f, r.p(sum), elems, r.stream); });
+                op(OC_OTHER, 0, "mid += controlnet residual", [=](const Run& r) { return mve_axpy_pair(d, r.p(m), r.p(m_lo), r.p(src), 1.0f, r.p(sum), r.p(sum_lo), elems, r.stream); });
             } else {
                 Ref tmp = ws(elems * e);
                 op(OC_OTHER, 0, "residual nchw->nhwc", [=](const Run& r) { return mve_nchw_to_nhwc(d, io_dtype, r.p(src), Bb, C, hh, ww, C, r.p(tmp), r.stream); });
-                op(OC_OTHER, 0, "mid += controlnet residual", [=](const Run& r) { return mve_axpy(d, r.p(m), r.p(tmp), 1.0f, r.p(sum), elems, r.stream); });
+                op(OC_OTHER, 0, "mid += controlnet residual", [=](const Run& r) { return mve_axpy_pair(d, r.p(m), r.p(m_lo), r.p(tmp), 1.0f, r.p(sum), r.p(sum_lo), elems, r.stream); });
                 rel(tmp);
             }
             rel(m);
@@ -243,7 +245,7 @@ int Builder::build(int B_, int H, int W, int n_img, int has_res, int io_dtype, i
         }
         if (i + 1 < n) {
             const std::string un = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
-            Ref y = ws((size_t)Bb * (2 * h) * (2 * w) * cout * e);
+            Ref y = ws_stream((size_t)Bb * (2 * h) * (2 * w) * cout * e);
             conv(x, cout, Bb, h, w, 1, 1, wt(un + ".w"), cout, y, wt(un + ".b"), Ref(), 0, Ref(), 0, "upsample+conv");
             rel(x);
             h *= 2; w *= 2;

@@ -11,6 +11,16 @@
 extern "C" {
 int mve_gemm(int, const void*, int, const void*, int, void*, int, int, int, int, const float*, const float*, int, int,
              const void*, int, int, float, void*, size_t, int, void*);
+int mve_gemm_pair(int, const void*, int, const void*, int, void*, int, int, int, int, const float*, const float*, int, int,
+                  const void*, int, int, float, void*, size_t, int, const void*, void*, void*);
+int mve_conv3x3_pair(int, const void*, int, const void*, int, int, int, int, int, int, const void*, int, void*, int,
+                     const float*, const float*, int, const void*, int, int, float, void*, size_t, const void*, void*, void*);
+int mve_conv3x3_shortcut_pair(int, const void*, int, const void*, int, const void*, int, int, int, int, const void*, int, void*, int,
+                              const float*, const float*, int, float, void*, size_t, void*, void*);
+int mve_groupnorm_silu_pair(int, const void*, int, const void*, int, int, int, int, float, const float*, const float*, int, void*,
+                            void*, const void*, const void*, void*);
+int mve_layernorm_pair(int, const void*, int, void*, int, int, int, const float*, const float*, float, const void*, void*);
+int mve_axpy_pair(int, const void*, const void*, const void*, float, void*, void*, size_t, void*);
 int mve_conv3x3(int, const void*, int, const void*, int, int, int, int, int, int, const void*, int, void*, int,
                 const float*, const float*, int, const void*, int, int, float, void*, size_t, void*);
 size_t mve_gemm_workspace_bytes(int, int, int, int);
@@ -170,12 +180,15 @@ struct Op {
 //                   lib/pipelines/zero123plus.py:43-77): 1 = 'w' (store the self-attention keys/values of every layer),
 //                   2 = 'r'/'m' (append the stored tokens to every self-attention's keys/values); ref_skip leading batch items
 //                   neither store nor read (is_cfg_guidance); ref_H x ref_W = latent size of the pass that wrote the store.
+//   residual_pair : not a processor option but a plan option of this engine (mve_unet_set_residual_mode): the residual stream of ResnetBlock2D /
+//                   BasicTransformerBlock / Transformer2DModel is kept as an unrounded (hi, lo) pair of 16-bit tensors (include/mvedit_amd.h).
 struct AttnOpts {
     int ip_tokens = 0; float ip_scale = 1.0f;
     int ref_mode = 0, ref_H = 0, ref_W = 0, ref_skip = 0;
+    int residual_pair = 0;
     bool operator==(const AttnOpts& o) const {
         return ip_tokens == o.ip_tokens && ip_scale == o.ip_scale && ref_mode == o.ref_mode && ref_H == o.ref_H && ref_W == o.ref_W &&
-               ref_skip == o.ref_skip;
+               ref_skip == o.ref_skip && residual_pair == o.residual_pair;
     }
 };
 

@@ -23,7 +23,27 @@ struct Builder {
     Builder(Unet& u_, Plan& p) : u(u_), pl(p), c(u_.cfg) {}
 
     Ref ws(size_t bytes) { Ref r; r.kind = Ref::WS; r.off = ar.alloc(bytes); return r; }
-    void rel(const Ref& r) { if (r.kind == Ref::WS) ar.release(r.off); }
+    // residual_pair mode (AttnOpts::residual_pair): a tensor of the residual stream gets a companion of the same size for its low half.  The
+    // companion is found through the high half's workspace offset, so the ops below pick it up by themselves: an output with a companion is
+    // written as a pair, a residual / normalised input with a companion is read as one.  Everything else -- every MFMA operand read -- sees the
+    // high half alone, exactly the tensor of the plain mode.
+    std::map<size_t, Ref> lo_of;
+    Ref ws_stream(size_t bytes) {
+        Ref r = ws(bytes);
+        if (pl.ao.residual_pair) lo_of[r.off] = ws(bytes);
+        return r;
+    }
+    Ref lo(const Ref& r) const {
+        if (r.kind != Ref::WS) return Ref();
+        auto it = lo_of.find(r.off);
+        return it == lo_of.end() ? Ref() : it->second;
+    }
+    void rel(const Ref& r) {
+        if (r.kind != Ref::WS) return;
+        auto it = lo_of.find(r.off);
+        if (it != lo_of.end()) { ar.release(it->second.off); lo_of.erase(it); }
+        ar.release(r.off);
+    }
     Ref wt(const std::string& n, size_t elem_off = 0) {
         auto it = u.params.find(n);
         Ref r;
@@ -53,9 +73,10 @@ struct Builder {
         live(A, what); live(out, what); live(res, what); live(rowvec, what);
         const size_t skb = mve_gemm_workspace_bytes(M, N, K, rimg);
         Ref sk = skb ? ws(skb) : Ref();
+        const Ref res_lo = lo(res), out_lo = lo(out);
         op(OC_LINEAR, 2.0 * M * N * K, what, [=](const Run& r) {
-            return mve_gemm(d, r.p(A), lda, r.p(W), ldw, r.p(out), ldc, M, N, K, (const float*)r.p(bias), (const float*)r.p(rowvec),
-                            ldrv, rpv, r.p(res), ldr, flags, out_scale, r.p(sk), skb, rimg, r.stream);
+            return mve_gemm_pair(d, r.p(A), lda, r.p(W), ldw, r.p(out), ldc, M, N, K, (const float*)r.p(bias), (const float*)r.p(rowvec),
+                                 ldrv, rpv, r.p(res), ldr, flags, out_scale, r.p(sk), skb, rimg, r.p(res_lo), r.p(out_lo), r.stream);
         });
         rel(sk);
     }
@@ -68,9 +89,11 @@ struct Builder {
         const int fl = flags | (C1 % 64 == 0 ? MVE_CONV_W_CHUNK64 : 0);   // must mirror load_param's packing rule
         const size_t skb = mve_gemm_workspace_bytes(Bn * Ho * Wo, Cout, 9 * C1, Ho * Wo);
         Ref sk = skb ? ws(skb) : Ref();
+        const Ref res_lo = lo(res), out_lo = (flags & MVE_GEMM_OUT_F32) ? Ref() : lo(out);
         op(OC_CONV, 2.0 * Bn * Ho * Wo * (double)Cout * 9 * C1, what, [=](const Run& r) {
-            return mve_conv3x3(d, r.p(x), C1, nullptr, 0, Bn, H, W, stride, ups, r.p(Wt), Cout, r.p(out), Cout,
-                               (const float*)r.p(bias), (const float*)r.p(rowvec), ldrv, r.p(res), Cout, fl, 1.0f, r.p(sk), skb, r.stream);
+            return mve_conv3x3_pair(d, r.p(x), C1, nullptr, 0, Bn, H, W, stride, ups, r.p(Wt), Cout, r.p(out), Cout,
+                                    (const float*)r.p(bias), (const float*)r.p(rowvec), ldrv, r.p(res), Cout, fl, 1.0f, r.p(sk), skb, r.p(res_lo),
+                                    r.p(out_lo), r.stream);
         });
         rel(sk);
     }
@@ -79,17 +102,19 @@ struct Builder {
         const size_t wsb = mve_groupnorm_workspace_bytes(Bn, HW, C1 + C2, G);
         Ref scratch = ws(wsb);
         live(x1, what); live(x2, what); live(out, what);
+        const Ref x1_lo = lo(x1), x2_lo = lo(x2);
         op(OC_NORM, 0, what, [=](const Run& r) {
-            return mve_groupnorm_silu(d, r.p(x1), C1, r.p(x2), C2, Bn, HW, G, eps, (const float*)r.p(g), (const float*)r.p(b), silu,
-                                      r.p(out), r.p(scratch), r.stream);
+            return mve_groupnorm_silu_pair(d, r.p(x1), C1, r.p(x2), C2, Bn, HW, G, eps, (const float*)r.p(g), (const float*)r.p(b), silu,
+                                           r.p(out), r.p(scratch), r.p(x1_lo), r.p(x2_lo), r.stream);
         });
         rel(scratch);
     }
     void ln(Ref x, Ref y, int M, int C, Ref g, Ref b) {
         const int d = dt;
         live(x, "layernorm"); live(y, "layernorm");
+        const Ref x_lo = lo(x);
         op(OC_NORM, 0, "layernorm", [=](const Run& r) {
-            return mve_layernorm(d, r.p(x), C, r.p(y), C, M, C, (const float*)r.p(g), (const float*)r.p(b), 1e-5f, r.stream);
+            return mve_layernorm_pair(d, r.p(x), C, r.p(y), C, M, C, (const float*)r.p(g), (const float*)r.p(b), 1e-5f, r.p(x_lo), r.stream);
         });
     }
     // Q as mve_attention_prescaled wants it: the output of a GEMM over a to_q weight slot that carries the softmax scale.  The only way to get one
@@ -156,15 +181,16 @@ struct Builder {
         rel(h1);
         if (Cin != Cout && u.fuse_sc) {
             // conv2 and the 1x1 conv_shortcut over [x | skip] share one K loop (mve_conv3x3_shortcut); no shortcut tensor exists
-            Ref out = ws((size_t)M * Cout * e);
+            Ref out = ws_stream((size_t)M * Cout * e);
+            const Ref out_lo = lo(out);
             const int d = dt, Bn = B;
             Ref Wt = wt(name + ".conv2.w"), b2 = wt(name + ".conv2.b"), bs = wt(name + ".sc.b");
             live(h2, "resnet.conv2+shortcut"); live(x, "resnet.conv2+shortcut"); live(skip, "resnet.conv2+shortcut");
             const size_t skb = mve_gemm_workspace_bytes(M, Cout, 9 * Cout + Cin, H * W);
             Ref sk = skb ? ws(skb) : Ref();
             op(OC_CONV, 2.0 * M * (double)Cout * (9 * Cout + Cin), "resnet.conv2+shortcut", [=](const Run& r) {
-                return mve_conv3x3_shortcut(d, r.p(h2), Cout, r.p(x), C1, r.p(skip), C2, Bn, H, W, r.p(Wt), Cout, r.p(out), Cout,
-                                            (const float*)r.p(b2), (const float*)r.p(bs), nullptr, 0, 0, 1.0f, r.p(sk), skb, r.stream);
+                return mve_conv3x3_shortcut_pair(d, r.p(h2), Cout, r.p(x), C1, r.p(skip), C2, Bn, H, W, r.p(Wt), Cout, r.p(out), Cout,
+                                                 (const float*)r.p(b2), (const float*)r.p(bs), 0, 1.0f, r.p(sk), skb, r.p(out_lo), r.stream);
             });
             rel(sk);
             rel(h2);
@@ -177,7 +203,7 @@ struct Builder {
             if (C2) gemm(skip, C2, wt(name + ".sc.w", C1), Cin, sc, Cout, M, Cout, C2, Ref(), Ref(), 0, 0, sc, Cout, 0, "resnet.shortcut(skip)");
             res = sc;
         }
-        Ref out = ws((size_t)M * Cout * e);
+        Ref out = ws_stream((size_t)M * Cout * e);
         conv(h2, Cout, B, H, W, 1, 0, wt(name + ".conv2.w"), Cout, out, wt(name + ".conv2.b"), Ref(), 0, res, 0, "resnet.conv2");
         rel(h2);
         rel(sc);
@@ -191,7 +217,7 @@ struct Builder {
         const int nb = B / pl.n_img, L = H * W * pl.n_img;     // cross-image attention: [n*b, L, C] seen as [b, n*L, C]
         Ref n0 = ws((size_t)M * C * e);
         gn(x, C, Ref(), 0, B, H * W, 1e-6f, wt(name + ".norm.g"), wt(name + ".norm.b"), 0, n0, "transformer.norm");
-        Ref h = ws((size_t)M * C * e);
+        Ref h = ws_stream((size_t)M * C * e);
         gemm(n0, C, wt(name + ".proj_in.w"), C, h, C, M, C, C, wt(name + ".proj_in.b"), Ref(), 0, 0, Ref(), 0, 0, "transformer.proj_in");
         rel(n0);
         for (int k = 0; k < layers; ++k) {
@@ -228,7 +254,7 @@ struct Builder {
                 }
             }
             rel(qkv);
-            Ref h2 = ws((size_t)M * C * e);
+            Ref h2 = ws_stream((size_t)M * C * e);
             gemm(a, C, wt(b + ".o1.w"), C, h2, C, M, C, C, wt(b + ".o1.b"), Ref(), 0, 0, h, C, 0, "attn1.to_out+residual");
             rel(a); rel(h); h = h2;
             // cross attention (K/V hoisted)
@@ -251,7 +277,7 @@ struct Builder {
                 rel(aip);
             }
             rel(q);
-            Ref h3 = ws((size_t)M * C * e);
+            Ref h3 = ws_stream((size_t)M * C * e);
             gemm(a2, C, wt(b + ".o2.w"), C, h3, C, M, C, C, wt(b + ".o2.b"), Ref(), 0, 0, h, C, 0, "attn2.to_out+residual");
             rel(a2); rel(h); h = h3;
             // feed forward (GEGLU fused in the first GEMM's epilogue)
@@ -260,11 +286,11 @@ struct Builder {
             Ref f = ws((size_t)M * 4 * C * e);
             gemm(n3, C, wt(b + ".ff1.w"), C, f, 4 * C, M, 8 * C, C, wt(b + ".ff1.b"), Ref(), 0, 0, Ref(), 0, MVE_GEMM_GEGLU, "ff.geglu");
             rel(n3);
-            Ref h4 = ws((size_t)M * C * e);
+            Ref h4 = ws_stream((size_t)M * C * e);
             gemm(f, 4 * C, wt(b + ".ff2.w"), 4 * C, h4, C, M, C, 4 * C, wt(b + ".ff2.b"), Ref(), 0, 0, h, C, 0, "ff.out+residual");
             rel(f); rel(h); h = h4;
         }
-        Ref out = ws((size_t)M * C * e);
+        Ref out = ws_stream((size_t)M * C * e);
         gemm(h, C, wt(name + ".proj_out.w"), C, out, C, M, C, C, wt(name + ".proj_out.b"), Ref(), 0, 0, x, C, 0, "transformer.proj_out+residual");
         rel(h);
         return out;

@@ -411,6 +411,7 @@ int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
         if (rc <= 0) return rc;
     }
     if (q->tile_n == 160 || mve_gemm_big_blocks(q->M, q->N, q->splitk) <= 0) return 1;
+    if (q->residual_lo || q->out_lo) return 1;        // residual_pair mode: only the ping-pong 320-wide tile and the 128-row kernel carry the pair
     return mve_gemm_big_launch(dtype, mode, q, s);
 }
 
@@ -440,7 +441,8 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         GemmParams q = p;
         q.splitk_seq = gemm_strict_splitk() ? p.splitk : 0;      // default: ONE accumulation chain over all of K (see gemm_strict_splitk)
         q.splitk = 1;
-        return launch_tile256(Tag::dtype, MODE, &q, s);
+        const int rc = launch_tile256(Tag::dtype, MODE, &q, s);
+        if (rc != 1) return rc;                            // 1: no 256-row loop takes it in this form (e.g. strict slices + residual pair): split K for real below
     }
     // small batches: 256 x 320 tiles would leave CUs without a block, 256 x 160 tiles (ping-pong loop only) still cover them
     const bool narrow = gemm_big_min_blocks() > 0 && gemm_pp_on() && p.splitk <= 1 && p.N % 320 == 0 && p.M >= 64 &&
@@ -471,6 +473,9 @@ int check_common(const GemmParams& p, const char* who) {
               "%s: rowvec needs rows_per_vec > 0 and ldrv (%d) a multiple of 4 >= N (or 0: one vector for all rows)", who, p.ldrv);
     MVE_CHECK(p.ldw % 8 == 0 && p.ldw >= p.K, MVE_ERR_ARG, "%s: ldw (%d) must be a multiple of 8 and >= K", who, p.ldw);
     MVE_CHECK(!(p.geglu && (p.residual || p.out_f32)), MVE_ERR_ARG, "%s: geglu excludes residual/out_f32", who);
+    MVE_CHECK(!(p.residual_lo && (!p.residual || p.res_after_scale)), MVE_ERR_ARG, "%s: residual_lo needs a residual that is added before the scale", who);
+    MVE_CHECK(!(p.out_lo && (p.out_f32 || p.geglu || p.ldc % 8 != 0 || (p.residual && p.res_after_scale))), MVE_ERR_ARG,
+              "%s: out_lo needs a 16-bit, non-GEGLU output with ldc a multiple of 8 and no residual after the scale", who);
     return MVE_OK;
 }
 
@@ -503,9 +508,18 @@ size_t mve_gemm_workspace_bytes(int M, int N, int K, int rows_per_image) {
 int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
              const float* bias, const float* rowvec, int ldrv, int rows_per_vec, const void* residual, int ldr, int flags,
              float out_scale, void* workspace, size_t workspace_bytes, int rows_per_image, void* stream) {
+    return mve_gemm_pair(dtype, A, lda, W, ldw, out, ldc, M, N, K, bias, rowvec, ldrv, rows_per_vec, residual, ldr, flags, out_scale, workspace,
+                         workspace_bytes, rows_per_image, nullptr, nullptr, stream);
+}
+
+int mve_gemm_pair(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
+                  const float* bias, const float* rowvec, int ldrv, int rows_per_vec, const void* residual, int ldr, int flags,
+                  float out_scale, void* workspace, size_t workspace_bytes, int rows_per_image, const void* residual_lo, void* out_lo,
+                  void* stream) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
+    p.residual_lo = residual_lo; p.out_lo = out_lo;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrv = ldrv;
     p.rows_per_vec = rows_per_vec;
     p.geglu = (flags & MVE_GEMM_GEGLU) ? 1 : 0;
@@ -530,7 +544,7 @@ int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* ou
 static int conv3x3_impl(int dtype, const void* x1, int C1, const void* x2, int C2, const void* x3, int C3, const void* x4, int C4, int B,
                         int Hs, int Ws, int stride, int upsample, const void* W, int Cout, void* out, int ldc, const float* bias,
                         const float* rowvec, int ldrv, const void* residual, int ldr, int flags, float out_scale, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+                        size_t workspace_bytes, void* stream, const void* residual_lo = nullptr, void* out_lo = nullptr) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     MVE_CHECK(stride == 1 || stride == 2, MVE_ERR_ARG, "conv3x3: stride must be 1 or 2");
@@ -553,6 +567,7 @@ static int conv3x3_impl(int dtype, const void* x1, int C1, const void* x2, int C
     MVE_CHECK(!p.g.chunk64 || (C1 % 64 == 0 && C2 % 64 == 0), MVE_ERR_ARG,
               "conv3x3: MVE_CONV_W_CHUNK64 needs channel counts that are multiples of 64 (C1=%d C2=%d)", C1, C2);
     p.A = x1; p.A2 = x2; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
+    p.residual_lo = residual_lo; p.out_lo = out_lo;
     p.M = B * p.g.Ho * p.g.Wo; p.N = Cout; p.K = 9 * (C1 + C2);
     if (C3 > 0) {     // fused 1x1 shortcut: K continues over the channels of x3 (and x4)
         MVE_CHECK(p.g.chunk64 && !upsample && stride == 1 && C3 % 64 == 0 && C4 >= 0 && C4 % 64 == 0 && x3 && (C4 == 0 || x4), MVE_ERR_ARG,
@@ -587,6 +602,22 @@ int mve_conv3x3(int dtype, const void* x1, int C1, const void* x2, int C2, int B
                 void* stream) {
     return conv3x3_impl(dtype, x1, C1, x2, C2, nullptr, 0, nullptr, 0, B, Hs, Ws, stride, upsample, W, Cout, out, ldc, bias, rowvec, ldrv,
                         residual, ldr, flags, out_scale, workspace, workspace_bytes, stream);
+}
+
+int mve_conv3x3_pair(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int Hs, int Ws, int stride,
+                     int upsample, const void* W, int Cout, void* out, int ldc, const float* bias, const float* rowvec,
+                     int ldrv, const void* residual, int ldr, int flags, float out_scale, void* workspace, size_t workspace_bytes,
+                     const void* residual_lo, void* out_lo, void* stream) {
+    return conv3x3_impl(dtype, x1, C1, x2, C2, nullptr, 0, nullptr, 0, B, Hs, Ws, stride, upsample, W, Cout, out, ldc, bias, rowvec, ldrv,
+                        residual, ldr, flags, out_scale, workspace, workspace_bytes, stream, residual_lo, out_lo);
+}
+
+int mve_conv3x3_shortcut_pair(int dtype, const void* x1, int C1, const void* x3, int C3, const void* x4, int C4, int B, int Hs, int Ws,
+                              const void* W, int Cout, void* out, int ldc, const float* bias, const float* bias2, int flags, float out_scale,
+                              void* workspace, size_t workspace_bytes, void* out_lo, void* stream) {
+    MVE_CHECK(C3 > 0, MVE_ERR_ARG, "conv3x3_shortcut: no shortcut source");
+    return conv3x3_impl(dtype, x1, C1, nullptr, 0, x3, C3, x4, C4, B, Hs, Ws, 1, 0, W, Cout, out, ldc, bias, bias2, 0, nullptr, 0,
+                        flags | MVE_CONV_W_CHUNK64, out_scale, workspace, workspace_bytes, stream, nullptr, out_lo);
 }
 
 int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* x3, int C3, const void* x4, int C4, int B, int Hs, int Ws,

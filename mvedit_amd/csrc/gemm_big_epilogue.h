@@ -19,8 +19,17 @@ __device__ __forceinline__ void big_lds_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// compiler-level ordering fence: nothing is moved across it (loads placed behind it stay behind the LDS writes in front of it)
+__device__ __forceinline__ void big_lds_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // WAVES_N: waves along N (4: 2 x 4 arrangement, wave tile 128 x BN2/4;  2: 4 x 2 arrangement, wave tile 64 x BN2/2)
-template <class Tag, int BN2, int WAVES_N = 4>
+// PAIR: the kernel instantiation that serves the executor's residual_pair mode (GemmParams::residual_lo / out_lo).  A separate instantiation, not a
+// run-time branch: with both fast paths in one function hipcc's register allocation of the ordinary one degrades from 1 to ~90 spilled registers.
+template <class Tag, int BN2, int WAVES_N = 4, bool PAIR = false>
 __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&acc)[BN2 / WAVES_N / 16][256 / (8 / WAVES_N) / 16], unsigned char* smem,
                                                   int m0, int n0, int kslice, int tid, int lane, int wm, int wn) {
     typedef typename Tag::V8 V8;
@@ -32,7 +41,7 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
     // ---- GEGLU epilogue: out[m][i] = (v[2i] + b[2i]) * gelu(v[2i+1] + b[2i+1]).  A lane owns 4 consecutive n = two
     // (value, gate) pairs of one row, so the activation is evaluated on the accumulators; only the 16-bit results (half the
     // columns) pass through LDS, in ONE 256-row pass, for 16-byte row-segment stores.  Same arithmetic as gemm_epilogue_store.
-    if (p.geglu && p.splitk <= 1) {
+    if (!PAIR && p.geglu && p.splitk <= 1) {
         constexpr int HS_LD = BN2 / 2 + 8;              // 168 elements: conflict-free 4-byte writes (row stride 84 words)
         T* Hs = reinterpret_cast<T*>(smem);
         typedef T T2 __attribute__((ext_vector_type(2)));
@@ -103,7 +112,7 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
             b1 = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
         }
         if (rv_pass) load_rv(m0 < p.M ? m0 : p.M - 1, rv0, rv1);
-        if (p.residual) {
+        if (!PAIR && p.residual) {         // (PAIR: the residual is inside the accumulators already, or -- split K -- the reducer's business)
 #pragma unroll
             for (int k = 0; k < NIT; ++k) rr[k] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)row_c(0, k) * p.ldr + nc);
         }
@@ -115,7 +124,73 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
     // Same operations in the same order as gemm_epilogue_tail, so the bits are the same.
     const bool fast = !partial && p.bias && p.out_scale == 1.0f && !p.res_after_scale && !p.out_f32 && (!p.rowvec || rv_pass) &&
                       m0 + BM2 <= p.M && n0 + BN2 <= p.N;
-    if (fast) {
+    if constexpr (PAIR) {
+      // ---- the fast path of the executor's residual_pair mode: the result leaves as (hi, lo) = (round16(v), round16(v - hi)).  The residual pair is
+      // NOT read here: the PAIR kernel starts its accumulators from it (k_gemm_pp, pp_acc_from_residual), so this epilogue has no loads behind its
+      // stores and nothing to prefetch next to the 160 accumulators.  (Reading both halves a pass ahead, as the ordinary path reads its one tensor,
+      // needs 48 registers in flight; hipcc assigns them while all accumulators are live and spills 100-146 registers INTO the chunk loop, where a
+      // scratch reload queues behind the stores -- 32-row passes, buffer addressing and late-born offsets brought that to ~20, not to zero.)
+      // A pass stages 32 rows of each wave row (tile rows [32 p, 32 p + 32) and [128 + 32 p, ...)); the four output streams are addressed as
+      // buffer resource (SGPRs: tile origin) + 32-bit lane offset per chunk + scalar offset per pass.
+      // A row vector must be constant over the tile (rows_per_vec % 256 == 0: every level but the 8 x 8 one, whose launches split K anyway).
+      static_assert(!PAIR || (WAVES_N == 4 && MF == 8), "the residual-pair epilogue is written for the 2 x 4 wave arrangement");
+      if (fast && p.out_lo && (!p.rowvec || p.rows_per_vec % BM2 == 0)) {
+        auto run_pair = [&](auto rv_c) {
+#pragma clang fp contract(off)
+            constexpr bool RV = decltype(rv_c)::value;
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            constexpr int HALF = 32;                         // staged rows per pass: HALF from each wave row
+            // staged row of chunk k (rows past the pass redo the previous row and store nothing) and its tile row in pass 0
+            auto srow = [&](int k) { const int r = r0c + RPI * k; return r < 64 ? r : r - RPI; };
+            auto trow0 = [&](int k) { const int r = srow(k); return r + (r >= HALF ? 128 - HALF : 0); };
+            auto rsrc = [&](const void* base, size_t elem_off) {
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + elem_off * sizeof(T), 0, 0x7FFFFFFF, 0x00020000);
+            };
+            const __amdgpu_buffer_rsrc_t b_out = rsrc(p.out, (size_t)m0 * p.ldc + n0), b_outl = rsrc(p.out_lo, (size_t)m0 * p.ldc + n0);
+            const int pass_o = HALF * p.ldc * (int)sizeof(T);                    // a pass advances every tile row by HALF
+            const f32x4 fb0 = *reinterpret_cast<const f32x4*>(p.bias + n), fb1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+            f32x4 frv0 = {}, frv1 = {};
+            if constexpr (RV) load_rv(m0, frv0, frv1);       // one image per tile
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const int r = wm * HALF + f * 16 + (lane & 15);
+                        const int c = wn * WTN + j * 16 + (lane >> 4) * 4;
+                        *reinterpret_cast<f32x4*>(Cs + r * CS_LD + c) = acc[j][pass * 2 + f];
+                    }
+                big_lds_barrier();
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const bool ok = active && r0c + RPI * k < 64;
+                    const float* cs = Cs + srow(k) * CS_LD + ch * 8;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cs), hi = *reinterpret_cast<const f32x4*>(cs + 4);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e] + fb0[e]; v[4 + e] = hi[e] + fb1[e]; }
+                    if constexpr (RV) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += frv0[e]; v[4 + e] += frv1[e]; }
+                    }
+                    V8 pk, pl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pk[e] = Tag::from_f32(v[e]); pl[e] = Tag::from_f32(v[e] - Tag::to_f32(pk[e])); }
+                    if (ok) {
+                        const int vw = (trow0(k) * p.ldc + ch * 8) * (int)sizeof(T);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pk), b_out, vw, pass * pass_o, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pl), b_outl, vw, pass * pass_o, 0);
+                    }
+                }
+                big_lds_barrier();
+            }
+        };
+        if (p.rowvec) run_pair(std::true_type()); else run_pair(std::false_type());
+        return;
+      }
+    }
+    if (!PAIR && fast) {
         auto run_fast = [&](auto rv_c, auto res_c) {
 #pragma clang fp contract(off)
             constexpr bool RV = decltype(rv_c)::value, RES = decltype(res_c)::value;
@@ -207,7 +282,7 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
             const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + rcl * CS_LD + ch * 8);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + rcl * CS_LD + ch * 8 + 4);
             const V8 res = rr[k];
-            if (!partial && p.residual && pass + 1 < NPASS)
+            if (!PAIR && !partial && p.residual && pass + 1 < NPASS)
                 rr[k] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)row_c(pass + 1, k) * p.ldr + nc);
             float v[8];
 #pragma unroll
@@ -230,7 +305,7 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
             }
-            gemm_epilogue_tail<Tag>(p, mc, nc, v, res, ok);
+            gemm_epilogue_tail<Tag, PAIR, PAIR>(p, mc, nc, v, res, ok);
         }
         big_lds_barrier();
     }

@@ -219,7 +219,7 @@ template <int V> struct PInt { static constexpr int value = V; };
 // NSL: LDS ring slots (prefetch distance NSL - 1).  NSL = 3 (BN2 = 160, dense GEMM only): the tile that lets TWO blocks share a CU -- 128
 // registers, 79 KiB -- so that one block's epilogue (memory-latency bound: residual reads, stores; no MFMA) runs under the other block's
 // K loop and the fragment reads of either hide behind the other's MFMAs; its epilogue is per wave (pp2_epilogue), without block barriers.
-template <class Tag, int MODE, bool SEQ, int BN2, bool PROF = false, int NSL = PNSLOT>        // MODE 1: slab-major (chunk64) conv only
+template <class Tag, int MODE, bool SEQ, int BN2, bool PROF = false, int NSL = PNSLOT, bool PAIR = false>        // MODE 1: slab-major (chunk64) conv only; PAIR: residual_pair epilogue
 __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmParams p) {
     typedef typename Tag::V8 V8;
     // BN2 = 320 | 256: waves 2 (M) x 4 (N), wave tile 128 x {80, 64};  BN2 = 128 (the 128-channel convolutions of the VAE at image
@@ -263,13 +263,51 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
     for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     unsigned long long prof_v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_start = 0, prof_loop0 = 0, prof_end_loop = 0;
     if constexpr (PROF) prof_start = __builtin_readcyclecounter();
     // Everything from here to the end of the K loop exists once per role (ROLE 0: waves 0-3 stream the weight rows, ROLE 1: waves 4-7
     // the activation rows): two straight-line copies instead of role tests, and their loop-carried copies, inside every step.
+    // (each role's copy of the loop starts its own accumulators: defined once in front of the role branch, hipcc parks 23 of them in scratch around the loops)
     auto run = [&](auto role_c) {
     constexpr int ROLE = decltype(role_c)::value;
+    if constexpr (PAIR) {
+        // residual_pair mode: the accumulators START from the residual, hi + lo (exact in fp32), read in the accumulator layout -- a lane owns 4
+        // consecutive columns of a row per fragment: 8-byte loads, 16 rows x 32 B per instruction -- before any LDS-DMA is in flight (the loads are
+        // the compiler's: it waits for them where it converts them).  The epilogue then has no load behind its stores and no residual to prefetch
+        // next to 160 accumulators (gemm_big_epilogue.h).  A split-K slice starts from zero: the reducer adds the residual.  Rows past M are clamped
+        // (never stored).  The sum is residual + sum_k a w, then + bias: the same value as the other kernels' (sum + bias) + residual up to the order
+        // of two fp32 additions.
+        if (p.residual && p.splitk <= 1) {
+            typedef typename Tag::T T;
+            typedef T T4 __attribute__((ext_vector_type(4)));
+            const T* rh = reinterpret_cast<const T*>(p.residual);
+            const T* rl = reinterpret_cast<const T*>(p.residual_lo);
+            const int col = n0 + wn * WTN + (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {                   // one fragment row at a time (10 loads in flight): hoisted to the top, the 80 loads would spill
+                int m = m0 + wm * WTM + i * 16 + (lane & 15);
+                m = m < p.M ? m : p.M - 1;
+                const size_t ro = (size_t)m * p.ldr + col;
+                T4 h[NF], l[NF];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    h[j] = *reinterpret_cast<const T4*>(rh + ro + j * 16);
+                    l[j] = rl ? *reinterpret_cast<const T4*>(rl + ro + j * 16) : T4{};
+                }
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {               // (whole-vector assignment: element writes through the captured reference keep `acc` in scratch)
+                    f32x4 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = Tag::to_f32(h[j][e]) + Tag::to_f32(l[j][e]);
+                    acc[j][i] = a;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing of the compiler's may be in flight when the counted LDS-DMA waits begin
+        }
+    }
     constexpr int NPM = ROLE == 0 ? NPB : NPA;                 // pieces this wave issues per step
     // ---- DMA role state ------------------------------------------------------------------------------------------------------
     // lane l of a piece writes LDS bytes [16 l, 16 l + 16): row l >> 2 of the piece, stored chunk l & 3 = source chunk ^ swizzle
@@ -519,7 +557,7 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
     pp_barrier();
     pp_mfma_settle();
     if constexpr (NSL == 3) pp2_epilogue<Tag>(p, acc, smem, m0, n0, wid, lane, wm, wn);
-    else big_tile_epilogue<Tag, BN2, WAVES_N>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
+    else big_tile_epilogue<Tag, BN2, WAVES_N, PAIR>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
     if constexpr (PROF) {
         if (g_pp_prof && lane == 0) {
             __builtin_amdgcn_s_waitcnt(0);     // the epilogue's stores have left the wave (vmcnt / lgkmcnt / expcnt all zero)
@@ -541,6 +579,23 @@ unsigned long long* g_pp_prof_host = nullptr;
 
 template <class Tag, int MODE, bool SEQ, int BN2>
 int launch_pp3(const GemmParams& p, hipStream_t s) {
+    if (p.residual_lo || p.out_lo) {          // residual_pair mode: the 320-wide tile without the slice fold has the instantiation for it
+        if constexpr (!SEQ && BN2 == 320) {
+            static bool configured_pair[64] = {};
+            int dev = 0;
+            MVE_HIP(hipGetDevice(&dev));
+            if (dev >= 0 && dev < 64 && !configured_pair[dev]) {
+                MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pp<Tag, MODE, SEQ, BN2, false, PNSLOT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pp_smem(BN2)));
+                configured_pair[dev] = true;
+            }
+            const unsigned grid = (unsigned)mve_cdiv(p.M, PBM) * (unsigned)mve_cdiv(p.N, BN2) * (unsigned)(p.splitk > 1 ? p.splitk : 1);
+            k_gemm_pp<Tag, MODE, SEQ, BN2, false, PNSLOT, true><<<grid, PNTH, pp_smem(BN2), s>>>(p);
+            MVE_LAUNCH_CHECK();
+            return MVE_OK;
+        } else {
+            return 1;                         // not eligible: the caller falls back (128-row kernel: gemm_epilogue_tail carries the pair)
+        }
+    }
     if constexpr (std::is_same<Tag, F16Tag>::value && !SEQ && BN2 == 320) {
         if (g_pp_prof_host) {
             MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pp<Tag, MODE, SEQ, BN2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pp_smem(BN2)));
@@ -567,6 +622,7 @@ int launch_pp3(const GemmParams& p, hipStream_t s) {
 bool pp2_eligible(int mode, const GemmParams& p) {
     if (mode != 0 || p.N % 160 != 0 || p.M % PBM != 0 || p.K % BK != 0) return false;
     if (p.splitk > 1 || p.splitk_seq > 1 || p.rowvec || p.out_f32 || p.out_scale != 1.0f || (p.residual && p.res_after_scale)) return false;
+    if (p.residual_lo || p.out_lo) return false;          // the pair epilogue lives in big_tile_epilogue / gemm_epilogue_tail only
     if (p.geglu && (p.ldc % 8 != 0)) return false;
     if (!p.geglu && p.ldc % 8 != 0) return false;
     return pp_fits((unsigned long long)p.N * p.ldw * 2) && pp_fits((unsigned long long)p.M * p.lda * 2);

@@ -36,6 +36,10 @@ struct GemmParams {
     const float* bias;       // [N] or null
     const float* rowvec;     // [M/rows_per_vec][ldrv] f32 (time embedding), or null
     const void* residual;    // [M][ldr] 16-bit or null
+    // Residual stream as an unrounded pair (round 4, the executor's `residual_pair` mode): a stream tensor x is stored as hi = round16(x) -- what every
+    // MFMA operand read sees -- and lo = round16(x - hi), together ~22 mantissa bits.  Both null: the single 16-bit tensors of rounds 1-3.
+    const void* residual_lo; // [M][ldr] 16-bit: the low half of the residual, or null (residual is then the whole value)
+    void* out_lo;            // [M][ldc] 16-bit: receives round16(v - round16(v)) next to out = round16(v), or null
     int M, N, K;
     int lda, ldw, ldc, ldr, ldrv;   // row strides (elements) of A, W, out, residual, rowvec
     int rows_per_vec;
@@ -88,20 +92,28 @@ __device__ __forceinline__ const T* conv_src(const GemmParams& p, int cb, int cy
 // Last part of the fused epilogue with the residual chunk already loaded (the 256-row tiles request it one pass ahead, see
 // gemm_big_epilogue.h): residual, output scale, storage-dtype (or fp32) store.  One definition, contraction off, so that every kernel
 // and the split-K reducer round identically.
-template <class Tag>
+// PAIR = false compiles the residual-pair handling out (the 256-row kernels that never see a pair keep the register allocation of rounds 1-3).
+// RES_DONE: the caller's accumulators started from the residual (the PAIR instantiation of k_gemm_pp): nothing to add here.
+template <class Tag, bool PAIR = true, bool RES_DONE = false>
 __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, int n, float (&v)[8], const typename Tag::V8& rr, bool ok = true) {
 #pragma clang fp contract(off)
     typedef typename Tag::T T;
     typedef typename Tag::V8 V8;
-    if (p.residual && !p.res_after_scale) {
+    if (!RES_DONE && p.residual && !p.res_after_scale) {
+        if (PAIR && p.residual_lo) {     // the pair is added as ONE value: hi + lo is exact in fp32 (|lo| <= ulp(hi) / 2)
+            const V8 rl = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual_lo) + (size_t)m * p.ldr + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
+            for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]) + Tag::to_f32(rl[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
+        }
     }
     if (p.out_scale != 1.0f) {           // (x * 1 == x bit for bit: the test only saves the multiplies)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
     }
-    if (p.residual && p.res_after_scale) {
+    if (!RES_DONE && p.residual && p.res_after_scale) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
     }
@@ -118,6 +130,12 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
         for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
         T* op = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n;
         if (ok) *reinterpret_cast<V8*>(op) = pk;
+        if (PAIR && p.out_lo) {
+            V8 pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pl[e] = Tag::from_f32(v[e] - Tag::to_f32(pk[e]));
+            if (ok) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out_lo) + (size_t)m * p.ldc + n) = pl;
+        }
     }
 }
 

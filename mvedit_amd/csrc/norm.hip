@@ -31,6 +31,7 @@ struct GNSrc {
     const void* x1; const void* x2;
     int C1, C2;       // channels of each source (C2 may be 0)
     int HW, B;
+    const void* x1_lo; const void* x2_lo;      // residual_pair mode: low halves of the sources (the value is hi + lo), or null
 };
 
 // chunk index (over the concatenated channel axis) -> source pointer for row r of image b
@@ -42,7 +43,26 @@ __device__ __forceinline__ const typename Tag::T* gn_chunk_ptr(const GNSrc& s, i
     return reinterpret_cast<const T*>(s.x2) + ((size_t)b * s.HW + r) * s.C2 + (ch - s.C1);
 }
 
-template <class Tag, int GN_TX>
+// 8 channels of row r as floats; PAIR: hi + lo of the stream pair (exact in fp32)
+template <class Tag, bool PAIR>
+__device__ __forceinline__ void gn_load8(const GNSrc& s, int b, int r, int chunk, float (&v)[8]) {
+    typedef typename Tag::T T;
+    const T* ph = gn_chunk_ptr<Tag>(s, b, r, chunk);
+    load8<Tag>(ph, v);
+    if constexpr (PAIR) {
+        const int ch = chunk * 8;
+        const T* base_h = reinterpret_cast<const T*>(ch < s.C1 ? s.x1 : s.x2);
+        const T* base_l = reinterpret_cast<const T*>(ch < s.C1 ? s.x1_lo : s.x2_lo);
+        if (base_l) {
+            float l[8];
+            load8<Tag>(base_l + (ph - base_h), l);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += l[e];
+        }
+    }
+}
+
+template <class Tag, int GN_TX, bool PAIR = false>
 __global__ __launch_bounds__(GN_THREADS) void k_gn_partial(GNSrc s, int nsplit, float* __restrict__ partial) {
     constexpr int GN_TY = GN_THREADS / GN_TX;
     // partial: [B][nsplit][C][2]
@@ -59,7 +79,7 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn_partial(GNSrc s, int nsplit, 
     if (active) {
         for (int r = r0 + threadIdx.y; r < r1; r += GN_TY) {
             float v[8];
-            load8<Tag>(gn_chunk_ptr<Tag>(s, b, r, chunk), v);
+            gn_load8<Tag, PAIR>(s, b, r, chunk, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sum[e] += v[e]; sq[e] += v[e] * v[e]; }
         }
@@ -105,7 +125,7 @@ __global__ void k_gn_finalize(const float* __restrict__ partial, int B, int nspl
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-template <class Tag, int GN_TX>
+template <class Tag, int GN_TX, bool PAIR = false>
 __global__ __launch_bounds__(GN_THREADS) void k_gn_apply(GNSrc s, int nsplit, int G, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int silu, void* __restrict__ out) {
@@ -131,7 +151,7 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn_apply(GNSrc s, int nsplit, in
     T* o = reinterpret_cast<T*>(out);
     for (int r = r0 + threadIdx.y; r < r1; r += GN_TY) {
         float v[8];
-        load8<Tag>(gn_chunk_ptr<Tag>(s, b, r, chunk), v);
+        gn_load8<Tag, PAIR>(s, b, r, chunk, v);
         V8 pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -306,7 +326,7 @@ int gnf_launch(const GNSrc& s, int G, int W8, int maxi, float eps, const float* 
 template <class Tag, int MAXC8>   // MAXC8: chunks per lane
 __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, int ldx, void* __restrict__ y, int ldy, int M,
                                                    int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   float eps) {
+                                                   float eps, const void* __restrict__ x_lo) {
     typedef typename Tag::T T;
     typedef typename Tag::V8 V8;
     const int lane = threadIdx.x & 63;
@@ -321,6 +341,12 @@ __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, i
         const int c = lane + i * 64;
         if (c < nchunk) {
             load8<Tag>(xr + c * 8, v[i]);
+            if (x_lo) {                  // residual_pair mode: the row is hi + lo (wave-uniform branch)
+                float l[8];
+                load8<Tag>(reinterpret_cast<const T*>(x_lo) + (size_t)row * ldx + c * 8, l);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] += l[e];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += v[i][e];
         }
@@ -375,6 +401,26 @@ int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* be
            hipStream_t st) {
     const int C = s.C1 + s.C2;
     int nt = 0, maxi = 0;
+    const bool pair = s.x1_lo || s.x2_lo;        // (the one-launch kernel keeps its slice packed in registers: the pair takes the three-launch path)
+    if (pair) {
+        const int tx = gn_tx(C);
+        const int ncg = (C / 8 + tx - 1) / tx;
+        const int ns = gn_nsplit(s.B, s.HW, C);
+        float* partial = ws;
+        float* stats = ws + (size_t)s.B * ns * C * 2;
+        dim3 grid(ns, ncg, s.B), block(tx, GN_THREADS / tx);
+        if (tx == 16) k_gn_partial<Tag, 16, true><<<grid, block, 0, st>>>(s, ns, partial);
+        else if (tx == 32) k_gn_partial<Tag, 32, true><<<grid, block, 0, st>>>(s, ns, partial);
+        else k_gn_partial<Tag, 64, true><<<grid, block, 0, st>>>(s, ns, partial);
+        MVE_LAUNCH_CHECK();
+        k_gn_finalize<<<mve_cdiv(s.B * G, 4), 256, 0, st>>>(partial, s.B, ns, C, G, s.HW, eps, stats);
+        MVE_LAUNCH_CHECK();
+        if (tx == 16) k_gn_apply<Tag, 16, true><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+        else if (tx == 32) k_gn_apply<Tag, 32, true><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+        else k_gn_apply<Tag, 64, true><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+        MVE_LAUNCH_CHECK();
+        return MVE_OK;
+    }
     if (const int W8 = gnf_plan(s.HW, C, G, &nt, &maxi))
         return nt == 256 ? gnf_launch<Tag, 256>(s, G, W8, maxi, eps, gamma, beta, silu, out, st)
                          : gnf_launch<Tag, 1024>(s, G, W8, maxi, eps, gamma, beta, silu, out, st);
@@ -399,13 +445,13 @@ int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* be
 
 template <class Tag>
 int ln_run(const void* x, int ldx, void* y, int ldy, int M, int C, const float* gamma, const float* beta, float eps,
-           hipStream_t st) {
+           hipStream_t st, const void* x_lo) {
     const int per_lane = (C / 8 + 63) / 64;
     const unsigned grid = mve_cdiv(M, 4);
-    if (per_lane <= 1) k_layernorm<Tag, 1><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps);
-    else if (per_lane == 2) k_layernorm<Tag, 2><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps);
-    else if (per_lane == 3) k_layernorm<Tag, 3><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps);
-    else k_layernorm<Tag, 4><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps);
+    if (per_lane <= 1) k_layernorm<Tag, 1><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
+    else if (per_lane == 2) k_layernorm<Tag, 2><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
+    else if (per_lane == 3) k_layernorm<Tag, 3><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
+    else k_layernorm<Tag, 4><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }
@@ -430,6 +476,12 @@ size_t mve_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
 
 int mve_groupnorm_silu(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int HW, int G, float eps,
                        const float* gamma, const float* beta, int silu, void* out, void* workspace, void* stream) {
+    return mve_groupnorm_silu_pair(dtype, x1, C1, x2, C2, B, HW, G, eps, gamma, beta, silu, out, workspace, nullptr, nullptr, stream);
+}
+
+int mve_groupnorm_silu_pair(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int HW, int G, float eps,
+                            const float* gamma, const float* beta, int silu, void* out, void* workspace, const void* x1_lo, const void* x2_lo,
+                            void* stream) {
     if (B == 0 || HW == 0) return MVE_OK;
     const int C = C1 + C2;
     MVE_CHECK(x1 && out && gamma && beta && workspace && (C2 == 0 || x2), MVE_ERR_ARG, "groupnorm: null pointer");
@@ -437,6 +489,7 @@ int mve_groupnorm_silu(int dtype, const void* x1, int C1, const void* x2, int C2
               "groupnorm: C1=%d C2=%d must be multiples of 8 and C divisible by G=%d", C1, C2, G);
     GNSrc s;
     s.x1 = x1; s.x2 = x2; s.C1 = C1; s.C2 = C2; s.HW = HW; s.B = B;
+    s.x1_lo = x1_lo; s.x2_lo = C2 ? x2_lo : nullptr;
     if (dtype == MVE_F16) return gn_run<F16Tag>(s, G, eps, gamma, beta, silu, out, (float*)workspace, (hipStream_t)stream);
     if (dtype == MVE_BF16) return gn_run<BF16Tag>(s, G, eps, gamma, beta, silu, out, (float*)workspace, (hipStream_t)stream);
     mve_set_error("groupnorm: unsupported dtype %d", dtype);
@@ -445,12 +498,17 @@ int mve_groupnorm_silu(int dtype, const void* x1, int C1, const void* x2, int C2
 
 int mve_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, int M, int C, const float* gamma, const float* beta,
                   float eps, void* stream) {
+    return mve_layernorm_pair(dtype, x, ldx, y, ldy, M, C, gamma, beta, eps, nullptr, stream);
+}
+
+int mve_layernorm_pair(int dtype, const void* x, int ldx, void* y, int ldy, int M, int C, const float* gamma, const float* beta,
+                       float eps, const void* x_lo, void* stream) {
     if (M == 0) return MVE_OK;
     MVE_CHECK(x && y && gamma && beta, MVE_ERR_ARG, "layernorm: null pointer");
     MVE_CHECK(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && ldy % 8 == 0, MVE_ERR_ARG,
               "layernorm: C=%d must be a multiple of 8 and <= 2048", C);
-    if (dtype == MVE_F16) return ln_run<F16Tag>(x, ldx, y, ldy, M, C, gamma, beta, eps, (hipStream_t)stream);
-    if (dtype == MVE_BF16) return ln_run<BF16Tag>(x, ldx, y, ldy, M, C, gamma, beta, eps, (hipStream_t)stream);
+    if (dtype == MVE_F16) return ln_run<F16Tag>(x, ldx, y, ldy, M, C, gamma, beta, eps, (hipStream_t)stream, x_lo);
+    if (dtype == MVE_BF16) return ln_run<BF16Tag>(x, ldx, y, ldy, M, C, gamma, beta, eps, (hipStream_t)stream, x_lo);
     mve_set_error("layernorm: unsupported dtype %d", dtype);
     return MVE_ERR_ARG;
 }

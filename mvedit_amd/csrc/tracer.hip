@@ -1,9 +1,9 @@
 // Kernels of the TRACER-B7 foreground segmentor (lib/models/segmentors/tracer_b7.py:16-73 over lib/models/architecture/tracerb7/: EfficientNet-B7
 // encoder + TRACER decoder), the pieces that the GEMM / 3x3-conv kernels do not cover.  Activations are NHWC 16-bit ([B, H, W, C] contiguous, the
 // layout every 1x1 convolution consumes as a plain [M, C] GEMM operand); single-channel decoder maps are fp32.  BatchNorm is folded into the
-// convolution weights and a per-channel bias by the host mirror (mvedit_amd/segmentor.py) when the state dict is loaded.  All of these are
-// HBM- / L2-bound gathers with fp32 arithmetic; nothing here is GEMM-shaped enough to go to the matrix cores except what already does
-// (expand / project 1x1 convolutions -> mve_gemm, dense 3x3 convolutions of the decoder -> mve_conv3x3).
+// convolution weights and a per-channel bias by the host mirror (mvedit_amd/segmentor.py) when the state dict is loaded.  The 1x1 / 1xk / kx1 /
+// dilated 3x3 layers run on the matrix cores here (mve_seg_mconv: v_mfma_f32_16x16x32 with operands loaded straight into the instruction's
+// layout, further down); dense 3x3 convolutions of the decoder go to mve_conv3x3; the rest are HBM- / L2-bound gathers with fp32 arithmetic:
 //   mve_seg_conv2d        depthwise (groups = C) or small dense convolution: any kernel size / stride / dilation / explicit top-left padding,
 //                         bias, activation, optional elementwise multiply / add of a second tensor, output into a channel slice of a wider tensor
 //   mve_seg_act           in-place activation of a GEMM / conv3x3 output (swish, SELU, ReLU, sigmoid)

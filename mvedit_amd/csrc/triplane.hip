@@ -458,13 +458,14 @@ extern "C" int mve_triplane_backward(const MveTriplaneDesc* d, const float* d_gr
     TriBwd b;
     b.g_sigma = d_grad_sigmas; b.g_rgb = colour ? d_grad_rgbs : nullptr;
     b.g_code = g->d_code; b.g_table = nl ? g->d_table : nullptr;
+    MVE_CHECK(((uintptr_t)d_workspace & 15) == 0, MVE_ERR_ARG, "triplane_backward: the workspace must be 16-byte aligned");
+    b.ws_do = ws; ws += N * 4;            // first: it is written as f32x4 (16-byte stores) -- behind N * (3C + ...) floats it was only 8-byte aligned for odd N, C = 6
     b.ws_feat = ws; ws += N * F3;
     b.ws_enc = ws; ws += N * 2 * nl;
     b.ws_dbase = ws; ws += N * H;
     b.ws_hid = ws; ws += N * (H + 16);
     b.ws_da2 = ws; ws += N * H2;
     b.ws_act2 = ws; ws += N * H2;
-    b.ws_do = ws; ws += N * 4;
     ws = (float*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
     float* partial = ws;
     if (!colour) p.dirs = nullptr;

@@ -518,6 +518,15 @@ int mve_unet_set_attention(void* handle, int ip_tokens, float ip_scale, int ref_
     return MVE_OK;
 }
 
+int mve_unet_set_residual_mode(void* handle, int pair) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "unet_set_residual_mode: null handle");
+    Unet* u = (Unet*)handle;
+    MVE_CHECK(!u->cfg.vae && !u->cfg.sr && !u->cfg.lpips, MVE_ERR_ARG, "unet_set_residual_mode: a UNet / ControlNet handle is needed");
+    const int old = u->ao.residual_pair;
+    if (pair >= 0) u->ao.residual_pair = pair ? 1 : 0;     // part of the plan key: plans of either mode stay cached side by side
+    return old;
+}
+
 size_t mve_unet_ref_store_bytes(void* handle, int B, int ref_H, int ref_W, int ref_skip) {
     if (!handle || B <= ref_skip) return 0;
     const Config& c = ((Unet*)handle)->cfg;

@@ -3,7 +3,6 @@ import torch
 
 from . import _lib
 
-_WARNED_TEXC_DETACH = False
 
 
 def _inference_only(name, *tensors):
@@ -333,11 +332,16 @@ class MeshRenderer:
     level stack and a trilinear fetch; 'linear' = plain bilinear).  forward is differentiable w.r.t. the texture / vertex colours and,
     through rasterize / interpolate / antialias, w.r.t. the geometry."""
 
-    def __init__(self, near=0.1, far=10, ssaa=1, texture_filter='linear-mipmap-linear'):
+    def __init__(self, near=0.1, far=10, ssaa=1, texture_filter='linear-mipmap-linear', allow_detached_uv=False, min_render_bs=32):
         assert texture_filter in ('linear', 'linear-mipmap-linear')
         # `render_bs` of get_cam_weights_uv / bake_multiview is the reference's memory knob for a 24 GB card; views are independent and the atlas
-        # accumulates them in view order whatever the chunking (bitwise the same result), so chunks of at least this many views are walked
-        self.min_render_bs = 32
+        # accumulates them in view order whatever the chunking (bitwise the same result), so by default chunks of at least 32 views are walked
+        # (up to 4x the workspace the caller's render_bs asks for: min_render_bs=1 honours the caller's value exactly)
+        self.min_render_bs = int(min_render_bs)
+        # a textured mesh with trainable vertices: False (default) = fail loudly (d albedo / d uv is not built), True = treat the fetch position
+        # as a constant and warn once per renderer
+        self.allow_detached_uv = bool(allow_detached_uv)
+        self._warned_uv = False
         self.near, self.far, self.ssaa, self.texture_filter = near, far, ssaa, texture_filter
 
     def project(self, v, poses, intrinsics, h, w):
@@ -395,13 +399,18 @@ class MeshRenderer:
                 # trainable vertices under a textured mesh: the reference propagates d albedo / d uv through dr.texture; no such kernel is
                 # built here (the shipped pipelines render in_mesh.detach()).  The fetch position is treated as a constant -- the gradient
                 # still reaches the vertices through rasterize / interpolate / antialias and the texture through the fetch -- and says so
-                # once; the public texture() op keeps refusing.
-                global _WARNED_TEXC_DETACH
-                if not _WARNED_TEXC_DETACH:
+                # once per renderer; the public texture() op keeps refusing.  OPT-IN (allow_detached_uv=True): by default the call fails loudly, as
+                # an incomplete gradient must not pass for the reference's.
+                if not self.allow_detached_uv:
+                    raise NotImplementedError(
+                        'MeshRenderer.forward: a textured mesh with trainable vertices needs d albedo / d uv through the texture fetch, which is not '
+                        'built; render mesh.detach() (as the shipped pipelines do) or construct MeshRenderer(allow_detached_uv=True) to treat the '
+                        'fetch position as a constant (vertex gradients through the albedo term are then missing)')
+                if not self._warned_uv:
                     import warnings
                     warnings.warn('MeshRenderer.forward: texture coordinates are detached (no gradient w.r.t. uv through the texture fetch); '
                                   'vertex gradients through the albedo term are missing', stacklevel=2)
-                    _WARNED_TEXC_DETACH = True
+                    self._warned_uv = True
                 texc = texc.detach()
                 texc_da = texc_da.detach() if texc_da is not None else None
             albedo = texture(mesh.albedo[None, ..., :3], texc, rast, uv_da=texc_da, filter_mode=self.texture_filter)   # background 0 (:264)

@@ -38,9 +38,24 @@ def _splitk_ws(M, N, K, device, rows_per_image):
     return (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes) if nbytes else (None, 0)
 
 
-def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, out=None, out_scale=1.0, rows_per_image=0):
-    """a [M,K], w [N,K] -> [M,N] (or [M,N/2] with GEGLU).  bias/rowvec fp32."""
-    _chk16(a, w, residual)
+def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, out=None, out_scale=1.0, rows_per_image=0, residual_lo=None,
+         pair_out=False):
+    """a [M,K], w [N,K] -> [M,N] (or [M,N/2] with GEGLU).  bias/rowvec fp32.
+    residual_lo / pair_out: the residual-pair entry point (mve_gemm_pair): the residual is residual + residual_lo, and with pair_out the
+    result comes back as (hi, lo) = (round16(v), round16(v - hi))."""
+    _chk16(a, w, residual, residual_lo)
+    if residual_lo is not None or pair_out:
+        M, K = a.shape
+        N = w.shape[0]
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+        out_lo = torch.empty_like(out) if pair_out else None
+        ws, ws_bytes = _splitk_ws(M, N, K, a.device, rows_per_image)
+        with torch.cuda.device(a.device):
+            _lib.call('mve_gemm_pair', dt(a), _lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(out), out.stride(0),
+                      M, N, K, _lib.ptr(bias), _lib.ptr(rowvec), rowvec.stride(0) if rowvec is not None else 0,
+                      int(rows_per_vec), _lib.ptr(residual), residual.stride(0) if residual is not None else 0, int(flags), float(out_scale),
+                      _lib.ptr(ws), ws_bytes, int(rows_per_image), _lib.ptr(residual_lo), _lib.ptr(out_lo), _s(a))
+        return (out, out_lo) if pair_out else out
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and (rowvec is None or rowvec.stride(-1) == 1)

@@ -62,12 +62,18 @@ class PadHW:
 
 
 class TracerUniversalB7Engine:
-    def __init__(self, input_image_size=640, batch_size=8, torch_dtype='bfloat16', erosion=1, device='cuda', min_chunk=32):
+    def __init__(self, input_image_size=640, batch_size=8, torch_dtype='bfloat16', erosion=1, device='cuda', min_chunk=32, pretrained=None,
+                 freeze=True):
+        # pretrained / freeze: the reference's constructor arguments (tracer_b7.py:16-30; a config built for the reference constructs this class
+        # too).  `pretrained` is a state-dict path the caller may load and hand to load_state_dict (no download here); the engine is inference-only,
+        # i.e. always frozen.
+        self.pretrained, self.freeze = pretrained, freeze
         self.input_image_size = tuple(input_image_size[:2]) if isinstance(input_image_size, (list, tuple)) else (input_image_size, input_image_size)
         assert self.input_image_size[0] % 32 == 0 and self.input_image_size[1] % 32 == 0, 'input_image_size must be a multiple of 32'
         self.batch_size = batch_size
-        # the reference's batch_size is a memory knob of a 24 GB card; an image's result does not depend on its chunk (bitwise, tested), so the
-        # engine walks chunks of at least `min_chunk` views: the deep 20 x 20 layers are latency-bound at 8 views and 4 x cheaper per view at 32
+        # the reference's batch_size is a memory knob of a 24 GB card; an image's result does not depend on its chunk (bitwise, tested), so by
+        # default the engine walks chunks of at least 32 views: the deep 20 x 20 layers are latency-bound at 8 views and 4 x cheaper per view
+        # at 32 -- for up to 4 x the activation memory batch_size asks for.  min_chunk=1 honours the caller's batch_size exactly.
         self.chunk = max(int(batch_size), int(min_chunk))
         self.dtype = getattr(torch, torch_dtype) if isinstance(torch_dtype, str) else torch_dtype
         assert self.dtype in (torch.float16, torch.bfloat16)

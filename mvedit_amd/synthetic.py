@@ -327,3 +327,38 @@ def make_tracer_state_dict(seed=0, dtype=torch.float32):
             t = torch.randn(shape, generator=g) * math.sqrt(1.7 / (shape[1] * shape[2] * shape[3]))
         out[name] = t.to(dtype)
     return out
+
+
+# lpips.LPIPS(net='vgg') as lib/models/losses/lpips_loss.py:8-42 builds it: torchvision VGG16 `features` convolutions in lpips' five slices, the
+# input scaling layer and one non-negative 1x1 `lin` weight per slice
+_VGG_IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+_VGG_CH = ((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512))
+_VGG_SLICE = (1, 1, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5)
+
+
+def lpips_param_shapes():
+    s = {'scaling_layer.shift': (1, 3, 1, 1), 'scaling_layer.scale': (1, 3, 1, 1)}
+    for i, (ci, co) in enumerate(_VGG_CH):
+        s[f'net.slice{_VGG_SLICE[i]}.{_VGG_IDX[i]}.weight'] = (co, ci, 3, 3)
+        s[f'net.slice{_VGG_SLICE[i]}.{_VGG_IDX[i]}.bias'] = (co,)
+    for k, c in enumerate((64, 128, 256, 512, 512)):
+        s[f'lin{k}.model.1.weight'] = (1, c, 1, 1)
+    return s
+
+
+def make_lpips_state_dict(seed=0, dtype=torch.float32):
+    """Seeded stand-in for the lpips / torchvision VGG16 checkpoints (not reachable offline): He-initialised convolutions (activations stay
+    O(1) through 13 ReLU layers), non-negative `lin` weights as in the trained model, lpips' published input shift / scale."""
+    g = torch.Generator().manual_seed(seed)
+    out = {'scaling_layer.shift': torch.tensor((-.030, -.088, -.188)).view(1, 3, 1, 1), 'scaling_layer.scale': torch.tensor((.458, .448, .450)).view(1, 3, 1, 1)}
+    for name, shape in lpips_param_shapes().items():
+        if name in out:
+            continue
+        if name.endswith('.bias'):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif name.startswith('lin'):
+            t = torch.rand(shape, generator=g) * 2.0 / shape[1]
+        else:
+            t = torch.randn(shape, generator=g) * (2.0 / (shape[1] * 9)) ** 0.5
+        out[name] = t.to(dtype)
+    return out

@@ -81,8 +81,17 @@ class TriPlaneDecoder:
         return self
 
     def _pack(self, tensors=None):
-        """kernel-side copies of the parameters: weight matrices transposed to [in][out] (one input's fan-out = one contiguous scalar load)"""
+        """kernel-side copies of the parameters: weight matrices transposed to [in][out] (one input's fan-out = one contiguous scalar load).
+        Without `tensors` the copies are rebuilt only when a parameter changed (torch's version counter: optimiser steps, in-place edits and
+        load_state_dict all bump it or replace the tensor) -- not on every call of the NeRF sampling hot path."""
         src = self.params if tensors is None else tensors
+        if tensors is None:
+            sig = tuple((n, id(t), t._version) for n, t in src.items())
+            if getattr(self, '_packed_sig', None) == sig:
+                return
+            self._packed_sig = sig
+        else:
+            self._packed_sig = None
         for name, t in src.items():
             if name in self._NAMES:
                 key, transpose = self._NAMES[name]
@@ -110,7 +119,9 @@ class TriPlaneDecoder:
         assert len(xyzs) == 1 and code.shape[0] == 1, 'one scene per call (as every MVEdit pipeline)'
         xyz = xyzs[0]
         d = None if (density_only or dirs is None) else dirs[0]
-        for t in (xyz, d, code, *self.params.values()):
+        # forward only: PARAMETERS that are marked trainable (nerf_optim's optimiser holds them) are read as constants; an input that requires
+        # grad is refused -- its gradient would silently be missing
+        for t in (xyz, d, code):
             if t is not None and torch.is_grad_enabled() and t.requires_grad:
                 raise NotImplementedError('tri-plane decoders: point_decode is the forward only -- use point_decode_autograd for gradients '
                                           '(or call under torch.no_grad())')

@@ -10,6 +10,7 @@ Run from the repo root (needs /root/reference):  python tests/golden/make_attn_p
 import ast
 import os
 import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 from typing import Any
 
 import numpy as np

@@ -10,6 +10,7 @@ import ast
 import importlib.util
 import os
 import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 import types
 
 import numpy as np

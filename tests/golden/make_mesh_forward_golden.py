@@ -6,6 +6,7 @@ bit-identical input.  Run from the repo root (needs /root/reference):  python te
 import importlib.util
 import os
 import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 import types
 
 import numpy as np

@@ -8,6 +8,7 @@ Run from the repo root (needs /root/reference):  python tests/golden/make_mesh_l
 import ast
 import os
 import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 import types
 
 import numpy as np

@@ -5,6 +5,8 @@ autograd for the gradients.
 The functions call `.cuda()` on index tensors; for this run `torch.Tensor.cuda` is the identity.  Meshes: a closed subdivided octahedron
 (every edge has two faces) and an open grid patch (boundary edges keep the reference's default face 0 on the missing side), both with
 perturbed vertices.  Run from the repo root (needs /root/reference):  python tests/golden/make_mesh_reg_golden.py"""
+import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 import ast
 import os
 

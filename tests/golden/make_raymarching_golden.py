@@ -7,6 +7,7 @@ Run from the repo root:  python tests/golden/make_raymarching_golden.py
 """
 import os
 import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 
 import numpy as np
 

@@ -12,6 +12,7 @@ import importlib.util
 import math
 import os
 import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 import textwrap
 import types
 

@@ -12,6 +12,8 @@ container (they cannot travel to the GPU box, the vectors can):
 Nothing is copied into the repo; the reference sources are read where they lie under /root/reference.
 Run from the repo root (needs /root/reference):  python tests/golden/make_reference_py_golden.py
 """
+import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 import ast
 import importlib.util
 import math

@@ -2,6 +2,8 @@
 `make_nerf_shading_fun`, `make_nerf_albedo_shading_fun` (lib/pipelines/mvedit_3d_pipeline.py:410-450, cut out of the class with `ast`) -- over
 the reference's Tonemapping class (float64) and a stand-in decoder, with torch autograd for the gradients w.r.t. albedo / decoder colour and
 world_normal.  Run from the repo root (needs /root/reference):  python tests/golden/make_shading_fun_golden.py"""
+import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 import ast
 import importlib.util
 import os

@@ -5,6 +5,7 @@ Run from the repo root (needs /root/reference):  python tests/golden/make_tonema
 import importlib.util
 import os
 import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 
 import numpy as np
 import torch

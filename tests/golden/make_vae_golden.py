@@ -3,6 +3,7 @@ to the restatement is noticed.  (diffusers is absent: this pins the oracle again
 Run from the repo root:  python tests/golden/make_vae_golden.py"""
 import os
 import sys
+sys.dont_write_bytecode = True      # never write __pycache__ into the read-only reference tree
 
 import numpy as np
 import torch

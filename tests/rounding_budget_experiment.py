@@ -50,7 +50,7 @@ def run(sd, cfg, x, t, ctx, q, engine=True, **off):
         h = S.norm(F.silu(F.group_norm(h, g, c.w(p + '.norm2.weight'), c.w(p + '.norm2.bias'), eps)))
         h = F.conv2d(h, c.w(p + '.conv2.weight'), c.w(p + '.conv2.bias'), padding=1)
         if (p + '.conv_shortcut.weight') in sd:
-            sc = F.conv2d(xin, c.w(p + '.conv_shortcut.weight'), c.w(p + '.conv_shortcut.bias'))                  # MFMA operand: always the 16-bit half
+            sc = F.conv2d(q(xs), c.w(p + '.conv_shortcut.weight'), c.w(p + '.conv_shortcut.bias'))                # MFMA operand: always the 16-bit half
             return S.res(h + sc) if engine else S.res(S.mm(sc) + S.mm(h))
         return S.res(xs + h) if engine else S.res(xs + S.mm(h))
 

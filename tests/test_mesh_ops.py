@@ -305,10 +305,11 @@ def test_texture_fitting_through_mesh_renderer(lib, filt):
 @pytest.mark.gpu
 @pytest.mark.parametrize('filt', ['linear', 'linear-mipmap-linear'])
 def test_textured_mesh_with_trainable_vertices_renders_and_backpropagates(lib, filt):
-    """A textured mesh (vt + albedo) whose VERTICES require grad (base_mesh_renderer.py:240-264 with a trainable in_mesh): forward must
-    render (the texture coordinates are treated as constants of the fetch, with one warning), the texture and the vertices both receive
-    finite gradients -- the vertices through rasterise / interpolate / antialias -- and the public texture() op still refuses a uv that
-    requires grad."""
+    """A textured mesh (vt + albedo) whose VERTICES require grad (base_mesh_renderer.py:240-264 with a trainable in_mesh): by default forward
+    refuses (d albedo / d uv through the texture fetch is not built: an incomplete gradient must not pass silently); with
+    allow_detached_uv=True it renders (the texture coordinates are treated as constants of the fetch, one warning per renderer), the texture
+    and the vertices both receive finite gradients -- the vertices through rasterise / interpolate / antialias -- and the public texture() op
+    still refuses a uv that requires grad."""
     import warnings
     from mvedit_amd import mesh_ops
     from mvedit_amd.mesh_ops import MeshRenderer, Mesh
@@ -319,15 +320,17 @@ def test_textured_mesh_with_trainable_vertices_renders_and_backpropagates(lib, f
     S, nv = 64, 4
     poses, intr = _clip_positions(v, nv, S)
     t = lambda a: torch.from_numpy(a).cuda()
-    mr = MeshRenderer(near=0.01, far=100, texture_filter=filt)
     verts = t(v).clone().requires_grad_(True)
     tex = torch.rand(64, 64, 3, generator=torch.Generator().manual_seed(2)).cuda().requires_grad_(True)
     mesh = Mesh(verts, t(f), t(vt), t(ft), vn=t(vn), fn=t(f), albedo=tex)
-    mesh_ops._WARNED_TEXC_DETACH = False
+    with pytest.raises(NotImplementedError):                                # the default: loud
+        MeshRenderer(near=0.01, far=100, texture_filter=filt)([mesh], t(poses)[None], t(intr)[None], S, S)
+    mr = MeshRenderer(near=0.01, far=100, texture_filter=filt, allow_detached_uv=True)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         out = mr([mesh], t(poses)[None], t(intr)[None], S, S)['rgba']
-    assert any('texture coordinates are detached' in str(x.message) for x in w)
+        mr([mesh], t(poses)[None], t(intr)[None], S, S)
+    assert sum('texture coordinates are detached' in str(x.message) for x in w) == 1      # once per renderer
     loss = (out[..., :3] ** 2).mean() + out[..., 3].mean()
     loss.backward()
     assert torch.isfinite(tex.grad).all() and tex.grad.abs().sum() > 0
