@@ -318,6 +318,9 @@ def secondary(dev):
     views = torch.rand(VIEWS, 3, 8 * LATENT, 8 * LATENT, device=dev)
     t = timed(lambda: seg(views), it=2)
     out['tracer_b7_masks'] = dict(ms=round(t * 1e3, 2), views=VIEWS, ms_per_view=round(t * 1e3 / VIEWS, 3), input=640)
+    for k, v in out.items():                      # the MFMA-bound secondary networks against the same dense fp16 peak as the headline
+        if isinstance(v, dict) and 'tflops_per_s' in v:
+            v['frac_of_mfma_peak'] = round(v['tflops_per_s'] / PEAK_TFLOPS_F16, 4)
     return out
 
 
@@ -748,14 +751,27 @@ def main():
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / n * 1e3
-        scene = torch.empty(56 << 20, dtype=torch.uint8, device=dev)
-        ag = timed(lambda: dist.all_gather_into_tensor(gathered, maps_local))
-        bc = timed(lambda: dist.broadcast(scene, src=0))
-        tc = torch.tensor([ag, bc], device=dev, dtype=torch.float64)
+        from mvedit_amd import parallel as PL
+        force = world == 1
+        # the scene as parallel.sync_scene sees it: hash table (2^19 x 12 levels x 2 fp32 = 48 MiB), MLP weights, 128^3 density grid + bitfield
+        scene = [torch.zeros(12 << 19, 2, device=dev), torch.zeros(64, 24, device=dev), torch.zeros(4, 64, device=dev),
+                 torch.zeros(128 ** 3, device=dev), torch.zeros(128 ** 3 // 8, dtype=torch.uint8, device=dev)]
+        scene_bytes = sum(t.numel() * t.element_size() for t in scene)
+        ag = timed(lambda: PL.all_gather_views(maps_local, V, force=force))
+        # ragged shards: V = 9 views after camera pruning (mvedit_3d_pipeline.py:1180-1215) do not divide by the world size -> pad + trim path
+        lo9, hi9 = partition_views(9, world, rank)
+        maps9 = torch.zeros(hi9 - lo9, 8, 8 * LATENT, 8 * LATENT, device=dev, dtype=torch.float16)
+        g9 = PL.all_gather_views(maps9, 9, force=force)
+        assert g9.shape[0] == 9
+        ag9 = timed(lambda: PL.all_gather_views(maps9, 9, force=force))
+        bc = timed(lambda: PL.sync_scene(scene, src=0, force=force))
+        tc = torch.tensor([ag, bc, ag9], device=dev, dtype=torch.float64)
         dist.all_reduce(tc, op=dist.ReduceOp.MAX)
         collectives = dict(all_gather_ms=round(float(tc[0]), 3), all_gather_bytes=int(gathered.numel() * gathered.element_size()),
-                           sync_scene_broadcast_ms=round(float(tc[1]), 3), sync_scene_bytes=56 << 20,
-                           note='max over ranks, 10 back-to-back calls each, outside the timed steps (the all-gather is also inside them)')
+                           all_gather_ragged_9_views_ms=round(float(tc[2]), 3),
+                           sync_scene_broadcast_ms=round(float(tc[1]), 3), sync_scene_bytes=int(scene_bytes),
+                           note='mvedit_amd.parallel.all_gather_views (32 views; 9 views = ragged shards after camera pruning) and sync_scene; max over '
+                                'ranks, 10 back-to-back calls each, outside the timed steps (the 32-view all-gather is also inside them)')
 
     # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------------------------
     roof = None
@@ -813,6 +829,11 @@ def main():
             line['collectives'] = collectives
         if sampler is not None and sampler.summary() is not None:
             line['power'] = sampler.summary()
+            # energy per unit of algorithmic work over the sampled (untimed) steps: what a kernel change has to lower when the package sits at its
+            # power cap (rocm-smi --showmaxpower on this pool: 1400 W, profiles/r04_smi_maxpower.log)
+            line['power']['joule_per_step'] = round(line['power']['avg_w'] * ms_per_step * 1e-3, 2)
+            line['power']['joule_per_tflop'] = round(line['power']['avg_w'] * ms_per_step * 1e-3 / (total_flops / 1e12), 3)
+            line['power']['cap_w'] = 1400
         if world == 1 and roof is not None:
             try:
                 clk = clock_probe(dev)

@@ -432,6 +432,9 @@ long long tile256_blocks(int M, int N, int splitk) {
 }
 
 template <class Tag, int MODE>
+int launch_gemm_split(const GemmParams& p, hipStream_t s);
+
+template <class Tag, int MODE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     if (tile256_bn(p.N, p.splitk) == 0) return launch_v<Tag, MODE>(p, s);
     // enough 256 x 320 tiles to fill the chip WITHOUT cutting K: one block per tile walks the slices one after the other and
@@ -444,6 +447,26 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
         const int rc = launch_tile256(Tag::dtype, MODE, &q, s);
         if (rc != 1) return rc;                            // 1: no 256-row loop takes it in this form (e.g. strict slices + residual pair): split K for real below
     }
+    // The slice rule asks for more slices than this launch needs to fill the chip (64 images at the 8 x 8 level: 64 tiles x 8 slices): cut K into
+    // just enough slices for one block per CU -- every slice fewer is 2 x M x N x 4 bytes of fp32 partials less through HBM and a longer K loop
+    // per prologue / epilogue.  Like the single chain above this changes the fp32 summation order with the batch, not the value; the strict mode
+    // keeps the rule's slice count.
+    GemmParams pfew;
+    const GemmParams* pp = &p;
+    if (!gemm_strict_splitk() && gemm_big_min_blocks() > 0 && p.splitk > 2 && p.N % 320 == 0) {
+        const long long t1 = tile256_blocks(p.M, p.N, 1);
+        if (t1 > 0 && t1 * p.splitk >= 2 * gemm_big_min_blocks()) {
+            int few = (int)((gemm_big_min_blocks() + t1 - 1) / t1);
+            few = few < 2 ? 2 : few;
+            if (few < p.splitk) { pfew = p; pfew.splitk = few; pp = &pfew; }
+        }
+    }
+    if (pp != &p) return launch_gemm_split<Tag, MODE>(*pp, s);
+    return launch_gemm_split<Tag, MODE>(p, s);
+}
+
+template <class Tag, int MODE>
+int launch_gemm_split(const GemmParams& p, hipStream_t s) {
     // small batches: 256 x 320 tiles would leave CUs without a block, 256 x 160 tiles (ping-pong loop only) still cover them
     const bool narrow = gemm_big_min_blocks() > 0 && gemm_pp_on() && p.splitk <= 1 && p.N % 320 == 0 && p.M >= 64 &&
                         tile256_blocks(p.M, p.N, 1) < gemm_big_min_blocks() && 2 * tile256_blocks(p.M, p.N, 1) >= gemm_big_min_blocks();

@@ -323,61 +323,80 @@ int gnf_launch(const GNSrc& s, int G, int W8, int maxi, float eps, const float* 
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm over the last axis (C <= 2048, C % 8 == 0): one wave per row, two passes over registers.
 // ---------------------------------------------------------------------------------------------------
-template <class Tag, int MAXC8>   // MAXC8: chunks per lane
+// R rows per wave: a 320-channel row is 640 bytes -- 40 of the 64 lanes load 16 bytes each -- and with one row per wave a CU has ~20 KiB of loads
+// in flight, a quarter of what 5 TB/s needs at HBM latency (round 3 measured 2.9 TB/s on the 64 x 64 level).  R = 4 (C <= 512) / 2 (C <= 1024)
+// rows are requested before the first one is reduced.  A row's arithmetic (lanes, order, shuffle tree) does not change: identical bits.
+template <class Tag, int MAXC8, int R>   // MAXC8: chunks per lane
 __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, int ldx, void* __restrict__ y, int ldy, int M,
                                                    int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float eps, const void* __restrict__ x_lo) {
     typedef typename Tag::T T;
     typedef typename Tag::V8 V8;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const T* xr = reinterpret_cast<const T*>(x) + (size_t)row * ldx;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= M) return;
     const int nchunk = C / 8;
-    float v[MAXC8][8];
-    float s = 0.f;
+    V8 raw[R][MAXC8], rawl[R][MAXC8];
 #pragma unroll
-    for (int i = 0; i < MAXC8; ++i) {
-        const int c = lane + i * 64;
-        if (c < nchunk) {
-            load8<Tag>(xr + c * 8, v[i]);
-            if (x_lo) {                  // residual_pair mode: the row is hi + lo (wave-uniform branch)
-                float l[8];
-                load8<Tag>(reinterpret_cast<const T*>(x_lo) + (size_t)row * ldx + c * 8, l);
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r < M ? row0 + r : M - 1;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[i][e] += l[e];
+        for (int i = 0; i < MAXC8; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
+                raw[r][i] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(x) + (size_t)row * ldx + c * 8);
+                if (x_lo) rawl[r][i] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(x_lo) + (size_t)row * ldx + c * 8);   // residual_pair mode (uniform branch)
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[i][e];
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    const float mean = s / (float)C;
-    float q = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        float v[MAXC8][8];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC8; ++i) {
-        const int c = lane + i * 64;
-        if (c < nchunk) {
+        for (int i = 0; i < MAXC8; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
-        }
-    }
+                for (int e = 0; e < 8; ++e) v[i][e] = Tag::to_f32(raw[r][i][e]);
+                if (x_lo) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
-    const float rstd = rsqrtf(q / (float)C + eps);
-    T* yr = reinterpret_cast<T*>(y) + (size_t)row * ldy;
+                    for (int e = 0; e < 8; ++e) v[i][e] += Tag::to_f32(rawl[r][i][e]);
+                }
 #pragma unroll
-    for (int i = 0; i < MAXC8; ++i) {
-        const int c = lane + i * 64;
-        if (c < nchunk) {
-            V8 pk;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ch = c * 8 + e;
-                pk[e] = Tag::from_f32((v[i][e] - mean) * rstd * gamma[ch] + beta[ch]);
+                for (int e = 0; e < 8; ++e) s += v[i][e];
             }
-            *reinterpret_cast<V8*>(yr + c * 8) = pk;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC8; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float rstd = rsqrtf(q / (float)C + eps);
+        T* yr = reinterpret_cast<T*>(y) + (size_t)row * ldy;
+#pragma unroll
+        for (int i = 0; i < MAXC8; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
+                V8 pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = c * 8 + e;
+                    pk[e] = Tag::from_f32((v[i][e] - mean) * rstd * gamma[ch] + beta[ch]);
+                }
+                *reinterpret_cast<V8*>(yr + c * 8) = pk;
+            }
         }
     }
 }
@@ -447,11 +466,10 @@ template <class Tag>
 int ln_run(const void* x, int ldx, void* y, int ldy, int M, int C, const float* gamma, const float* beta, float eps,
            hipStream_t st, const void* x_lo) {
     const int per_lane = (C / 8 + 63) / 64;
-    const unsigned grid = mve_cdiv(M, 4);
-    if (per_lane <= 1) k_layernorm<Tag, 1><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
-    else if (per_lane == 2) k_layernorm<Tag, 2><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
-    else if (per_lane == 3) k_layernorm<Tag, 3><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
-    else k_layernorm<Tag, 4><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
+    if (per_lane <= 1) k_layernorm<Tag, 1, 4><<<mve_cdiv(M, 16), 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
+    else if (per_lane == 2) k_layernorm<Tag, 2, 2><<<mve_cdiv(M, 8), 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
+    else if (per_lane == 3) k_layernorm<Tag, 3, 1><<<mve_cdiv(M, 4), 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
+    else k_layernorm<Tag, 4, 1><<<mve_cdiv(M, 4), 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
     MVE_LAUNCH_CHECK();
     return MVE_OK;
 }

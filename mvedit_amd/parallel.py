@@ -30,14 +30,15 @@ def partition_sizes(num_views, world_size):
             for r in range(world_size)]
 
 
-def all_gather_views(local, num_views, group=None):
+def all_gather_views(local, num_views, group=None, force=False):
     """local: [v_local, ...] tensor of this rank's views -> [num_views, ...] on every rank.
+    force: issue the collective even in a one-rank group (bench.py's RCCL smoke on a 1-GPU box).
 
     One collective.  Equal shards use all_gather_into_tensor (a single RCCL call writing straight into the
     output); ragged shards (V not divisible by the world size, e.g. after camera pruning 32 -> 9) pad to
     the largest shard and trim.
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         assert local.shape[0] == num_views
         return local
     world = dist.get_world_size(group)
@@ -68,7 +69,7 @@ def repartition(per_view, old_num, keep_ids, group=None):
     return kept[lo:hi].contiguous()
 
 
-def sync_scene(tensors, src=0, group=None):
+def sync_scene(tensors, src=0, group=None, force=False):
     """Re-align the replicated scene (hash table, MLP weights, density grid / bitfield, or SDF / deformation / texture) with rank `src`.
 
     The 3D update is replicated, not sharded, and several of its backward kernels scatter with float atomics (hash-table gradient, texture
@@ -77,7 +78,7 @@ def sync_scene(tensors, src=0, group=None):
     broadcast per outer step of the whole scene (about 52 MiB for the hash grid + 4 MiB of density grid: well under a millisecond over
     xGMI) removes the drift at its source.  ONE collective per dtype: the tensors are coalesced into a flat buffer and copied back in place.
     """
-    if not _dist_on() or dist.get_world_size(group) == 1:
+    if not _dist_on() or (dist.get_world_size(group) == 1 and not force):      # force: bench.py's one-rank RCCL smoke
         return tensors
     # `src` is a rank of `group`; dist.broadcast wants the global rank
     src_global = dist.get_global_rank(group, src) if group is not None else src

@@ -1,0 +1,95 @@
+"""Where one nerf_optim / mesh_optim iteration spends its time (the replicated 3D update of an outer step: 96 iterations per denoise step,
+lib/pipelines/mvedit_3d_pipeline.py:507-633, :716-847): bench.py's outer_step() iteration split into forward / loss / LPIPS / backward /
+optimiser with a device synchronisation after each part, and the un-split iteration next to it (the difference is host overhead hidden by the
+asynchronous queue).  python tools/optim_profile.py [iterations]"""
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from scene import sphere_density_grid  # noqa: E402
+from mvedit_amd import nerf, raymarching as rm, synthetic as SY  # noqa: E402
+from mvedit_amd.lpips import LPIPSEngine  # noqa: E402
+from mvedit_amd.recon_loss import nerf_optim_loss  # noqa: E402
+from mvedit_amd.tonemapping import Tonemapping  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(11)
+meta, rows = nerf.grid_meta(12, 16, 320)
+table = (torch.rand(rows, 2, generator=g) * 2 - 1) * 0.1
+w1 = (torch.rand(64, 24, generator=g) * 2 - 1) * math.sqrt(6 / (64 + 24))
+w2 = (torch.rand(4, 64, generator=g) * 2 - 1) * math.sqrt(6 / (4 + 64))
+dec = nerf.INGPDecoderParams(table, w1, torch.zeros(64), w2, torch.tensor([2.0, 0.0, 0.0, 0.0]), 12, 320, device=dev)
+bits = rm.packbits(torch.from_numpy(sphere_density_grid(128, radius=0.5)).to(dev), 0.5)
+ps, P, S = 128, 1, 512
+fl = S / (2 * math.tan(math.radians(15)))
+intr = torch.tensor([[fl, fl, S / 2, S / 2]], device=dev)
+c = torch.tensor([3.7 * math.cos(0.2), 0.0, 3.7 * math.sin(0.2)])
+fwd = -c / c.norm()
+right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0])); right = right / right.norm()
+down = torch.linalg.cross(fwd, right)
+pose = torch.zeros(1, 3, 4); pose[0, :, 0], pose[0, :, 1], pose[0, :, 2], pose[0, :, 3] = right, down, fwd, c
+pose = pose.to(dev)
+ro, rd, _ = nerf.camera_rays(intr * (ps / S), pose, ps, ps)
+ys, xs = torch.meshgrid(torch.arange(ps, dtype=torch.float32), torch.arange(ps, dtype=torch.float32), indexing='ij')
+flp = ps / (2 * math.tan(math.radians(15)))
+dirs = torch.stack([(xs + 0.5 - ps / 2) / flp, (ys + 0.5 - ps / 2) / flp, torch.ones_like(xs)], -1)[None].to(dev)
+for t in dec.parameters().values():
+    t.requires_grad_(True)
+dec.max_steps = 512
+vr = nerf.VolumeRenderer(dec)
+vr.training = True
+tm = Tonemapping(device=dev)
+lights = torch.nn.functional.normalize(torch.tensor([[0.3, -0.5, -1.0]], device=dev), dim=-1)
+tgt_m = torch.rand(P, ps, ps, 1, generator=g).to(dev)
+tgt_rgb = torch.rand(P, ps, ps, 3, generator=g).to(dev)
+lp = LPIPSEngine.from_state_dict({k: v.to(torch.bfloat16).float() for k, v in SY.make_lpips_state_dict().items()}, torch.bfloat16, device=dev)
+opt = torch.optim.Adam(list(dec.parameters().values()), lr=1e-2, eps=1e-15)
+sync = torch.cuda.synchronize
+
+
+def it(split, acc):
+    t = [time.perf_counter()]
+
+    def mark():
+        if split:
+            sync()
+        t.append(time.perf_counter())
+    opt.zero_grad()
+    mark()
+    o = vr.forward(ro, rd, bits, 128, dt_gamma=0.0)
+    mark()
+    res = nerf_optim_loss(o['image'], o['weights_sum'], o['depth'], o['weights'], o['ts'][0], tgt_rgb, tgt_m, dirs, torch.ones(P, device=dev),
+                          lights, tonemapping=tm, shaded=True, normal_reg_weight=0.5, entropy_weight=0.2)
+    mark()
+    loss = res['loss'] + 0.3 * lp(res['out_rgbs'].permute(0, 3, 1, 2), tgt_rgb.permute(0, 3, 1, 2)).mean()
+    mark()
+    loss.backward()
+    mark()
+    opt.step()
+    mark()
+    for i in range(len(t) - 1):
+        acc[i] += t[i + 1] - t[i]
+    return int(o['weights'].shape[0])
+
+
+names = ['zero_grad', 'forward (march, cull, decode, composite)', 'losses', 'LPIPS patch', 'backward', 'Adam']
+for _ in range(3):
+    ns = it(True, [0.0] * 6)
+acc = [0.0] * 6
+for _ in range(N):
+    it(True, acc)
+print(f'nerf_optim iteration, {ps * ps * P} rays, {ns} samples after culling; synchronised parts (ms): ' +
+      ', '.join(f'{n} {a / N * 1e3:.3f}' for n, a in zip(names, acc)) + f'; sum {sum(acc) / N * 1e3:.3f}')
+sync()
+t0 = time.perf_counter()
+for _ in range(N):
+    it(False, [0.0] * 6)
+sync()
+print(f'un-synchronised iteration: {(time.perf_counter() - t0) / N * 1e3:.3f} ms')

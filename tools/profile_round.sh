@@ -3,10 +3,10 @@
 REPO=$PWD
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
+BENCH="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-extra"
 timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_stats -o bench -- $BENCH > $REPO/gpurun_out/prof_stats.log 2>&1
 tail -3 $REPO/gpurun_out/prof_stats.log
-BENCH1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-op-timing"
+BENCH1="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-extra --no-op-timing"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $REPO/gpurun_out/prof_fetch -o bench -- $BENCH1 > $REPO/gpurun_out/prof_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $REPO/gpurun_out/prof_write -o bench -- $BENCH1 > $REPO/gpurun_out/prof_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 -d $REPO/gpurun_out/prof_mfma -o bench -- $BENCH1 > $REPO/gpurun_out/prof_mfma.log 2>&1
