@@ -161,13 +161,17 @@ __global__ __launch_bounds__(NB, 2) void k_decode_backward(DecoderParams p, cons
     __shared__ __attribute__((aligned(16))) float w1t[HID * 2 * NL];
     stage_w1<NL>(p, w1t);
     __syncthreads();
-    const uint32_t m = blockIdx.x * NB + threadIdx.x;
-    if (m >= M) return;
+    // (every lane stays to the end: the table-gradient scatter below merges neighbouring lanes' contributions with cross-lane moves.  A lane past
+    // the last point redoes point M - 1 with zero incoming gradients, stores nothing and scatters nothing.)
+    const uint32_t m_raw = blockIdx.x * NB + threadIdx.x;
+    const bool valid = m_raw < M;
+    const uint32_t m = valid ? m_raw : M - 1;
     const float3p q = reinterpret_cast<const float3p*>(xyz)[m];
     const float x = q.x, y = q.y, z = q.z;
     const float inv = 1.0f / (2.0f * p.bound);
     const float u[3] = {(x + p.bound) * inv, (y + p.bound) * inv, (z + p.bound) * inv};
     // one level: cell / interpolation weights / table row of each corner, through `visit(corner_weight, row)`
+    uint32_t cell_key = 0;                    // cell of the last level() call, 10 bits per axis (exact for resolutions below 1023)
     auto level = [&](int l, auto&& visit) {
         const float scale = p.g.scale[l];
         const uint32_t res = p.g.res[l], size = p.g.size[l];
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(NB, 2) void k_decode_backward(DecoderParams p, cons
             const float fr = pos - fl;
             w[d] = fr * fr * (3.0f - 2.0f * fr);
         }
+        cell_key = (cell[0] & 1023u) | ((cell[1] & 1023u) << 10) | ((cell[2] & 1023u) << 20);
         const bool s1 = res <= size;
         const bool s2 = s1 && (uint64_t)res * res <= size;
         const uint64_t stride3 = (uint64_t)res * res * (s2 ? res : 1u);
@@ -209,8 +214,10 @@ __global__ __launch_bounds__(NB, 2) void k_decode_backward(DecoderParams p, cons
     for (int l = 0; l < NL; ++l) {
         float a0 = 0.f, a1 = 0.f;
         level(l, [&](float wt, uint32_t row) { const float2p f = tab[row]; a0 = fmaf(wt, f.x, a0); a1 = fmaf(wt, f.y, a1); });
-        ws_enc[(size_t)m * (2 * NL) + 2 * l] = a0;
-        ws_enc[(size_t)m * (2 * NL) + 2 * l + 1] = a1;
+        if (valid) {
+            ws_enc[(size_t)m * (2 * NL) + 2 * l] = a0;
+            ws_enc[(size_t)m * (2 * NL) + 2 * l + 1] = a1;
+        }
         const f32x4* wl = reinterpret_cast<const f32x4*>(w1t + l * (HID * 2));
 #pragma unroll
         for (int j2 = 0; j2 < HID / 2; ++j2) {
@@ -232,13 +239,13 @@ __global__ __launch_bounds__(NB, 2) void k_decode_backward(DecoderParams p, cons
     const float d2 = fmaxf(x * x + y * y + z * z, 0.2f);
     const float sigma = expf(o[0] + p.blob_density * expf(-d2 * p.blob_inv_2r2));
     float dout[4];
-    dout[0] = g_sigma[m] * fminf(fmaxf(sigma, 1e-6f), 1e6f);
+    dout[0] = valid ? g_sigma[m] * fminf(fmaxf(sigma, 1e-6f), 1e6f) : 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float sg = 1.0f / (1.0f + expf(-o[1 + k]));
-        dout[1 + k] = (g_rgb ? g_rgb[3ull * m + k] : 0.0f) * p.sat_scale * sg * (1.0f - sg);
+        dout[1 + k] = (valid && g_rgb ? g_rgb[3ull * m + k] : 0.0f) * p.sat_scale * sg * (1.0f - sg);
     }
-    reinterpret_cast<f32x4*>(ws_do)[m] = f32x4{dout[0], dout[1], dout[2], dout[3]};
+    if (valid) reinterpret_cast<f32x4*>(ws_do)[m] = f32x4{dout[0], dout[1], dout[2], dout[3]};
     // ---- hidden layer backward: store relu(h) (for dW2) and dh (for dW1), keep dh in registers -------------------------------------
 #pragma unroll
     for (int j4 = 0; j4 < HID / 4; ++j4) {
@@ -254,10 +261,14 @@ __global__ __launch_bounds__(NB, 2) void k_decode_backward(DecoderParams p, cons
             dh[e] = on ? g : 0.0f;
             h[j] = dh[e];
         }
-        reinterpret_cast<f32x4*>(ws_hr + (size_t)m * HID)[j4] = hr;
-        reinterpret_cast<f32x4*>(ws_dh + (size_t)m * HID)[j4] = dh;
+        if (valid) {
+            reinterpret_cast<f32x4*>(ws_hr + (size_t)m * HID)[j4] = hr;
+            reinterpret_cast<f32x4*>(ws_dh + (size_t)m * HID)[j4] = dh;
+        }
     }
     // ---- encoding backward: d enc_l = W1[:, 2l:2l+2]^T dh, scattered to the 8 corners of every level ------------------------------
+    // (all levels' d enc first, parked in LDS: the 64 hidden-unit gradients are dead by the time the scatter loop needs its registers for the merge)
+    __shared__ float es[2 * NL][NB];
 #pragma unroll 1
     for (int l = 0; l < NL; ++l) {
         const f32x4* wl = reinterpret_cast<const f32x4*>(w1t + l * (HID * 2));
@@ -268,10 +279,67 @@ __global__ __launch_bounds__(NB, 2) void k_decode_backward(DecoderParams p, cons
             e0 = fmaf(wv[0], h[2 * j2], e0); e1 = fmaf(wv[1], h[2 * j2], e1);
             e0 = fmaf(wv[2], h[2 * j2 + 1], e0); e1 = fmaf(wv[3], h[2 * j2 + 1], e1);
         }
-        level(l, [&](float wt, uint32_t row) {
-            atomicAdd(g_table + 2ull * row, wt * e0);
-            atomicAdd(g_table + 2ull * row + 1, wt * e1);
-        });
+        es[2 * l][threadIdx.x] = e0;
+        es[2 * l + 1][threadIdx.x] = e1;
+    }
+#pragma unroll 1
+    for (int l = 0; l < NL; ++l) {
+        const float e0 = es[2 * l][threadIdx.x], e1 = es[2 * l + 1][threadIdx.x];      // (a thread reads back its own slots: no barrier)
+        // Points are in ray order, so neighbouring lanes sit in the same cell of a coarse level (18 consecutive samples per 16^3 cell at the
+        // renderer's step, 2 at 141^3) and would send the same 8 rows 2 x 8 float atomics each.  MI355X retires ~20.8 G float atomics / s whatever
+        // the table size, the contention or the scope (tools/probe/atomic_probe.hip, profiles/r04_atomic_probe.log): the 46.6 M atomics of a
+        // 242 k-point batch were 2.2 ms of this kernel's 3.5.  So lanes merge first: a butterfly over aligned blocks of 2, 4, 8, 16 lanes -- the
+        // leader of a block takes its partner block's leader's sums when both hold the same cell (exact 30-bit cell key), and only lanes still
+        // holding sums scatter.  (Summation order changes, as it does with every run of the atomics themselves.)
+        // (four corners at a time: all sixteen sums next to the 64 hidden-unit gradients would spill)
+        bool alive = valid;
+        bool take[4] = {false, false, false, false};
+        const bool merge = p.g.res[l] <= 160u;    // (wave-uniform: finer levels have ~1 point per cell, nothing to merge)
+        const int lane = threadIdx.x & 63;
+        {
+            level(l, [&](float, uint32_t) {});    // the cell of this level -> cell_key
+            const uint32_t key = cell_key;
+            if (merge) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int d = 1 << s4;
+                    const uint32_t pkey = (uint32_t)__shfl_xor((int)key, d, 64);
+                    const int palive = __shfl_xor((int)alive, d, 64);
+                    const bool can = ((lane & (d - 1)) == 0) && alive && palive && pkey == key;      // both lead their block of d lanes and hold the same cell
+                    take[s4] = can && !(lane & d);
+                    alive = alive && !(can && (lane & d));
+                }
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float c0[4], c1[4];
+            uint32_t rows[4];
+            int k = 0;
+            level(l, [&](float wt, uint32_t row) {
+                if ((k >> 2) == half) { c0[k & 3] = wt * e0; c1[k & 3] = wt * e1; rows[k & 3] = row; }
+                ++k;
+            });
+            if (merge) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int d = 1 << s4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float p0 = __shfl_xor(c0[j], d, 64), p1 = __shfl_xor(c1[j], d, 64);
+                        c0[j] += take[s4] ? p0 : 0.0f;
+                        c1[j] += take[s4] ? p1 : 0.0f;
+                    }
+                }
+            }
+            if (alive) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    atomicAdd(g_table + 2ull * rows[j], c0[j]);
+                    atomicAdd(g_table + 2ull * rows[j] + 1, c1[j]);
+                }
+            }
+        }
     }
 }
 
