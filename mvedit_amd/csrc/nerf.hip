@@ -343,9 +343,9 @@ __global__ __launch_bounds__(NB, 2) void k_decode_backward(DecoderParams p, cons
     }
 }
 
-// out[p][q] = sum_m X[m][p] * Y[m][q]  (and colsum: sum_m X[m][p]): per-block partials over 1024-row chunks, reduced in a
+// out[p][q] = sum_m X[m][p] * Y[m][q]  (and colsum: sum_m X[m][p]): per-block partials over XTY_ROWS-row chunks, reduced in a
 // fixed order by k_xty_reduce -> deterministic.  P, Q <= 64, P * Q <= 2048.
-constexpr int XTY_ROWS = 1024, XTY_STEP = 32;
+constexpr int XTY_ROWS = 256, XTY_STEP = 32;       // (256-row chunks since round 4: 948 blocks for a 242 k-point batch instead of 237 on 256 CUs -- the kernel is LDS-read bound per block)
 __global__ __launch_bounds__(256) void k_xty(const float* __restrict__ X, int P, const float* __restrict__ Y, int Q, uint32_t M,
                                              float* __restrict__ partial /*[nblk][P*Q + P]*/) {
     __shared__ float xs[XTY_STEP][64], ys[XTY_STEP][64];
@@ -379,8 +379,15 @@ __global__ __launch_bounds__(256) void k_xty_reduce(const float* __restrict__ pa
                                                     float* __restrict__ out_col) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float a = 0.f;
-    for (int b = 0; b < nblk; ++b) a += partial[(size_t)b * n + i];
+    // eight independent chains (fixed order: deterministic): one chain waits out a load per partial
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += partial[(size_t)(b + k) * n + i];
+    }
+    for (; b < nblk; ++b) a8[b & 7] += partial[(size_t)b * n + i];
+    const float a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     if (i < n_mat) out_mat[i] = a;
     else if (out_col) out_col[i - n_mat] = a;
 }

@@ -14,5 +14,7 @@ cd $REPO/gpurun_out && find . -name "*.csv" | head -30 && du -sh .
 # keep only per-kernel aggregates of the PMC passes (raw per-dispatch csv can be large)
 python $REPO/tools/summarize_prof.py $REPO/gpurun_out > $REPO/gpurun_out/prof_summary.txt 2>&1
 tail -60 $REPO/gpurun_out/prof_summary.txt
-# afterwards, in the repo: python tools/summarize_prof.py gpurun_out > profiles/rNN_rocprof_vK_summary.txt
-#                           python tools/make_pmc_traffic.py gpurun_out profiles/rNN_rocprof_vK_summary.txt > profiles/pmc_traffic.json
+# pmc_traffic.json from the same databases, then drop the raw rocpd databases: gpurun merges at most 64 MiB back (the MFMA pass alone is > 100 MB)
+python $REPO/tools/make_pmc_traffic.py $REPO/gpurun_out profiles/${PROF_TAG:-rNN}_rocprof_summary.txt > $REPO/gpurun_out/pmc_traffic.json 2>$REPO/gpurun_out/pmc_traffic.err
+rm -rf $REPO/gpurun_out/prof_stats $REPO/gpurun_out/prof_fetch $REPO/gpurun_out/prof_write $REPO/gpurun_out/prof_mfma
+# afterwards, in the repo: cp gpurun_out/prof_summary.txt profiles/rNN_rocprof_summary.txt; cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
