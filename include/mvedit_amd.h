@@ -190,6 +190,10 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int l
  * (threshold and option bits), so `old = tune(x); ...; tune(old)` restores every switch.  The defaults come from the environment
  * variables MVE_GEMM_BIG, MVE_GEMM_PP, MVE_GEMM_PP2 (0 never / 1 wherever eligible / 2 narrow launches only) and MVE_GEMM_STRICT_SPLITK. */
 MVE_API int mve_gemm_tune(int big_min_blocks);
+/* Diagnostics: the number of K slices a GEMM / conv launch of this shape runs with under the current switches -- the slice rule's count (a function
+ * of rows per image, N, K only), 1 where the un-split launch fills the chip (or the rule's count again in the strict mode, which emulates the slices
+ * inside one block), or the smallest count that fills the chip where the rule would over-fill it.  Host logic only. */
+MVE_API int mve_gemm_effective_splitk(int M, int N, int K, int rows_per_image);
 
 /* Development aid for csrc/gemm_pp.hip: with `d_buf` (device, 64 uint64 per launched block) set, fp16 320-wide launches of the
  * ping-pong kernel run an instrumented copy and every wave writes its shader-clock sums {L-section work, wait at the L barrier,

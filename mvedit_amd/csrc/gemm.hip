@@ -522,6 +522,24 @@ int mve_gemm_tune(int big_min_blocks) {
     return old;
 }
 
+/* The number of K slices a launch of this shape actually runs with under the current switches (diagnostics / tests; no GPU touched): the slice
+ * rule's count (choose_splitk: a function of rows per image, N, K only), 1 where the un-split launch fills the chip (one accumulation chain;
+ * the strict mode emulates the rule's slices inside one block instead: reported as the rule's count), or the smallest count that fills the
+ * chip where the rule would over-fill it. */
+int mve_gemm_effective_splitk(int M, int N, int K, int rows_per_image) {
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    const int sk = choose_splitk(rows_per_image, N, K);
+    if (sk <= 1 || tile256_bn(N, sk) == 0 || gemm_big_min_blocks() <= 0 || N % 320 != 0) return sk < 1 ? 1 : sk;
+    const long long t1 = tile256_blocks(M, N, 1);
+    if (g_seq_splitk && t1 >= gemm_big_min_blocks() && (size_t)t1 * 256 * 320 <= (size_t)sk * M * N) return gemm_strict_splitk() ? sk : 1;
+    if (!gemm_strict_splitk() && sk > 2 && t1 > 0 && t1 * sk >= 2 * gemm_big_min_blocks()) {
+        int few = (int)((gemm_big_min_blocks() + t1 - 1) / t1);
+        few = few < 2 ? 2 : few;
+        return few < sk ? few : sk;
+    }
+    return sk;
+}
+
 size_t mve_gemm_workspace_bytes(int M, int N, int K, int rows_per_image) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int sk = choose_splitk(rows_per_image, N, K);

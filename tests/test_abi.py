@@ -3,6 +3,8 @@ import ctypes
 import os
 import subprocess
 
+import pytest
+
 
 def test_library_exports_every_declared_symbol(lib):
     protos = lib.parse_header()
@@ -120,3 +122,49 @@ def test_host_side_dispatch_knobs_round_trip_and_do_not_depend_on_the_batch():
     for (hw, c) in ((4096, 320), (4096, 960), (1024, 640), (256, 1280), (64, 2560), (262144, 128)):
         per_image = [(ws(b, hw, c, 32) - 64) // b for b in (1, 2, 8, 64)]      # partials + statistics scale with the batch and with nothing else
         assert max(per_image) - min(per_image) <= 64, (hw, c, per_image)
+
+
+def test_slice_decisions_of_the_gemm_dispatcher():
+    """Host logic of round 4's dispatcher (csrc/gemm.hip): the slice RULE depends on the layer only; what a launch actually runs with depends on
+    whether it fills the chip -- one chain where the un-split launch does (64 images at the 32 x 32 / 16 x 16 levels), just enough slices where
+    the rule would over-fill it (64 images at 8 x 8: 64 tiles x 8 slices -> 4), the rule's count for small batches and in the strict mode."""
+    from mvedit_amd import _lib
+    eff = _lib.raw('mve_gemm_effective_splitk')
+    ws = _lib.raw('mve_gemm_workspace_bytes')
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    try:
+        tune(256)
+        rule = lambda M, N, K, rpi: ws(M, N, K, rpi) // (M * N * 4) if ws(M, N, K, rpi) else 1
+        for rpi, N, K in ((1024, 640, 5760), (256, 1280, 11520), (64, 1280, 11520), (256, 1280, 5120)):
+            assert len({rule(B * rpi, N, K, rpi) for B in (1, 2, 8, 64)}) == 1, 'the rule never looks at the batch'
+        assert rule(64 * 1024, 640, 5760, 1024) == 2 and eff(64 * 1024, 640, 5760, 1024) == 1         # 32 x 32 level, 64 images: one chain
+        assert rule(64 * 256, 1280, 11520, 256) == 4 and eff(64 * 256, 1280, 11520, 256) == 1         # 16 x 16 level
+        assert rule(64 * 64, 1280, 11520, 64) == 8 and eff(64 * 64, 1280, 11520, 64) == 4             # 8 x 8 level: 64 tiles -> 4 slices fill 256 CUs
+        for B in (1, 2, 8):                                                                          # small batches (every rank of an 8-GPU job): the rule
+            for rpi, N, K in ((1024, 640, 5760), (256, 1280, 11520), (64, 1280, 11520)):
+                assert eff(B * rpi, N, K, rpi) == rule(B * rpi, N, K, rpi), (B, rpi)
+        tune(256 | (1 << 30))                                                                        # strict: the rule at any batch
+        for rpi, N, K in ((1024, 640, 5760), (256, 1280, 11520), (64, 1280, 11520)):
+            assert eff(64 * rpi, N, K, rpi) == rule(64 * rpi, N, K, rpi)
+        assert eff(64 * 4096, 320, 2880, 4096) == 1                                                  # 64 x 64 level: the rule itself never splits
+    finally:
+        tune(old)
+
+
+def test_residual_pair_is_a_plan_option(lib):
+    """mve_unet_set_residual_mode (plan-time only, no GPU): the pair mode doubles the residual-stream tensors of the workspace, keeps the op list,
+    round-trips, and is refused by the non-UNet executors."""
+    import torch
+    from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG
+    eng = UNet2DConditionEngine(SD15_CONFIG, torch.float16, device='cpu')
+    a = eng.plan(2, 64, 64, 77)
+    assert eng.residual_pair is False and eng.set_residual_pair(True) is False and eng.residual_pair is True
+    b = eng.plan(2, 64, 64, 77)
+    assert b['n_ops'] == a['n_ops'] and b['flops'] == a['flops']
+    assert a['workspace_bytes'] < b['workspace_bytes'] < 2 * a['workspace_bytes']
+    assert eng.set_residual_pair(False) is True and eng.plan(2, 64, 64, 77)['workspace_bytes'] == a['workspace_bytes']
+    from mvedit_amd.vae import AutoencoderKLEngine, SD_VAE_CONFIG
+    vae = AutoencoderKLEngine(dict(SD_VAE_CONFIG), torch.float16, 'cpu')
+    with pytest.raises(lib.MveError):
+        lib.call('mve_unet_set_residual_mode', vae.decoder._h, 1)
