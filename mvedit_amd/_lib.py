@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: pins ONE libamdhip64 in the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'mvedit_amd.h')
-LIB_PATH = os.path.join(_HERE, 'libmvedit_amd.so')
+LIB_PATH = os.path.join(_HERE, 'libmvedit_amd.so' if not os.environ.get('MVE_LIB_TAG') else f"libmvedit_amd_{os.environ['MVE_LIB_TAG']}.so")      # (tagged: an A/B build of mvedit_amd.build)
 
 _CTYPE = {
     'void': None,

@@ -43,6 +43,15 @@ EXTRA_FLAGS = {
 }
 
 
+# A/B builds: MVE_BUILD_TAG=<tag> writes libmvedit_amd_<tag>.so (objects under _build_<tag>/) with the extra -D switches of MVE_BUILD_DEFS
+# (comma separated), e.g. MVE_BUILD_TAG=staged64 MVE_BUILD_DEFS=MVE_EPI_STAGED64 for the rounds 1-3 GEMM epilogue; mvedit_amd._lib loads the
+# tagged library when MVE_LIB_TAG=<tag> is set.
+_TAG = os.environ.get('MVE_BUILD_TAG', '')
+if _TAG:
+    OBJDIR = os.path.join(ROOT, '_build_' + _TAG)
+    LIB = os.path.join(ROOT, f'libmvedit_amd_{_TAG}.so')
+    COMMON_FLAGS = COMMON_FLAGS + ['-D' + d for d in os.environ.get('MVE_BUILD_DEFS', '').split(',') if d]
+
 if os.environ.get('MVE_ATTN_LAB') == '1':        # development build: the timing-only ablation instantiations of k_attention3 (tools/ab_attention_ablate.py)
     EXTRA_FLAGS['attention.hip'] = EXTRA_FLAGS['attention.hip'] + ['-DMVE_ATTN_LAB']
 
