@@ -228,6 +228,25 @@ MVE_API int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* 
                                  const void* residual, int ldr, int flags, float out_scale, void* d_workspace,
                                  size_t workspace_bytes, void* stream);
 
+/* ---- nearest-2x upsample + 3 x 3 conv as four 2 x 2 phase convs (round 4) -------------------------------------------------------------------------
+ * Replaces, for Upsample2D (diffusers 0.27.2 resnet/upsampling: F.interpolate(scale_factor=2, mode="nearest") then conv 3x3 pad 1; the UNet's
+ * up_blocks.*.upsamplers.0 and the VAE decoder's, reached from lib/models/architecture/diffusers.py:57-164 / lib/pipelines/utils.py decode), the
+ * fused form mve_conv3x3(..., upsample = 1): output pixel (2 i + py, 2 j + px) reads source rows {i - 1 + py, i + py} and columns
+ * {j - 1 + px, j + px} only, the 3 x 3 taps landing on one source pixel add up, so each output parity (py, px) is a 2 x 2 conv over the SOURCE
+ * with K = 4 C: 4 / 9 of the multiply-adds.  Zero padding of the upsampled image = zero padding of the source: exact at the borders.
+ *   d_W4 : [phase = 2 py + px][Cout][C / 64][2][2][64], the summed taps from mve_pack_upsample_phase_weights (fp32 sums in ascending (row, column)
+ *          order, ONE rounding to the storage type).  That rounding is the only arithmetic difference from the 3 x 3 form: the two agree to the
+ *          storage precision of the weights, not bit for bit (tests/test_unet_ops.py pins both the exact identity on the rounded phase weights and
+ *          the distance to the 3 x 3 form; end to end: tests/rounding_budget_experiment.py --phase).
+ *   d_out: [B][2 Hs][2 Ws][Cout] NHWC, dense; d_out_lo (NULL or same shape): the low half in residual_pair mode.
+ * Needs C % 64 == 0, Cout a multiple of 128, Ws a power of two, B Hs Ws >= 64 (mve_upsample_conv_phases_supported = 1); four launches of the
+ * ping-pong kernel (2 x 2 window, grouped output rows), K slices as for any conv of that shape (workspace: *_workspace_bytes). */
+MVE_API int mve_upsample_conv_phases_supported(int C, int Cout, int B, int Hs, int Ws);
+MVE_API size_t mve_upsample_conv_phases_workspace_bytes(int C, int Cout, int B, int Hs, int Ws);
+MVE_API int mve_pack_upsample_phase_weights(int src_dtype, int dst_dtype, const void* d_w_oihw, int Cout, int C, void* d_W4, void* stream);
+MVE_API int mve_upsample_conv_phases(int dtype, const void* d_x, int C, int B, int Hs, int Ws, const void* d_W4, int Cout, void* d_out,
+                                     const float* d_bias, int flags, void* d_workspace, size_t workspace_bytes, void* d_out_lo, void* stream);
+
 /* ---- residual stream as an unrounded pair (round 4; the executor's `residual_pair` mode, mve_unet_set_residual_mode) -----------------------------
  * The reference's half-precision modules round the residual stream x + f(x) of ResnetBlock2D / BasicTransformerBlock / Transformer2DModel
  * (diffusers 0.27.2, driven from lib/models/architecture/diffusers.py:57-164) to 16 bits after every block: ~30 % of the end-to-end error against

@@ -246,7 +246,7 @@ int Builder::build(int B_, int H, int W, int n_img, int has_res, int io_dtype, i
         if (i + 1 < n) {
             const std::string un = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
             Ref y = ws_stream((size_t)Bb * (2 * h) * (2 * w) * cout * e);
-            conv(x, cout, Bb, h, w, 1, 1, wt(un + ".w"), cout, y, wt(un + ".b"), Ref(), 0, Ref(), 0, "upsample+conv");
+            upsample_conv(x, cout, Bb, h, w, un, y);
             rel(x);
             h *= 2; w *= 2;
             x = y;

@@ -115,7 +115,7 @@ int Builder::build_vae(int B_, int H, int W, int io_dtype) {
                 const std::string un = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
                 Ref y = ws((size_t)Bb * (2 * h) * (2 * w) * cout * e);
                 rows_img = 4 * h * w;
-                conv(x, cout, Bb, h, w, 1, 1, wt(un + ".w"), cout, y, wt(un + ".b"), Ref(), 0, Ref(), 0, "upsample+conv");
+                upsample_conv(x, cout, Bb, h, w, un, y);
                 rel(x);
                 h *= 2; w *= 2;
                 x = y;

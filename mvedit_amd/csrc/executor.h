@@ -24,6 +24,10 @@ int mve_axpy_pair(int, const void*, const void*, const void*, float, void*, void
 int mve_conv3x3(int, const void*, int, const void*, int, int, int, int, int, int, const void*, int, void*, int,
                 const float*, const float*, int, const void*, int, int, float, void*, size_t, void*);
 size_t mve_gemm_workspace_bytes(int, int, int, int);
+int mve_upsample_conv_phases_supported(int, int, int, int, int);
+size_t mve_upsample_conv_phases_workspace_bytes(int, int, int, int, int);
+int mve_pack_upsample_phase_weights(int, int, const void*, int, int, void*, void*);
+int mve_upsample_conv_phases(int, const void*, int, int, int, int, const void*, int, void*, const float*, int, void*, size_t, void*, void*);
 int mve_attention_prescaled(int, const void*, int, const void*, int, const void*, int, const void*, int, const void*, int, void*, int, int, int, int, int, int, int, void*);
 int mve_attention(int, const void*, int, const void*, int, const void*, int, const void*, int, const void*, int, void*, int,
                   int, int, int, int, int, int, float, void*);

@@ -97,6 +97,32 @@ struct Builder {
         });
         rel(sk);
     }
+    // Upsample2D: nearest 2x + conv 3x3.  Default: four 2 x 2 phase convs over the source (mve_upsample_conv_phases: 4 / 9 of the flops, one extra
+    // rounding on the summed weights) wherever the shape allows; the 3 x 3 conv over the virtual upsampled image otherwise, with MVE_UPSAMPLE_PHASES=0,
+    // and in residual_pair mode (the accuracy mode keeps the reference's arithmetic).  The choice depends on the shape and the mode only, except
+    // below 64 source pixels per launch (tiny test sizes at batch 1), where the 3 x 3 form runs.
+    static bool upsample_phases_on() {
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("MVE_UPSAMPLE_PHASES"); on = e ? (atoi(e) != 0) : 1; }
+        return on != 0;
+    }
+    void upsample_conv(Ref x, int C, int Bn, int H, int W, const std::string& slot, Ref out) {
+        const bool have4 = u.params.count(slot + ".w4") != 0;
+        if (!have4 || !upsample_phases_on() || pl.ao.residual_pair || !mve_upsample_conv_phases_supported(C, C, Bn, H, W)) {
+            conv(x, C, Bn, H, W, 1, 1, wt(slot + ".w"), C, out, wt(slot + ".b"), Ref(), 0, Ref(), 0, "upsample+conv");
+            return;
+        }
+        const int d = dt;
+        const char* what = "upsample+conv (4 phases)";
+        live(x, what); live(out, what);
+        const size_t skb = mve_upsample_conv_phases_workspace_bytes(C, C, Bn, H, W);
+        Ref sk = skb ? ws(skb) : Ref();
+        const Ref W4 = wt(slot + ".w4"), bias = wt(slot + ".b"), out_lo = lo(out);
+        op(OC_CONV, 2.0 * Bn * (4.0 * H * W) * (double)C * 4 * C, what, [=](const Run& r) {
+            return mve_upsample_conv_phases(d, r.p(x), C, Bn, H, W, r.p(W4), C, r.p(out), (const float*)r.p(bias), 0, r.p(sk), skb, r.p(out_lo), r.stream);
+        });
+        rel(sk);
+    }
     void gn(Ref x1, int C1, Ref x2, int C2, int Bn, int HW, float eps, Ref g, Ref b, int silu, Ref out, const char* what) {
         const int d = dt, G = c.groups;
         const size_t wsb = mve_groupnorm_workspace_bytes(Bn, HW, C1 + C2, G);

@@ -98,6 +98,7 @@ void layout_params(Unet& u) {
             const size_t Cs = c.vae == 1 ? c.ch[n - 1 - i] : c.ch[i];
             const std::string sn = (c.vae == 1 ? "up_blocks." + std::to_string(i) + ".upsamplers" : "down_blocks." + std::to_string(i) + ".downsamplers") + ".0.conv";
             sb.add(sn + ".w", Cs * 9 * Cs, false); need(sn + ".weight");
+            if (c.vae == 1 && Cs % 64 == 0) sb.add(sn + ".w4", Cs * 16 * Cs, false);      // the upsampler's summed taps (mve_upsample_conv_phases)
             sb.add(sn + ".b", Cs, true); need(sn + ".bias");
         }
         sb.add("norm_out.g", Cout0, true); need("conv_norm_out.weight");
@@ -183,6 +184,7 @@ void layout_params(Unet& u) {
         const size_t Cu = c.ch[c.n_levels - 1 - i];
         const std::string up = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
         sb.add(up + ".w", Cu * 9 * Cu, false); need(up + ".weight");
+        if (Cu % 64 == 0) sb.add(up + ".w4", Cu * 16 * Cu, false);      // the summed taps of the four 2 x 2 phase convs (mve_upsample_conv_phases)
         sb.add(up + ".b", Cu, true); need(up + ".bias");
     }
     if (!c.controlnet) {
@@ -411,6 +413,8 @@ int load_param(Unet& u, const std::string& name, const void* src, int src_dtype,
             if (u.sc_cin.count(r)) conv_row = 9 * shape[1] + u.sc_cin[r];
         }
         rc = conv(P(base + ".w"), shape[0], shape[1], shape[0], shape[1]);
+        if (rc == MVE_OK && P(base + ".w4"))      // an upsampler: also the summed taps of its four 2 x 2 phase convs
+            rc = mve_pack_upsample_phase_weights(src_dtype, c.dtype, src, (int)shape[0], (int)shape[1], dstp(P(base + ".w4"), 0), s);
     } else if (ends_with(name, ".conv1.bias") || ends_with(name, ".conv2.bias") || ends_with(name, ".conv.bias"))
         rc = vec(P(strip(name, ".bias") + ".b"), 0, shape[0], 1);
     else if (ends_with(name, ".proj_in.weight") || ends_with(name, ".proj_out.weight")) {

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
             const int y = r / p.g.Wo;
             cb[j] = b;
             cy[j] = y * p.g.stride - p.g.pad;
-            cx[j] = (r - y * p.g.Wo) * p.g.stride - p.g.pad;
+            cx[j] = (r - y * p.g.Wo) * p.g.stride - p.g.pad_x;
         }
     }
     const T* w_row[B_PASSES];
@@ -325,6 +325,7 @@ int choose_splitk(int rows_per_image, int N, int K) {
 
 template <class Tag, int MODE>
 int launch_v(const GemmParams& p, hipStream_t s) {
+    MVE_CHECK(p.g.kw != 2, MVE_ERR_STATE, "gemm: 2 x 2 conv windows run on the ping-pong kernel only");
     // tile width: prefer the widest tile that divides N (no dead columns), else 128
     int bn = 128;
     if (p.N % 160 == 0) bn = 160;
@@ -502,6 +503,56 @@ int check_common(const GemmParams& p, const char* who) {
     return MVE_OK;
 }
 
+// one K-sliced launch of a phase of mve_upsample_conv_phases: launch_gemm's slice policy on the ping-pong kernel alone
+template <class Tag>
+int launch_phase(GemmParams q, hipStream_t s) {
+    const int minb = gemm_big_min_blocks() > 0 ? gemm_big_min_blocks() : 256;
+    if (q.splitk > 1 && q.N % 320 != 0) q.splitk = 1;         // (only the 320-wide tile cuts K)
+    if (q.splitk > 1) {
+        const long long t1 = tile256_blocks(q.M, q.N, 1);
+        if (t1 >= minb) {                                     // the un-split launch fills the chip
+            if (gemm_strict_splitk() && !q.out_lo) q.splitk_seq = q.splitk;
+            if (!gemm_strict_splitk() || !q.out_lo) q.splitk = 1;
+        } else if (!gemm_strict_splitk() && q.splitk > 2 && t1 > 0 && t1 * q.splitk >= 2 * minb) {
+            const int few = (int)((minb + t1 - 1) / t1);
+            q.splitk = few < 2 ? 2 : (few < q.splitk ? few : q.splitk);
+        }
+    }
+    const int rc = mve_gemm_pp_launch(Tag::dtype, 1, &q, s);
+    if (rc == 1) {
+        mve_set_error("upsample_conv_phases: the ping-pong kernel does not take M=%d N=%d K=%d (mve_upsample_conv_phases_supported)", q.M, q.N, q.K);
+        return MVE_ERR_ARG;
+    }
+    if (rc != MVE_OK) return rc;
+    if (q.splitk > 1) {
+        k_splitk_reduce<Tag><<<mve_cdiv((size_t)q.M * (q.N / 8), 256), 256, 0, s>>>(q);
+        MVE_LAUNCH_CHECK();
+    }
+    return MVE_OK;
+}
+
+// one thread per destination element [phase][o][slab][a][b][c]: the 3 x 3 taps (rows ys, columns xs) that land on window position (a, b) of
+// phase (py, px) are summed in fp32 in ascending (row, column) order -- py = 0: rows {0}, {1, 2}; py = 1: rows {0, 1}, {2}; columns likewise
+template <class SrcT, class Tag>
+__global__ __launch_bounds__(256) void k_pack_phase_weights(const SrcT* __restrict__ w, typename Tag::T* __restrict__ w4, int Cout, int C) {
+#pragma clang fp contract(off)
+    const size_t per_phase = (size_t)Cout * 4 * C;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 4 * per_phase) return;
+    const int ph = (int)(i / per_phase);
+    size_t r = i - (size_t)ph * per_phase;
+    const int o = (int)(r / (4 * C));
+    r -= (size_t)o * 4 * C;
+    const int slab = (int)(r / 256), t = (int)(r % 256) / 64, c = (int)(r % 64);
+    const int py = ph >> 1, px = ph & 1, a = t >> 1, b = t & 1;
+    const int y0 = a == 0 ? 0 : (py ? 2 : 1), y1 = a == 0 ? (py ? 1 : 0) : 2;
+    const int x0 = b == 0 ? 0 : (px ? 2 : 1), x1 = b == 0 ? (px ? 1 : 0) : 2;
+    const SrcT* src = w + ((size_t)o * C + slab * 64 + c) * 9;
+    float acc = 0.f;
+    for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) acc += (float)src[yy * 3 + xx];
+    w4[i] = Tag::from_f32(acc);
+}
 }  // namespace
 
 extern "C" {
@@ -598,7 +649,7 @@ static int conv3x3_impl(int dtype, const void* x1, int C1, const void* x2, int C
     p.g.ups = upsample ? 1 : 0;
     p.g.Hv = Hs << p.g.ups; p.g.Wv = Ws << p.g.ups;
     p.g.stride = stride;
-    p.g.pad = (flags & MVE_CONV_PAD_BR) ? 0 : 1;        // one output size either way: the window only shifts by a pixel
+    p.g.pad = p.g.pad_x = (flags & MVE_CONV_PAD_BR) ? 0 : 1;        // one output size either way: the window only shifts by a pixel
     MVE_CHECK(p.g.pad == 1 || (stride == 2 && !upsample && Hs % 2 == 0 && Ws % 2 == 0), MVE_ERR_ARG,
               "conv3x3: MVE_CONV_PAD_BR is the stride-2 downsampler of an even-sized input");
     p.g.Ho = (p.g.Hv + 2 - 3) / stride + 1;
@@ -651,6 +702,89 @@ int mve_conv3x3_pair(int dtype, const void* x1, int C1, const void* x2, int C2, 
                      const void* residual_lo, void* out_lo, void* stream) {
     return conv3x3_impl(dtype, x1, C1, x2, C2, nullptr, 0, nullptr, 0, B, Hs, Ws, stride, upsample, W, Cout, out, ldc, bias, rowvec, ldrv,
                         residual, ldr, flags, out_scale, workspace, workspace_bytes, stream, residual_lo, out_lo);
+}
+
+/* Nearest-2x upsample + 3 x 3 conv (pad 1) as FOUR 2 x 2 convs over the low-resolution input, one per output parity (py, px): output pixel
+ * (2 i + py, 2 j + px) sees source rows {i - 1 + py, i + py} and columns {j - 1 + px, j + px} only, because the 3 x 3 taps that fall on the same
+ * source pixel add up: 4 / 9 of the multiply-adds of the conv over the upsampled image, and the zero padding of the upsampled image is the zero
+ * padding of the source.  W4 = the summed taps [phase = 2 py + px][Cout][C / 64][2][2][64] (mve_pack_upsample_phase_weights: summed in fp32, ONE
+ * rounding to the storage type -- a rounding the 3 x 3 form does not have: the two forms agree to the storage precision of the weights, not bit
+ * for bit).  Each phase is one launch of the ping-pong kernel with a 2 x 2 window (ConvGeom::kw) that writes its quarter of the [B][2H][2W][Cout]
+ * output through the grouped output rows of GemmParams::orow_*.  Slice policy as in launch_gemm. */
+
+
+int mve_pack_upsample_phase_weights(int src_dtype, int dst_dtype, const void* w_oihw, int Cout, int C, void* W4, void* stream) {
+    MVE_CHECK(w_oihw && W4 && Cout > 0 && C > 0 && C % 64 == 0, MVE_ERR_ARG, "pack_upsample_phase_weights: needs C %% 64 == 0 (Cout=%d C=%d)", Cout, C);
+    const size_t n = (size_t)16 * Cout * C;
+    const unsigned grid = (unsigned)mve_cdiv(n, 256);
+    hipStream_t s = (hipStream_t)stream;
+#define MVE_PPW(ST, TAG) k_pack_phase_weights<ST, TAG><<<grid, 256, 0, s>>>((const ST*)w_oihw, (typename TAG::T*)W4, Cout, C)
+    if (dst_dtype == MVE_F16) {
+        if (src_dtype == MVE_F32) MVE_PPW(float, F16Tag); else if (src_dtype == MVE_F16) MVE_PPW(f16, F16Tag); else if (src_dtype == MVE_BF16) MVE_PPW(bf16, F16Tag);
+        else { mve_set_error("pack_upsample_phase_weights: unsupported source dtype %d", src_dtype); return MVE_ERR_ARG; }
+    } else if (dst_dtype == MVE_BF16) {
+        if (src_dtype == MVE_F32) MVE_PPW(float, BF16Tag); else if (src_dtype == MVE_F16) MVE_PPW(f16, BF16Tag); else if (src_dtype == MVE_BF16) MVE_PPW(bf16, BF16Tag);
+        else { mve_set_error("pack_upsample_phase_weights: unsupported source dtype %d", src_dtype); return MVE_ERR_ARG; }
+    } else { mve_set_error("pack_upsample_phase_weights: unsupported destination dtype %d", dst_dtype); return MVE_ERR_ARG; }
+#undef MVE_PPW
+    MVE_LAUNCH_CHECK();
+    return MVE_OK;
+}
+
+int mve_upsample_conv_phases_supported(int C, int Cout, int B, int Hs, int Ws) {
+    if (C <= 0 || C % 64 != 0 || Cout <= 0 || B <= 0 || Hs <= 0 || Ws <= 0 || (Ws & (Ws - 1)) != 0) return 0;
+    if (Cout % 320 != 0 && Cout % 256 != 0 && Cout % 128 != 0) return 0;
+    if (!gemm_pp_on() || (long long)B * Hs * Ws < 64 || (long long)B * Hs * Ws > 0x7fffffffll / 4) return 0;
+    return 1;
+}
+
+size_t mve_upsample_conv_phases_workspace_bytes(int C, int Cout, int B, int Hs, int Ws) {
+    return mve_gemm_workspace_bytes(B * Hs * Ws, Cout, 4 * C, Hs * Ws);
+}
+
+int mve_upsample_conv_phases(int dtype, const void* x, int C, int B, int Hs, int Ws, const void* W4, int Cout, void* out, const float* bias,
+                             int flags, void* workspace, size_t workspace_bytes, void* out_lo, void* stream) {
+    if (B == 0) return MVE_OK;
+    MVE_CHECK(mve_upsample_conv_phases_supported(C, Cout, B, Hs, Ws), MVE_ERR_ARG,
+              "upsample_conv_phases: needs C %% 64 == 0, Cout a multiple of 128, a power-of-two source width and >= 64 source pixels (C=%d Cout=%d B=%d %dx%d)",
+              C, Cout, B, Hs, Ws);
+    MVE_CHECK(x && W4 && out, MVE_ERR_ARG, "upsample_conv_phases: null pointer");
+    MVE_CHECK(dtype == MVE_F16 || dtype == MVE_BF16, MVE_ERR_ARG, "upsample_conv_phases: unsupported dtype %d", dtype);
+    int lw = 0;
+    while ((1 << lw) < Ws) ++lw;
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.g.Hs = p.g.Hv = p.g.Ho = Hs;
+        p.g.Ws = p.g.Wv = p.g.Wo = Ws;
+        p.g.stride = 1;
+        p.g.kw = 2;
+        p.g.pad = 1 - py; p.g.pad_x = 1 - px;
+        p.g.C1 = C;
+        p.g.chunk64 = 1;
+        p.M = B * Hs * Ws; p.N = Cout; p.K = 4 * C;
+        p.A = x;
+        p.W = (const char*)W4 + (size_t)ph * Cout * p.K * 2;
+        const size_t o0 = ((size_t)py * 2 * Ws + px) * Cout * 2;       // bytes: pixel (py, px) of image 0
+        p.out = (char*)out + o0;
+        p.out_lo = out_lo ? (char*)out_lo + o0 : nullptr;
+        p.bias = bias;
+        p.ldc = 2 * Cout; p.ldw = p.K;
+        p.orow_shift = lw; p.orow_extra = 2 * Ws * Cout;
+        p.rows_per_vec = Hs * Ws;
+        p.out_scale = 1.0f;
+        int rc = check_common(p, "upsample_conv_phases");
+        if (rc) return rc;
+        p.splitk = 1;
+        if (workspace && !(flags & MVE_GEMM_NO_SPLITK)) {
+            const int sk = choose_splitk(Hs * Ws, p.N, p.K);
+            if (sk > 1 && workspace_bytes >= (size_t)sk * p.M * p.N * sizeof(float)) { p.splitk = sk; p.partial = (float*)workspace; }
+        }
+        rc = dtype == MVE_F16 ? launch_phase<F16Tag>(p, (hipStream_t)stream) : launch_phase<BF16Tag>(p, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return MVE_OK;
 }
 
 int mve_conv3x3_shortcut_pair(int dtype, const void* x1, int C1, const void* x3, int C3, const void* x4, int C4, int B, int Hs, int Ws,

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NTH, 2) void k_gemm_big(const GemmParams p) {
             const int y = r / p.g.Wo;
             cb[j] = b;
             cy[j] = y * p.g.stride - p.g.pad;
-            cx[j] = (r - y * p.g.Wo) * p.g.stride - p.g.pad;
+            cx[j] = (r - y * p.g.Wo) * p.g.stride - p.g.pad_x;
             if constexpr (FAST) {     // per-row pixel base and 9-bit halo mask; cb/cy/cx are dead after this in the fast kernel
                 // nearest 2x upsample: the source pixel of virtual (y, x) is (y >> 1, x >> 1); bits 9 / 10 keep the parities of the
                 // window origin, from which a tap's source offset is ((parity + d) >> 1)

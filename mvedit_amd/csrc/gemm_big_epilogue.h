@@ -123,7 +123,7 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
     // 64-bit row address products per chunk; the epilogue is VALU-bound (2 waves per SIMD, ~70 VALU per chunk there, ~30 here).
     // Same operations in the same order as gemm_epilogue_tail, so the bits are the same.
     const bool fast = !partial && p.bias && p.out_scale == 1.0f && !p.res_after_scale && !p.out_f32 && (!p.rowvec || rv_pass) &&
-                      m0 + BM2 <= p.M && n0 + BN2 <= p.N;
+                      m0 + BM2 <= p.M && n0 + BN2 <= p.N && p.orow_extra == 0;      // (grouped output rows: the generic path below addresses per row)
     if constexpr (PAIR) {
       // ---- the fast path of the executor's residual_pair mode: the result leaves as (hi, lo) = (round16(v), round16(v - hi)).  The residual pair is
       // NOT read here: the PAIR kernel starts its accumulators from it (k_gemm_pp, pp_acc_from_residual), so this epilogue has no loads behind its

@@ -321,6 +321,8 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
     unsigned long long op_base;               // group 0: weights; group 1: dense A (MODE 0)
     unsigned dst0;                            // LDS offset of this wave's first piece inside a slot
     const int conv_bias = p.g.Ws + 1;
+    const bool win2 = p.g.kw == 2;            // 2 x 2 window (a phase of upsample + conv) instead of the 3 x 3 taps: uniform
+    const int KW = win2 ? 2 : 3, KT = win2 ? 4 : 9;
     if constexpr (ROLE == 0) {
         const int pstart = widx * NPB_BASE + (widx < NPB_REM ? widx : NPB_REM);      // first piece of this wave
 #pragma unroll
@@ -342,13 +344,13 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
             else {
                 const int b = m / hw, r = m - b * hw;
                 const int y = r / p.g.Wo;
-                const int cy = y * p.g.stride - p.g.pad, cx = (r - y * p.g.Wo) * p.g.stride - p.g.pad;
+                const int cy = y * p.g.stride - p.g.pad, cx = (r - y * p.g.Wo) * p.g.stride - p.g.pad_x;
                 pixb[q] = (unsigned)((b * p.g.Hs + (cy >> p.g.ups)) * p.g.Ws + (cx >> p.g.ups) + conv_bias);
                 unsigned mk = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int yi = cy + t / 3, xi = cx + t % 3;
-                    if (yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv) mk |= 1u << t;
+                    const int yi = cy + (win2 ? t >> 1 : t / 3), xi = cx + (win2 ? t & 1 : t % 3);
+                    if (t < KT && yi >= 0 && yi < p.g.Hv && xi >= 0 && xi < p.g.Wv) mk |= 1u << t;
                 }
                 if (p.g.ups) mk |= ((unsigned)(cy & 1) << 9) | ((unsigned)(cx & 1) << 10);
                 vmask[q] = mk;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
     const int dC21 = p.g.C2 - p.g.C1, dC43 = p.g.C4 - p.g.C3;             // (differences: arithmetic results cannot be re-materialised as loads)
     const long long gA1 = (long long)p.A, gA3 = (long long)p.A3;
     const long long dA21 = (long long)p.A2 - (long long)p.A, dA43 = (long long)p.A4 - (long long)p.A3;
-    int i_kt = kt_begin, i_tap = kt_begin % 9, i_c0 = (kt_begin / 9) * 64, cs_cur = -1;      // issue-side K position (conv)
+    int i_kt = kt_begin, i_tap = kt_begin % KT, i_c0 = (kt_begin / KT) * 64, cs_cur = -1;      // issue-side K position (conv)
     int d_px = 0, d_row = 0;                  // byte step of the base from one tap to the next: same row / next row
     unsigned vrow[NPA] = {0u, 0u, 0u, 0u};    // conv rows: byte offset of the lane's chunk at the window origin for the current source
     i32x4 r_cur;                              // resource and LDS destination of the step being issued
@@ -402,11 +404,11 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
                         cs = gC3 + (second ? dC43 : 0);
                         ch = second ? c0 - gC3 : c0;
                     }
-                    const int dy = (t_ * 11) >> 5, dx = t_ - dy * 3;    // t_ / 3 for 0 <= t_ < 9
+                    const int dy = win2 ? t_ >> 1 : (t_ * 11) >> 5, dx = t_ - dy * KW;    // (t_ * 11) >> 5 = t_ / 3 for 0 <= t_ < 9
                     const int toff = p.g.ups ? 0 : dy * p.g.Ws + dx;
                     conv_base = (unsigned long long)(src + 2ll * ((long long)(toff - conv_bias) * cs + ch));
                     d_px = p.g.ups ? 0 : cs * 2;
-                    d_row = p.g.ups ? 0 : (p.g.Ws - 2) * cs * 2;
+                    d_row = p.g.ups ? 0 : (p.g.Ws - (KW - 1)) * cs * 2;
                     if (cs != cs_cur || p.g.ups) {                     // the row offsets depend on the source's channel count only (and on the tap when upsampling)
                         cs_cur = cs;
 #pragma unroll
@@ -417,10 +419,10 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
                         }
                     }
                 } else {
-                    conv_base += (unsigned long long)(long long)((i_tap == 3 || i_tap == 6) ? d_row : d_px);
+                    conv_base += (unsigned long long)(long long)((win2 ? i_tap == 2 : (i_tap == 3 || i_tap == 6)) ? d_row : d_px);
                 }
                 ++i_kt;
-                if (++i_tap == 9) { i_tap = 0; i_c0 += 64; }
+                if (++i_tap == KT) { i_tap = 0; i_c0 += 64; }
 #pragma unroll
                 for (int q = 0; q < NPA; ++q)      // halo row: all-ones offset = out of range (two VALU: v_bfe_i32 of the inverted mask, v_or)
                     vo[q] = vrow[q] | (unsigned)__builtin_amdgcn_sbfe((int)~vmask[q], (unsigned)t_, 1u);

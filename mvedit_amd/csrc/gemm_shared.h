@@ -24,6 +24,10 @@ struct ConvGeom {
     // fused 1x1 shortcut (ResnetBlock2D conv2 + conv_shortcut in ONE K loop): after the nk_main tiles of the 3x3 part, K continues
     // over the channels of up to two more NHWC tensors sampled at the output pixel (centre tap); 0 = no shortcut part
     int nk_main, C3, C4;
+    // window: 0 / 3 = the 3 x 3 taps; 2 = a 2 x 2 window (K = 4 C, taps in row-major order) whose origin is (y - pad, x - pad_x): one output-parity
+    // phase of nearest-2x upsample + 3 x 3 conv, see mve_upsample_conv_phases.  2 x 2 windows: ping-pong kernel (gemm_pp.hip) only.
+    int kw;
+    int pad_x;         // columns of zero padding before the first pixel (= pad for every 3 x 3 conv)
 };
 
 struct GemmParams {
@@ -55,6 +59,10 @@ struct GemmParams {
     int tile_n;        // 256-row ping-pong tile only: 0 = widest width that divides N (320 / 256 / 128); 160 = the 160-wide tile (N % 160 == 0),
                        // which the dispatcher picks when the 320-wide tiling would leave CUs without a block (small batches)
     int old_swizzle;   // ping-pong tile only, A/B aid: 1 = round 2's ring swizzle (2-way bank conflicts on every fragment read)
+    // Output rows in groups: row m of out (and out_lo) starts at element m * ldc + (m >> orow_shift) * orow_extra.  orow_extra = 0: plain rows.
+    // The phase convs of mve_upsample_conv_phases write pixel (b, i, j) of a [B][H][W] launch to pixel (b, 2 i + py, 2 j + px) of the [B][2H][2W]
+    // NHWC output: ldc = 2 C, orow_shift = log2 W, orow_extra = 2 W C, base shifted by (py 2 W + px) C.
+    int orow_shift, orow_extra;
     ConvGeom g;
 };
 
@@ -118,8 +126,9 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
         for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
     }
     // (`ok` guards only the stores: callers that keep loads in flight across chunks must not wrap the arithmetic in divergent control flow)
+    const size_t orow = (size_t)m * p.ldc + (size_t)(m >> p.orow_shift) * p.orow_extra;
     if (p.out_f32) {
-        float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+        float* op = reinterpret_cast<float*>(p.out) + orow + n;
         if (ok) {
             *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -128,13 +137,13 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
         V8 pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
-        T* op = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldc + n;
+        T* op = reinterpret_cast<T*>(p.out) + orow + n;
         if (ok) *reinterpret_cast<V8*>(op) = pk;
         if (PAIR && p.out_lo) {
             V8 pl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pl[e] = Tag::from_f32(v[e] - Tag::to_f32(pk[e]));
-            if (ok) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out_lo) + (size_t)m * p.ldc + n) = pl;
+            if (ok) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out_lo) + orow + n) = pl;
         }
     }
 }

@@ -110,6 +110,37 @@ def conv3x3_shortcut(x1, w, B, H, W, x3, x4=None, bias=None, bias2=None, residua
     return out
 
 
+def pack_upsample_phase_weights(w_oihw, dtype=None):
+    """torch conv weight [O, I, 3, 3] of an Upsample2D conv (I % 64 == 0, on the GPU) -> the summed taps of its four 2 x 2 phase convs,
+    [4, O, I/64, 2, 2, 64] in `dtype` (default: the weight's), see mve_upsample_conv_phases."""
+    O, I = w_oihw.shape[:2]
+    dtype = dtype or w_oihw.dtype
+    w = w_oihw.contiguous()
+    w4 = torch.empty(4, O, I // 64, 2, 2, 64, dtype=dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.call('mve_pack_upsample_phase_weights', _DT[w.dtype], _DT[dtype], _lib.ptr(w), O, I, _lib.ptr(w4), _s(w))
+    return w4
+
+
+def upsample_conv_phases_supported(C, Cout, B, H, W):
+    return bool(_lib.raw('mve_upsample_conv_phases_supported')(C, Cout, B, H, W))
+
+
+def upsample_conv_phases(x, w4, B, H, W, bias=None, pair_out=False, splitk=True):
+    """x [B*H*W, C] NHWC, w4 from pack_upsample_phase_weights -> nearest-2x upsample + conv3x3 (pad 1) as [B*2H*2W, Cout] (, low half)."""
+    _chk16(x, w4)
+    C, Cout = x.shape[1], w4.shape[1]
+    assert w4.numel() == 16 * Cout * C
+    out = torch.empty(B * 4 * H * W, Cout, dtype=x.dtype, device=x.device)
+    out_lo = torch.empty_like(out) if pair_out else None
+    nb = _lib.raw('mve_upsample_conv_phases_workspace_bytes')(C, Cout, B, H, W) if splitk else 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+    with torch.cuda.device(x.device):
+        _lib.call('mve_upsample_conv_phases', dt(x), _lib.ptr(x), C, B, H, W, _lib.ptr(w4), Cout, _lib.ptr(out), _lib.ptr(bias), 0,
+                  _lib.ptr(ws), nb, _lib.ptr(out_lo), _s(x))
+    return (out, out_lo) if pair_out else out
+
+
 def pack_conv_weight(w_oihw, chunk64=None):
     """torch conv weight [O, I, 3, 3] -> (packed weight, flag): [O,3,3,I], or [O, I/64, 3, 3, 64] when I % 64 == 0."""
     O, I = w_oihw.shape[:2]

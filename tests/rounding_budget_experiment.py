@@ -27,8 +27,12 @@ class Sites:
             setattr(self, k, ident if off.get(k) else q)
 
 
-def run(sd, cfg, x, t, ctx, q, engine=True, **off):
-    """engine=True: the engine's rounding points (one rounding per fused op); False: PyTorch-half's (every op output)."""
+upsample_conv_phases = UO.upsample_conv_phases
+
+
+def run(sd, cfg, x, t, ctx, q, engine=True, phase_ups=False, **off):
+    """engine=True: the engine's rounding points (one rounding per fused op); False: PyTorch-half's (every op output).
+    phase_ups: the upsampler convs as four 2x2 phase convs whose summed weights are rounded to the storage type."""
     S = Sites(q, **off)
     c = UO._Ctx(sd, cfg, q, None)
 
@@ -117,7 +121,11 @@ def run(sd, cfg, x, t, ctx, q, engine=True, **off):
             if rev('down_attn')[i]:
                 h = transformer(f'up_blocks.{i}.attentions.{j}', h, cx, rev('num_heads')[i], rev('transformer_layers')[i])
         if i < n_lv - 1:
-            h = conv(F.interpolate(op(h), scale_factor=2.0, mode='nearest'), f'up_blocks.{i}.upsamplers.0.conv', qq=S.res)
+            if phase_ups:
+                nm = f'up_blocks.{i}.upsamplers.0.conv'
+                h = S.res(upsample_conv_phases(op(h), c.w(nm + '.weight'), c.w(nm + '.bias'), q))
+            else:
+                h = conv(F.interpolate(op(h), scale_factor=2.0, mode='nearest'), f'up_blocks.{i}.upsamplers.0.conv', qq=S.res)
     h = S.norm(F.silu(F.group_norm(S.bin(h), cfg['norm_num_groups'], c.w('conv_norm_out.weight'), c.w('conv_norm_out.bias'), cfg['norm_eps'])))
     return F.conv2d(h, c.w('conv_out.weight'), c.w('conv_out.bias'), padding=1)
 
@@ -139,6 +147,16 @@ if __name__ == '__main__':
             chk = run(sd, cfg, x, t, ctx, ident)
             print(f'{dt}: re-walk with no rounding vs oracle fp32: {rel(chk):.2e} (must be ~1e-6)', flush=True)
             print(f'  oracle, every op output rounded (PyTorch half)          {rel(UO.unet_forward(sd, cfg, x, t, ctx, q=q)):.3e}', flush=True)
+            if '--phase' in sys.argv:
+                xx = torch.randn(2, 8, 5, 6)
+                ww, bb = torch.randn(4, 8, 3, 3), torch.randn(4)
+                d = (upsample_conv_phases(xx, ww, bb) - F.conv2d(F.interpolate(xx, scale_factor=2.0), ww, bb, padding=1)).abs().max()
+                print(f'  phase decomposition vs upsample + conv, fp32: max |diff| {float(d):.1e}')
+                for label, off in [('engine', {}), ('engine + pair + pair-reading norms', dict(res=1, bin=1))]:
+                    a = rel(run(sd, cfg, x, t, ctx, q, True, **off))
+                    b = rel(run(sd, cfg, x, t, ctx, q, True, phase_ups=True, **off))
+                    print(f'  {label:40s} 3x3 on the upsampled input {a:.3e}   four 2x2 phase convs, summed weights rounded {b:.3e}', flush=True)
+                continue
             for label, eng, off in [
                 ('PyTorch-half rounding points (re-walk)', False, {}),
                 ('engine rounding points', True, {}),

@@ -152,6 +152,21 @@ def test_slice_decisions_of_the_gemm_dispatcher():
         tune(old)
 
 
+def test_upsample_phase_conv_shape_rule():
+    """mve_upsample_conv_phases_supported: a function of the shape -- 64-channel slabs, an output width the 256-row tiles come in (multiples of
+    128), a power-of-two source width (grouped output rows), at least 64 source pixels in the launch."""
+    from mvedit_amd import _lib
+    ok = _lib.raw('mve_upsample_conv_phases_supported')
+    for C, H in ((1280, 8), (1280, 16), (640, 32)):            # the UNet's three upsamplers at a 64 x 64 latent, any batch
+        assert all(ok(C, C, B, H, H) == 1 for B in (1, 2, 64))
+    for C, H in ((512, 64), (512, 128), (256, 256)):           # the VAE decoder's at 512 x 512
+        assert ok(C, C, 1, H, H) == 1
+    assert ok(1280, 1280, 1, 4, 4) == 0 and ok(1280, 1280, 4, 4, 4) == 1        # 16 source pixels per image: from batch 4 on
+    assert ok(1280, 1280, 2, 12, 12) == 0                      # 96 x 96 latent: source width 12
+    assert ok(96, 128, 2, 8, 8) == 0 and ok(128, 200, 2, 8, 8) == 0
+    assert _lib.raw('mve_upsample_conv_phases_workspace_bytes')(1280, 1280, 2, 8, 8) == _lib.raw('mve_gemm_workspace_bytes')(128, 1280, 5120, 64)
+
+
 def test_residual_pair_is_a_plan_option(lib):
     """mve_unet_set_residual_mode (plan-time only, no GPU): the pair mode doubles the residual-stream tensors of the workspace, keeps the op list,
     round-trips, and is refused by the non-UNet executors."""
@@ -160,8 +175,14 @@ def test_residual_pair_is_a_plan_option(lib):
     eng = UNet2DConditionEngine(SD15_CONFIG, torch.float16, device='cpu')
     a = eng.plan(2, 64, 64, 77)
     assert eng.residual_pair is False and eng.set_residual_pair(True) is False and eng.residual_pair is True
+    ups_a = [(lab, fl) for _, _, fl, lab in eng.op_table() if lab.startswith('upsample+conv')]
     b = eng.plan(2, 64, 64, 77)
-    assert b['n_ops'] == a['n_ops'] and b['flops'] == a['flops']
+    ups_b = [(lab, fl) for _, _, fl, lab in eng.op_table() if lab.startswith('upsample+conv')]
+    # the default plan runs Upsample2D as four 2 x 2 phase convs (4 / 9 of the flops); the pair (accuracy) mode keeps the reference's 3 x 3 form
+    assert [l for l, _ in ups_a] == ['upsample+conv (4 phases)'] * 3 and [l for l, _ in ups_b] == ['upsample+conv'] * 3
+    assert all(abs(fa * 9 - fb * 4) <= 1e-6 * fb for (_, fa), (_, fb) in zip(ups_a, ups_b))
+    assert b['n_ops'] == a['n_ops']
+    assert {k: v for k, v in b['flops'].items() if k != 'conv3x3'} == {k: v for k, v in a['flops'].items() if k != 'conv3x3'}
     assert a['workspace_bytes'] < b['workspace_bytes'] < 2 * a['workspace_bytes']
     assert eng.set_residual_pair(False) is True and eng.plan(2, 64, 64, 77)['workspace_bytes'] == a['workspace_bytes']
     from mvedit_amd.vae import AutoencoderKLEngine, SD_VAE_CONFIG

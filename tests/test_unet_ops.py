@@ -512,6 +512,46 @@ def test_conv3x3_big_tiles_and_upsample_addressing(lib, dtype, B, H, W, C1, C2, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('B,H,W,C,Cout', [
+    (2, 8, 8, 128, 320),          # one partial 256-row tile per phase
+    (4, 16, 16, 64, 128),         # the 128-wide tile (VAE, image resolution), whole tiles, one 64-channel slab
+    (1, 32, 32, 64, 256),         # the 256-wide tile; rows of a tile span 8 source rows
+    (3, 16, 8, 192, 640),         # non-square, W = 8: a tile spans 32 source rows, ragged last tile
+    (2, 8, 8, 1280, 1280),        # the 8 x 8 level of the UNet: K = 5120 in slices + reducer
+    (1, 4, 256, 64, 128),         # a source row longer than a tile would be split; here W = 256 = one tile per source row
+])
+def test_upsample_conv_phases(lib, dtype, B, H, W, C, Cout):
+    """Upsample2D as four 2 x 2 phase convs (mve_upsample_conv_phases): (a) the packed summed taps are the oracle's, bit for bit; (b) the output against
+    the oracle's phase form on those rounded weights: the usual conv tolerance; (c) against nearest-2x + conv 3x3 on the original weights (what the
+    reference computes): the extra weight rounding stays inside the same tolerance; (d) the residual-pair output."""
+    from mvedit_amd import ops
+    from oracle import unet_oracle as UO
+    x = rnd((B, C, H, W), dtype, 1)
+    w = rnd((Cout, C, 3, 3), dtype, 3, (9 * C) ** -0.5)
+    bias = rnd((Cout,), torch.float32, 4)
+    assert ops.upsample_conv_phases_supported(C, Cout, B, H, W)
+    w4 = ops.pack_upsample_phase_weights(w.cuda())
+    q = UO.quantizer(dtype)
+    ref4 = UO.upsample_phase_weights(w, q)
+    for py in (0, 1):
+        for px in (0, 1):
+            want = ref4[py][px].reshape(Cout, C // 64, 64, 2, 2).permute(0, 1, 3, 4, 2).to(dtype)        # [O][I/64][2][2][64]
+            assert torch.equal(w4[2 * py + px].cpu(), want), (py, px)
+    out = ops.upsample_conv_phases(to_nhwc(x).cuda(), w4, B, H, W, bias=bias.cuda())
+    assert out.shape == (B * 4 * H * W, Cout)
+    check('upsample phases vs oracle phases', out, to_nhwc(UO.upsample_conv_phases(x, w, bias, q)), dtype, f'{(B, H, W, C, Cout)}')
+    check('upsample phases vs upsample + conv3x3', out, to_nhwc(conv_ref(x, w, bias, 1, True)), dtype, f'{(B, H, W, C, Cout)}')
+    if Cout % 320 == 0:
+        hi, lo = ops.upsample_conv_phases(to_nhwc(x).cuda(), w4, B, H, W, bias=bias.cuda(), pair_out=True)
+        v = to_nhwc(UO.upsample_conv_phases(x, w, bias, q))
+        check('upsample phases, pair hi', hi, v, dtype)
+        err_pair = float(((hi.float() + lo.float()).cpu() - v).norm() / v.norm())
+        err_hi = float((hi.float().cpu() - v).norm() / v.norm())
+        assert err_pair < 0.25 * err_hi, (err_pair, err_hi)
+
+
+@pytest.mark.gpu
 def test_gemm_256_wide_tile_matches_small_kernel(lib):
     from mvedit_amd import ops, _lib
     dtype = torch.float16
