@@ -242,6 +242,11 @@ MVE_API int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* 
  * Needs C % 64 == 0, Cout a multiple of 128, Ws a power of two, B Hs Ws >= 64 (mve_upsample_conv_phases_supported = 1); four launches of the
  * ping-pong kernel (2 x 2 window, grouped output rows), K slices as for any conv of that shape (workspace: *_workspace_bytes). */
 MVE_API int mve_upsample_conv_phases_supported(int C, int Cout, int B, int Hs, int Ws);
+/* Where B Hs Ws is a multiple of 256 the four phases run as ONE launch of 4 B Hs Ws rows (the phases share the chip like the tiles of any conv: 64
+ * images at the 8 x 8 level = one block per CU in one accumulation chain instead of 4 x (64 tiles x 4 K slices + reducer)); same arithmetic per
+ * element up to the K-slice policy.  mve_upsample_conv_phases_tune(0): always four launches (A/B; env MVE_PHASES_ONE_LAUNCH); negative: query;
+ * returns the previous value. */
+MVE_API int mve_upsample_conv_phases_tune(int one_launch);
 MVE_API size_t mve_upsample_conv_phases_workspace_bytes(int C, int Cout, int B, int Hs, int Ws);
 MVE_API int mve_pack_upsample_phase_weights(int src_dtype, int dst_dtype, const void* d_w_oihw, int Cout, int C, void* d_W4, void* stream);
 MVE_API int mve_upsample_conv_phases(int dtype, const void* d_x, int C, int B, int Hs, int Ws, const void* d_W4, int Cout, void* d_out,

@@ -118,7 +118,9 @@ struct Builder {
         const size_t skb = mve_upsample_conv_phases_workspace_bytes(C, C, Bn, H, W);
         Ref sk = skb ? ws(skb) : Ref();
         const Ref W4 = wt(slot + ".w4"), bias = wt(slot + ".b"), out_lo = lo(out);
-        op(OC_CONV, 2.0 * Bn * (4.0 * H * W) * (double)C * 4 * C, what, [=](const Run& r) {
+        // (flops: the op's ALGORITHMIC count -- the 3 x 3 conv over the upsampled image the reference computes, SURVEY.md 8(d) -- of which this form
+        // executes 4 / 9; bench.py reports both)
+        op(OC_CONV, 2.0 * Bn * (4.0 * H * W) * (double)C * 9 * C, what, [=](const Run& r) {
             return mve_upsample_conv_phases(d, r.p(x), C, Bn, H, W, r.p(W4), C, r.p(out), (const float*)r.p(bias), 0, r.p(sk), skb, r.p(out_lo), r.stream);
         });
         rel(sk);

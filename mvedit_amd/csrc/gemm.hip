@@ -738,8 +738,18 @@ int mve_upsample_conv_phases_supported(int C, int Cout, int B, int Hs, int Ws) {
     return 1;
 }
 
+/* 1 (default; MVE_PHASES_ONE_LAUNCH): the four phases run as one launch where a phase fills whole tiles; 0: always four launches.  Negative: query.
+ * Returns the previous value. */
+int mve_upsample_conv_phases_tune(int one_launch) {
+    static int cur = -1;
+    if (cur < 0) { const char* e = getenv("MVE_PHASES_ONE_LAUNCH"); cur = e ? (atoi(e) != 0) : 1; }
+    const int old = cur;
+    if (one_launch >= 0) cur = one_launch ? 1 : 0;
+    return old;
+}
+
 size_t mve_upsample_conv_phases_workspace_bytes(int C, int Cout, int B, int Hs, int Ws) {
-    return mve_gemm_workspace_bytes(B * Hs * Ws, Cout, 4 * C, Hs * Ws);
+    return mve_gemm_workspace_bytes(4 * B * Hs * Ws, Cout, 4 * C, Hs * Ws);      // (the four phases may run as one launch of 4 B Hs Ws rows)
 }
 
 int mve_upsample_conv_phases(int dtype, const void* x, int C, int B, int Hs, int Ws, const void* W4, int Cout, void* out, const float* bias,
@@ -752,7 +762,12 @@ int mve_upsample_conv_phases(int dtype, const void* x, int C, int B, int Hs, int
     MVE_CHECK(dtype == MVE_F16 || dtype == MVE_BF16, MVE_ERR_ARG, "upsample_conv_phases: unsupported dtype %d", dtype);
     int lw = 0;
     while ((1 << lw) < Ws) ++lw;
-    for (int ph = 0; ph < 4; ++ph) {
+    // All four phases in ONE launch when the rows of a phase fill whole 256-row tiles (ConvGeom::phase_rows): the phases then share the chip
+    // like the tiles of any conv (64 images at the 8 x 8 level: 4 x 64 tiles = one block per CU in a single accumulation chain, instead of four
+    // launches of 64 tiles x 4 K slices and four reducers; 8 images per rank: 2 launches instead of 8).  Same arithmetic per output element either
+    // way up to the K-slice policy.  MVE_PHASES_ONE_LAUNCH=0: always four launches (A/B).
+    const bool fused = mve_upsample_conv_phases_tune(-1) && (B * Hs * Ws) % 256 == 0;
+    for (int ph = 0; ph < (fused ? 1 : 4); ++ph) {
         const int py = ph >> 1, px = ph & 1;
         GemmParams p;
         memset(&p, 0, sizeof(p));
@@ -764,6 +779,7 @@ int mve_upsample_conv_phases(int dtype, const void* x, int C, int B, int Hs, int
         p.g.C1 = C;
         p.g.chunk64 = 1;
         p.M = B * Hs * Ws; p.N = Cout; p.K = 4 * C;
+        if (fused) { p.g.phase_rows = p.M; p.M *= 4; }
         p.A = x;
         p.W = (const char*)W4 + (size_t)ph * Cout * p.K * 2;
         const size_t o0 = ((size_t)py * 2 * Ws + px) * Cout * 2;       // bytes: pixel (py, px) of image 0

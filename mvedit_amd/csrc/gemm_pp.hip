@@ -333,6 +333,9 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
         }
         if (NPB_REM && widx >= NPB_REM) vo[NPB - 1] = 0xFFFFFFFFu;                    // filler piece: out of range, zeros
         op_base = (unsigned long long)p.W + (unsigned long long)kt_begin * (BK * 2);
+        if constexpr (MODE == 1) {             // all four phases in one launch: this tile's phase picks its weight block
+            if (p.g.phase_rows > 0) op_base += (unsigned long long)(m0 / p.g.phase_rows) * ((unsigned long long)p.N * p.ldw * 2ull);
+        }
         dst0 = smem_base + P_A_SLOT + pstart * 1024;
     } else {
         const int hw = p.g.Ho * p.g.Wo;
@@ -342,9 +345,15 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
             m = m < p.M ? m : p.M - 1;
             if constexpr (MODE == 0) vo[q] = (unsigned)m * (unsigned)p.lda * 2u + c16;
             else {
+                int pad_y = p.g.pad, pad_x = p.g.pad_x;
+                if (p.g.phase_rows > 0) {              // rows [ph R, (ph + 1) R): phase ph of the upsampler
+                    const int ph = conv_phase_of(m, p.g.phase_rows);
+                    m -= ph * p.g.phase_rows;
+                    pad_y = 1 - (ph >> 1); pad_x = 1 - (ph & 1);
+                }
                 const int b = m / hw, r = m - b * hw;
                 const int y = r / p.g.Wo;
-                const int cy = y * p.g.stride - p.g.pad, cx = (r - y * p.g.Wo) * p.g.stride - p.g.pad_x;
+                const int cy = y * p.g.stride - pad_y, cx = (r - y * p.g.Wo) * p.g.stride - pad_x;
                 pixb[q] = (unsigned)((b * p.g.Hs + (cy >> p.g.ups)) * p.g.Ws + (cx >> p.g.ups) + conv_bias);
                 unsigned mk = 0;
 #pragma unroll
@@ -676,7 +685,9 @@ bool pp_eligible(int mode, const GemmParams& p) {
     if (mode == 0) return pp_fits((unsigned long long)p.M * p.lda * 2);
     if (!p.g.chunk64) return false;
     const int hw = p.g.Ho * p.g.Wo;
-    const unsigned long long px = (unsigned long long)((p.M + hw - 1) / hw) * p.g.Hs * p.g.Ws + 2ull * p.g.Ws + 4;
+    if (p.g.phase_rows > 0 && (p.g.kw != 2 || p.g.phase_rows % PBM != 0 || p.M != 4 * p.g.phase_rows)) return false;
+    const int m_img = p.g.phase_rows > 0 ? p.g.phase_rows : p.M;      // rows that address distinct source pixels
+    const unsigned long long px = (unsigned long long)((m_img + hw - 1) / hw) * p.g.Hs * p.g.Ws + 2ull * p.g.Ws + 4;
     int cmax = p.g.C1 > p.g.C2 ? p.g.C1 : p.g.C2;
     cmax = cmax > p.g.C3 ? cmax : p.g.C3;
     cmax = cmax > p.g.C4 ? cmax : p.g.C4;

@@ -28,7 +28,14 @@ struct ConvGeom {
     // phase of nearest-2x upsample + 3 x 3 conv, see mve_upsample_conv_phases.  2 x 2 windows: ping-pong kernel (gemm_pp.hip) only.
     int kw;
     int pad_x;         // columns of zero padding before the first pixel (= pad for every 3 x 3 conv)
+    // phase_rows = R > 0 (2 x 2 windows only): ONE launch computes all four phases -- its M = 4 R rows are [phase][image][y][x], rows
+    // [ph R, (ph + 1) R) take pad = 1 - (ph >> 1), pad_x = 1 - (ph & 1) and the weights W + ph N ldw, and write through the grouped output rows
+    // shifted by ((ph >> 1) * orow_extra + (ph & 1) * ldc / 2).  R is a multiple of 256: a tile never straddles two phases.
+    int phase_rows;
 };
+
+// phase of row m in a phase_rows launch (0 otherwise) -- three compares, no division
+__device__ __forceinline__ int conv_phase_of(int m, int R) { return R > 0 ? (int)(m >= R) + (int)(m >= 2 * R) + (int)(m >= 3 * R) : 0; }
 
 struct GemmParams {
     const void* A;     // dense A [M][lda]  or conv source 1 (NHWC)
@@ -126,7 +133,11 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
         for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
     }
     // (`ok` guards only the stores: callers that keep loads in flight across chunks must not wrap the arithmetic in divergent control flow)
-    const size_t orow = (size_t)m * p.ldc + (size_t)(m >> p.orow_shift) * p.orow_extra;
+    size_t orow;
+    if (p.g.phase_rows > 0) {            // (uniform branch: the four phases of mve_upsample_conv_phases in one launch)
+        const int ph = conv_phase_of(m, p.g.phase_rows), mm = m - ph * p.g.phase_rows;
+        orow = (size_t)mm * p.ldc + (size_t)((mm >> p.orow_shift) + (ph >> 1)) * p.orow_extra + (size_t)(ph & 1) * (p.ldc >> 1);
+    } else orow = (size_t)m * p.ldc + (size_t)(m >> p.orow_shift) * p.orow_extra;
     if (p.out_f32) {
         float* op = reinterpret_cast<float*>(p.out) + orow + n;
         if (ok) {

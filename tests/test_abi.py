@@ -164,7 +164,7 @@ def test_upsample_phase_conv_shape_rule():
     assert ok(1280, 1280, 1, 4, 4) == 0 and ok(1280, 1280, 4, 4, 4) == 1        # 16 source pixels per image: from batch 4 on
     assert ok(1280, 1280, 2, 12, 12) == 0                      # 96 x 96 latent: source width 12
     assert ok(96, 128, 2, 8, 8) == 0 and ok(128, 200, 2, 8, 8) == 0
-    assert _lib.raw('mve_upsample_conv_phases_workspace_bytes')(1280, 1280, 2, 8, 8) == _lib.raw('mve_gemm_workspace_bytes')(128, 1280, 5120, 64)
+    assert _lib.raw('mve_upsample_conv_phases_workspace_bytes')(1280, 1280, 2, 8, 8) == _lib.raw("mve_gemm_workspace_bytes")(4 * 128, 1280, 5120, 64)
 
 
 def test_residual_pair_is_a_plan_option(lib):
@@ -178,11 +178,10 @@ def test_residual_pair_is_a_plan_option(lib):
     ups_a = [(lab, fl) for _, _, fl, lab in eng.op_table() if lab.startswith('upsample+conv')]
     b = eng.plan(2, 64, 64, 77)
     ups_b = [(lab, fl) for _, _, fl, lab in eng.op_table() if lab.startswith('upsample+conv')]
-    # the default plan runs Upsample2D as four 2 x 2 phase convs (4 / 9 of the flops); the pair (accuracy) mode keeps the reference's 3 x 3 form
+    # the default plan runs Upsample2D as four 2 x 2 phase convs (4 / 9 of the multiply-adds); the pair (accuracy) mode keeps the reference's 3 x 3 form
     assert [l for l, _ in ups_a] == ['upsample+conv (4 phases)'] * 3 and [l for l, _ in ups_b] == ['upsample+conv'] * 3
-    assert all(abs(fa * 9 - fb * 4) <= 1e-6 * fb for (_, fa), (_, fb) in zip(ups_a, ups_b))
-    assert b['n_ops'] == a['n_ops']
-    assert {k: v for k, v in b['flops'].items() if k != 'conv3x3'} == {k: v for k, v in a['flops'].items() if k != 'conv3x3'}
+    assert [f for _, f in ups_a] == [f for _, f in ups_b]          # the plan prices an op at the reference's form of it either way
+    assert b['n_ops'] == a['n_ops'] and b['flops'] == a['flops']
     assert a['workspace_bytes'] < b['workspace_bytes'] < 2 * a['workspace_bytes']
     assert eng.set_residual_pair(False) is True and eng.plan(2, 64, 64, 77)['workspace_bytes'] == a['workspace_bytes']
     from mvedit_amd.vae import AutoencoderKLEngine, SD_VAE_CONFIG

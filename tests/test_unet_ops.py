@@ -520,6 +520,7 @@ def test_conv3x3_big_tiles_and_upsample_addressing(lib, dtype, B, H, W, C1, C2, 
     (3, 16, 8, 192, 640),         # non-square, W = 8: a tile spans 32 source rows, ragged last tile
     (2, 8, 8, 1280, 1280),        # the 8 x 8 level of the UNet: K = 5120 in slices + reducer
     (1, 4, 256, 64, 128),         # a source row longer than a tile would be split; here W = 256 = one tile per source row
+    (8, 8, 8, 1280, 1280),        # 8 images at the 8 x 8 level: the four phases in ONE launch of 2048 rows, K in slices + one reducer
 ])
 def test_upsample_conv_phases(lib, dtype, B, H, W, C, Cout):
     """Upsample2D as four 2 x 2 phase convs (mve_upsample_conv_phases): (a) the packed summed taps are the oracle's, bit for bit; (b) the output against
@@ -540,6 +541,17 @@ def test_upsample_conv_phases(lib, dtype, B, H, W, C, Cout):
             assert torch.equal(w4[2 * py + px].cpu(), want), (py, px)
     out = ops.upsample_conv_phases(to_nhwc(x).cuda(), w4, B, H, W, bias=bias.cuda())
     assert out.shape == (B * 4 * H * W, Cout)
+    if (B * H * W) % 256 == 0:        # that was one launch for the four phases: four launches give the same elements (same K chain unless K is sliced)
+        from mvedit_amd import _lib
+        old = _lib.raw('mve_upsample_conv_phases_tune')(0)
+        try:
+            out4 = ops.upsample_conv_phases(to_nhwc(x).cuda(), w4, B, H, W, bias=bias.cuda())
+        finally:
+            _lib.raw('mve_upsample_conv_phases_tune')(old)
+        if C < 1280:
+            assert torch.equal(out, out4)
+        else:
+            check('one launch vs four launches (different K slices)', out, out4.float(), dtype)
     check('upsample phases vs oracle phases', out, to_nhwc(UO.upsample_conv_phases(x, w, bias, q)), dtype, f'{(B, H, W, C, Cout)}')
     check('upsample phases vs upsample + conv3x3', out, to_nhwc(conv_ref(x, w, bias, 1, True)), dtype, f'{(B, H, W, C, Cout)}')
     if Cout % 320 == 0:

@@ -77,7 +77,7 @@ def test_plan_flops_and_parameter_inventory(lib):
     assert _lib.raw('mve_unet_missing_params')(dec._h, buf, 256) == sum(k.startswith(('decoder.', 'post_quant_conv.')) for k in names)
     assert _lib.raw('mve_unet_missing_params')(enc._h, buf, 256) == sum(k.startswith(('encoder.', 'quant_conv.')) for k in names)
     labels = [lab for _, _, lab in dec.op_table()]
-    assert labels.count('vae attention.softmax') == 8 and labels.count('upsample+conv') == 3
+    assert labels.count('vae attention.softmax') == 8 and labels.count('upsample+conv (4 phases)') == 3
     assert [lab for _, _, lab in enc.op_table()].count('downsample (pad bottom/right)') == 3
     with pytest.raises(_lib.MveError):
         dec.plan(32, 64, 64, torch.float16)                      # 2^31 elements at 512 x 512 x 256: must be chunked

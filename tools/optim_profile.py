@@ -89,7 +89,41 @@ print(f'nerf_optim iteration, {ps * ps * P} rays, {ns} samples after culling; sy
       ', '.join(f'{n} {a / N * 1e3:.3f}' for n, a in zip(names, acc)) + f'; sum {sum(acc) / N * 1e3:.3f}')
 sync()
 t0 = time.perf_counter()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
 for _ in range(N):
     it(False, [0.0] * 6)
+ev1.record()
+t_host = time.perf_counter() - t0           # the host has enqueued everything; how much is still running says who is ahead
 sync()
-print(f'un-synchronised iteration: {(time.perf_counter() - t0) / N * 1e3:.3f} ms')
+t_all = time.perf_counter() - t0
+print(f'un-synchronised iteration: {t_all / N * 1e3:.3f} ms; host enqueue time {t_host / N * 1e3:.3f} ms per iteration '
+      f'({"host-bound: the queue is empty when the host finishes" if t_host > 0.97 * t_all else "device-bound"}); device span {ev0.elapsed_time(ev1) / N:.3f} ms')
+if os.environ.get('MVE_OPTIM_CPROFILE'):
+    # where the HOST spends an iteration (the loop is host-bound: two device->host reads per iteration, as in the reference, keep the queue short)
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(N):
+        it(False, [0.0] * 6)
+    sync()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats('cumulative').print_stats(45)
+    st.sort_stats('tottime').print_stats(30)
+if os.environ.get('MVE_OPTIM_COUNT'):
+    # launches per iteration as the device sees them: kernel count from a short kineto trace
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(4):
+            it(False, [0.0] * 6)
+        sync()
+    ev = [e for e in prof.events() if e.device_type.name == 'CUDA']
+    busy = sum(e.device_time for e in ev) if ev and hasattr(ev[0], 'device_time') else sum(e.cuda_time for e in ev)
+    print(f'kineto: {len(ev) / 4:.0f} device activities per iteration, device busy {busy / 4 / 1e3:.3f} ms per iteration')
+    agg = {}
+    for e in ev:
+        a = agg.setdefault(e.name[:60], [0, 0.0]); a[0] += 1; a[1] += getattr(e, 'device_time', None) or e.cuda_time
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f'   {k:60s} x{n / 4:5.1f}  {t / 4:8.1f} us')
