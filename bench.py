@@ -870,6 +870,9 @@ def main():
             except Exception as e:
                 line['parity'] = {'error': repr(e)[:300]}
         line['config']['residual_stream'] = 'unrounded (hi, lo) pair' if args.residual_pair else '16-bit (as the reference)'
+        phases = not args.residual_pair and os.environ.get('MVE_UPSAMPLE_PHASES', '1') != '0'
+        line['config']['upsample2d'] = ('four 2x2 phase convs over the source (summed 3x3 taps rounded once to the storage type; 4/9 of the multiply-adds)'
+                                        if phases else '3x3 conv over the nearest-upsampled image (as the reference)')
         if world == 1 and not args.no_extra and wl == 'mvedit32' and dtype == torch.float16 and not args.residual_pair:
             # the other configurations BASELINE.json names, and the two other numeric modes, as compact driver-visible lines (3 steps each)
             del eng
