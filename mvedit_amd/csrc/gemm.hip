@@ -749,7 +749,7 @@ int mve_upsample_conv_phases_tune(int one_launch) {
 }
 
 size_t mve_upsample_conv_phases_workspace_bytes(int C, int Cout, int B, int Hs, int Ws) {
-    return mve_gemm_workspace_bytes(4 * B * Hs * Ws, Cout, 4 * C, Hs * Ws);      // (the four phases may run as one launch of 4 B Hs Ws rows)
+    return mve_gemm_workspace_bytes(4 * B * Hs * Ws, Cout, 4 * C, 4 * Hs * Ws);      // (the four phases of an image are 4 Hs Ws rows of one launch)
 }
 
 int mve_upsample_conv_phases(int dtype, const void* x, int C, int B, int Hs, int Ws, const void* W4, int Cout, void* out, const float* bias,
@@ -794,7 +794,10 @@ int mve_upsample_conv_phases(int dtype, const void* x, int C, int B, int Hs, int
         if (rc) return rc;
         p.splitk = 1;
         if (workspace && !(flags & MVE_GEMM_NO_SPLITK)) {
-            const int sk = choose_splitk(Hs * Ws, p.N, p.K);
+            // The slice rule sees an image as the 4 Hs Ws rows its four phases put into a launch (whether or not they share one): K = 4 C is short
+            // and the launch is four times an ordinary conv's rows, so the rule stops slicing from the 16 x 16 level up -- and a view gets the same
+            // slices alone or in a batch until the batch fills the chip (tests/test_unet.py::test_engine_sd15_full_size_properties).
+            const int sk = choose_splitk(4 * Hs * Ws, p.N, p.K);
             if (sk > 1 && workspace_bytes >= (size_t)sk * p.M * p.N * sizeof(float)) { p.splitk = sk; p.partial = (float*)workspace; }
         }
         rc = dtype == MVE_F16 ? launch_phase<F16Tag>(p, (hipStream_t)stream) : launch_phase<BF16Tag>(p, (hipStream_t)stream);

@@ -164,7 +164,7 @@ def test_upsample_phase_conv_shape_rule():
     assert ok(1280, 1280, 1, 4, 4) == 0 and ok(1280, 1280, 4, 4, 4) == 1        # 16 source pixels per image: from batch 4 on
     assert ok(1280, 1280, 2, 12, 12) == 0                      # 96 x 96 latent: source width 12
     assert ok(96, 128, 2, 8, 8) == 0 and ok(128, 200, 2, 8, 8) == 0
-    assert _lib.raw('mve_upsample_conv_phases_workspace_bytes')(1280, 1280, 2, 8, 8) == _lib.raw("mve_gemm_workspace_bytes")(4 * 128, 1280, 5120, 64)
+    assert _lib.raw('mve_upsample_conv_phases_workspace_bytes')(1280, 1280, 2, 8, 8) == _lib.raw("mve_gemm_workspace_bytes")(4 * 128, 1280, 5120, 4 * 64)
 
 
 def test_residual_pair_is_a_plan_option(lib):
