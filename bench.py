@@ -565,7 +565,7 @@ def outer_step(dev, n_optim_timed=24):
             loss = loss + 0.3 * lp(res['out_rgbs'].permute(0, 3, 1, 2), tgt_rgb.permute(0, 3, 1, 2)).mean()
         loss.backward()
         opt.step()
-    ms, _ = timed(nerf_iter, it=n_optim_timed, warm=4)        # (few iterations after a short warm-up read higher than tools/optim_profile.py's 30-iteration loop of the same composition)
+    ms, _ = timed(nerf_iter, it=n_optim_timed, warm=4)
     out['nerf_optim_iter_ms'] = round(ms, 3)
     if lp is not None:
         a = torch.rand(8, 3, 128, 128, device=dev, requires_grad=True)
