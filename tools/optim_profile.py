@@ -50,7 +50,9 @@ lights = torch.nn.functional.normalize(torch.tensor([[0.3, -0.5, -1.0]], device=
 tgt_m = torch.rand(P, ps, ps, 1, generator=g).to(dev)
 tgt_rgb = torch.rand(P, ps, ps, 3, generator=g).to(dev)
 lp = LPIPSEngine.from_state_dict({k: v.to(torch.bfloat16).float() for k, v in SY.make_lpips_state_dict().items()}, torch.bfloat16, device=dev)
-opt = torch.optim.Adam(list(dec.parameters().values()), lr=1e-2, eps=1e-15)
+# MVE_OPTIM_LR=0 freezes the scene (Adam does the same work, the parameters do not move): the sample count after culling stays what it is, so
+# that loops timed one after the other in this process see the same workload
+opt = torch.optim.Adam(list(dec.parameters().values()), lr=float(os.environ.get('MVE_OPTIM_LR', '1e-2')), eps=1e-15)
 sync = torch.cuda.synchronize
 
 
@@ -79,6 +81,50 @@ def it(split, acc):
     return int(o['weights'].shape[0])
 
 
+if os.environ.get('MVE_OPTIM_WITH_ENGINES'):
+    # the iteration inside a process that also holds the outer step's big engines (bench.py's outer_step, the real pipeline): does their presence
+    # (allocator state, garbage-collector load, clocks after a heavy launch sequence) change the host-paced iteration?  Run with MVE_OPTIM_LR=0.
+    import gc
+    from mvedit_amd.unet import SD15_CONFIG, UNet2DConditionEngine
+    from mvedit_amd.vae import AutoencoderKLEngine, SD_VAE_CONFIG
+
+    def loop(n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ns_ = it(False, [0.0] * 6)
+        sync()
+        return (time.perf_counter() - t0) / n * 1e3, ns_
+    loop(6)
+    print('before the engines exist: %.3f ms per iteration (%d samples); gc objects %d' % (*loop(N), len(gc.get_objects())), flush=True)
+    unet = UNet2DConditionEngine.from_state_dict(SY.make_state_dict(dict(SD15_CONFIG), seed=1234, dtype=torch.float16), dict(SD15_CONFIG), torch.float16, 'cuda')
+    xx = torch.randn(64, 4, 64, 64, device=dev, dtype=torch.float16)
+    cc = torch.randn(64, 77, 768, device=dev, dtype=torch.float16)
+    for _ in range(3):
+        unet(xx, 499, cc)
+    vae = AutoencoderKLEngine.from_state_dict(SY.make_vae_state_dict(dict(SD_VAE_CONFIG), dtype=torch.float16), dict(SD_VAE_CONFIG), torch.float16, dev)
+    vae.decoder.run(xx[:8], 8)
+    sync()
+    print('engines resident:', round(torch.cuda.memory_allocated() / 2 ** 30, 2), 'GiB allocated,', round(torch.cuda.memory_reserved() / 2 ** 30, 2), 'GiB reserved; gc objects',
+          len(gc.get_objects()), flush=True)
+    loop(4)
+    st0 = torch.cuda.memory_stats()
+    a, ns_ = loop(N)
+    st1 = torch.cuda.memory_stats()
+    print(f'with engines resident: {a:.3f} ms per iteration ({ns_} samples); device mallocs during the loop {st1["num_device_alloc"] - st0["num_device_alloc"]}, '
+          f'alloc retries {st1["num_alloc_retries"] - st0["num_alloc_retries"]}', flush=True)
+    gc.disable()
+    print('same with the garbage collector off: %.3f ms (%d samples)' % loop(N), flush=True)
+    gc.enable()
+    print('garbage collector on again: %.3f ms (%d samples)' % loop(N), flush=True)
+    for _ in range(2):
+        unet(xx, 499, cc)                      # a heavy launch sequence right before: clocks / power state
+    print('right after two 64-image UNet forwards: %.3f ms (%d samples)' % loop(N), flush=True)
+    del unet, vae, xx, cc
+    gc.collect()
+    torch.cuda.empty_cache()
+    print('engines released: %.3f ms (%d samples)' % loop(N), flush=True)
+    sys.exit(0)
 names = ['zero_grad', 'forward (march, cull, decode, composite)', 'losses', 'LPIPS patch', 'backward', 'Adam']
 for _ in range(3):
     ns = it(True, [0.0] * 6)
