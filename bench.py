@@ -499,7 +499,12 @@ def outer_step(dev, n_optim_timed=24):
     ctrl_dep = torch.rand(V, 3, S, S, generator=g).to(dev, f16)
     two = lambda x: torch.cat([x, x], 0)
     t_step = torch.full((2 * V,), 499.0, device=dev)
-    ms, noise = timed(lambda: pipe.get_noise_pred([two(lat)], [ctx], [two(ctrl_img)], [two(ctrl_dep)], t_step, 1.0, 1.0, GUIDANCE))
+    # the reference's call (mvedit_3d_pipeline.py:1226-1249, diff_bs 6): latents and embeddings of both CFG halves in chunks of 6, the control
+    # images of the second half being the SAME tensors as the first (`.split(diff_bs) * 2`); the mixin fuses the chunks into one 64-image launch
+    # and the ControlNet engines embed each control image once for both halves
+    DIFF_BS = 6
+    ms, noise = timed(lambda: pipe.get_noise_pred(list(two(lat).split(DIFF_BS)), list(ctx.split(DIFF_BS)), list(ctrl_img.split(DIFF_BS)) * 2,
+                                                  list(ctrl_dep.split(DIFF_BS)) * 2, t_step, 1.0, 1.0, GUIDANCE))
     out['noise_pred_unet_2_controlnets_ms'] = round(ms, 2)
 
     def decode():

@@ -525,7 +525,7 @@ MVE_API int mve_unet_forward(void* handle, int phase, const void* d_sample, int 
  * conv_in(sample), and one 1x1 "zero" convolution per skip / mid tensor.  Same topology arguments and parameter-loading
  * protocol as the UNet (mve_unet_load_param / _missing_params / _plan / _weight_bytes / _destroy work on the handle; parameter
  * names are the ControlNetModel state-dict names).
- *   d_cond       [B, conditioning_channels, 8H, 8W] NCHW in io_dtype
+ *   d_cond       [B, conditioning_channels, 8H, 8W] NCHW in io_dtype ([B / R, ...] after mve_controlnet_set_cond_repeat(handle, R))
  *   d_outputs    n_levels*(layers_per_block+1) + 1 device pointers: down_block_res_samples then mid_block_res_sample, each NHWC
  *                [B*h*w, C] in the ENGINE dtype -- exactly what mve_unet_forward accepts with residuals_nhwc = 1
  *   out_k = conditioning_scale * zero_conv_k(feature_k), or, with accumulate != 0, out_k += that (MultiControlNetModel's sum) */
@@ -533,6 +533,12 @@ MVE_API int mve_controlnet_create(void** handle, int dtype, int in_channels, int
                                   const int* block_out_channels, int layers_per_block, const int* down_attn, const int* num_heads,
                                   const int* transformer_layers, int cross_attention_dim, int norm_num_groups, float norm_eps,
                                   int use_linear_projection);
+/* Shared conditioning images: with repeat = R >= 1, d_cond of mve_controlnet_forward holds B / R images and batch item b uses image b mod (B / R).
+ * Under classifier-free guidance both halves of the batch carry the same control images (lib/pipelines/mvedit_3d_pipeline.py:1232, :1417:
+ * `ctrl_images.split(diff_bs) * 2`): the conditioning embedding (8 convs on the 8H x 8W image, ~10 % of a ControlNet forward) then runs once for
+ * both.  Bit-identical to passing the images R times.  Part of the plan key; returns the previous value (repeat < 1: query).  Not combined with the
+ * residual-pair mode. */
+MVE_API int mve_controlnet_set_cond_repeat(void* handle, int repeat);
 MVE_API int mve_controlnet_forward(void* handle, const void* d_sample, int io_dtype, const float* d_timesteps, const void* d_ctx,
                                    const void* d_cond, int B, int H, int W, int ctx_len, float conditioning_scale, int accumulate,
                                    void* const* d_outputs, void* d_workspace, size_t workspace_bytes,

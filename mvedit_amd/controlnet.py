@@ -57,6 +57,8 @@ class ControlNetEngine(UNet2DConditionEngine):
         mk = lambda s: torch.empty(B, s[1], s[2], s[0], dtype=self.dtype, device=self.device).permute(0, 3, 1, 2)
         return [mk(s) for s in shapes], mk(mid)
 
+    shares_cond = True        # run() takes B / R conditioning images for a batch of B (pipelines/adapter3d_mixin.py: the CFG halves share theirs)
+
     def run(self, sample, timestep, encoder_hidden_states, cond, scale, down, mid, accumulate, profile=False):
         B, _, H, W = sample.shape
         io = encoder_hidden_states.dtype
@@ -64,6 +66,10 @@ class ControlNetEngine(UNet2DConditionEngine):
         sample = sample.to(device=self.device, dtype=io).contiguous()
         cond = cond.to(device=self.device, dtype=io).contiguous()
         assert cond.shape[2] == 8 * H and cond.shape[3] == 8 * W, 'controlnet_cond must be 8x the latent size'
+        # fewer conditioning images than batch items: item b uses image b mod len(cond) (the two halves of a CFG batch share their control
+        # images, mvedit_3d_pipeline.py:1232) and the conditioning embedding runs once per image -- bit-identical to repeating the images
+        assert B % cond.shape[0] == 0, f'{cond.shape[0]} conditioning images for a batch of {B}'
+        _lib.raw('mve_controlnet_set_cond_repeat')(self._h, B // cond.shape[0])
         t = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
         t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()
         info = self.plan(B, H, W, ctx.shape[1], 1, False, io)

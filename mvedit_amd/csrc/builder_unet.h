@@ -107,21 +107,26 @@ int Builder::build(int B_, int H, int W, int n_img, int has_res, int io_dtype, i
     if (c.controlnet) {
         // controlnet_cond_embedding on the 8H x 8W conditioning image, added to conv_in(sample)
         const int Hc = 8 * H, Wc = 8 * W, cc = c.cond_ch;
-        Ref cimg = ws((size_t)Bb * Hc * Wc * 8 * e);
+        // cn_cond_repeat = R: Bc = Bb / R conditioning images, item b of the batch uses image b mod Bc (the two halves of a CFG batch share them)
+        const int R = pl.ao.cn_cond_repeat > 1 ? pl.ao.cn_cond_repeat : 1;
+        MVE_CHECK(Bb % R == 0, MVE_ERR_ARG, "controlnet: batch %d is not a multiple of the conditioning repeat %d", Bb, R);
+        MVE_CHECK(R == 1 || !pl.ao.residual_pair, MVE_ERR_ARG, "controlnet: shared conditioning images are not combined with the residual-pair mode");
+        const int Bc = Bb / R;
+        Ref cimg = ws((size_t)Bc * Hc * Wc * 8 * e);
         {
             Ref src; src.kind = Ref::CNCOND;
-            op(OC_OTHER, 0, "cond nchw->nhwc", [=](const Run& r) { return mve_nchw_to_nhwc(d, io_dtype, r.p(src), Bb, cc, Hc, Wc, 8, r.p(cimg), r.stream); });
+            op(OC_OTHER, 0, "cond nchw->nhwc", [=](const Run& r) { return mve_nchw_to_nhwc(d, io_dtype, r.p(src), Bc, cc, Hc, Wc, 8, r.p(cimg), r.stream); });
         }
         const std::string en = "controlnet_cond_embedding.";
         int hc = Hc, wc = Wc, ci = 8;
         Ref cur = cimg;
         auto emb_conv = [&](const std::string& nm, int co, int stride, bool act) {
             const int ho = (hc - 1) / stride + 1, wo = (wc - 1) / stride + 1;
-            Ref y = ws((size_t)Bb * ho * wo * co * e);
-            conv(cur, ci, Bb, hc, wc, stride, 0, wt(nm + ".w"), co, y, wt(nm + ".b"), Ref(), 0, Ref(), 0, "cond_embedding.conv");
+            Ref y = ws((size_t)Bc * ho * wo * co * e);
+            conv(cur, ci, Bc, hc, wc, stride, 0, wt(nm + ".w"), co, y, wt(nm + ".b"), Ref(), 0, Ref(), 0, "cond_embedding.conv");
             rel(cur);
             if (act) {
-                const size_t nel = (size_t)Bb * ho * wo * co;
+                const size_t nel = (size_t)Bc * ho * wo * co;
                 op(OC_OTHER, 0, "silu", [=](const Run& r) { return mve_silu(d, r.p(y), r.p(y), nel, r.stream); });
             }
             cur = y; hc = ho; wc = wo; ci = co;
@@ -130,7 +135,12 @@ int Builder::build(int B_, int H, int W, int n_img, int has_res, int io_dtype, i
         for (int k = 0; k < 6; ++k) emb_conv(en + "blocks." + std::to_string(k), CN_EMB[(k + 1) / 2], (k & 1) ? 2 : 1, true);
         emb_conv(en + "conv_out", c.ch[0], 1, false);
         MVE_CHECK(hc == H && wc == W, MVE_ERR_ARG, "controlnet: conditioning image must be 8x the latent size");
-        conv(x_in, 8, Bb, H, W, 1, 0, wt("conv_in.w"), c.ch[0], x, wt("conv_in.b"), Ref(), 0, cur, 0, "conv_in + cond_embedding");
+        for (int rep = 0; rep < R; ++rep) {      // one conv_in launch per group of Bc items: each adds the same embedding in its epilogue
+            Ref xi = x_in, xo = x;
+            xi.off += (size_t)rep * Bc * H * W * 8 * e;
+            xo.off += (size_t)rep * Bc * H * W * c.ch[0] * e;
+            conv(xi, 8, Bc, H, W, 1, 0, wt("conv_in.w"), c.ch[0], xo, wt("conv_in.b"), Ref(), 0, cur, 0, "conv_in + cond_embedding");
+        }
         rel(cur);
     } else {
         conv(x_in, 8, Bb, H, W, 1, 0, wt("conv_in.w"), c.ch[0], x, wt("conv_in.b"), Ref(), 0, Ref(), 0, "conv_in");

@@ -186,13 +186,17 @@ struct Op {
 //                   neither store nor read (is_cfg_guidance); ref_H x ref_W = latent size of the pass that wrote the store.
 //   residual_pair : not a processor option but a plan option of this engine (mve_unet_set_residual_mode): the residual stream of ResnetBlock2D /
 //                   BasicTransformerBlock / Transformer2DModel is kept as an unrounded (hi, lo) pair of 16-bit tensors (include/mvedit_amd.h).
+//   cn_cond_repeat: ControlNet plans only (mve_controlnet_set_cond_repeat): the conditioning images are given for B / R items and item b uses image
+//                   b mod (B / R) -- under classifier-free guidance both halves of the batch see the same control images
+//                   (mvedit_3d_pipeline.py:1232: `ctrl_images.split(diff_bs) * 2`), so the conditioning embedding runs once, not R times.
 struct AttnOpts {
     int ip_tokens = 0; float ip_scale = 1.0f;
     int ref_mode = 0, ref_H = 0, ref_W = 0, ref_skip = 0;
     int residual_pair = 0;
+    int cn_cond_repeat = 1;
     bool operator==(const AttnOpts& o) const {
         return ip_tokens == o.ip_tokens && ip_scale == o.ip_scale && ref_mode == o.ref_mode && ref_H == o.ref_H && ref_W == o.ref_W &&
-               ref_skip == o.ref_skip && residual_pair == o.residual_pair;
+               ref_skip == o.ref_skip && residual_pair == o.residual_pair && cn_cond_repeat == o.cn_cond_repeat;
     }
 };
 

@@ -527,6 +527,15 @@ int mve_unet_set_residual_mode(void* handle, int pair) {
     return old;
 }
 
+int mve_controlnet_set_cond_repeat(void* handle, int repeat) {
+    MVE_CHECK(handle, MVE_ERR_ARG, "controlnet_set_cond_repeat: null handle");
+    Unet* u = (Unet*)handle;
+    MVE_CHECK(u->cfg.controlnet, MVE_ERR_ARG, "controlnet_set_cond_repeat: a ControlNet handle is needed");
+    const int old = u->ao.cn_cond_repeat;
+    if (repeat >= 1) u->ao.cn_cond_repeat = repeat;        // part of the plan key
+    return old;
+}
+
 size_t mve_unet_ref_store_bytes(void* handle, int B, int ref_H, int ref_W, int ref_skip) {
     if (!handle || B <= ref_skip) return 0;
     const Config& c = ((Unet*)handle)->cfg;

@@ -76,9 +76,10 @@ class Adapter3DMixin:
         fuse = self.fuse_chunks and same_shape and added_cond_kwargs_batches is None and len(latent_batches) > 1
         if fuse:
             cat = lambda bs: None if bs[0] is None else torch.cat(list(bs), dim=0)
+            cond = self._cat_shared_cond if self._controlnet_shares_cond() else cat
             noise_pred = self._unet_chunk(
-                cat(latent_batches), cat(prompt_embeds_batches), cat(ctrl_images_batches), cat(ctrl_depths_batches),
-                [cat(e) for e in extra_control_batches], t, tile_weight, depth_weight, None)
+                cat(latent_batches), cat(prompt_embeds_batches), cond(ctrl_images_batches), cond(ctrl_depths_batches),
+                [cond(e) for e in extra_control_batches], t, tile_weight, depth_weight, None)
         else:
             outs = []
             for i, (lat, emb, ci, cd, *extra) in enumerate(zip(latent_batches, prompt_embeds_batches, ctrl_images_batches,
@@ -113,6 +114,26 @@ class Adapter3DMixin:
         down_res = [torch.stack([torch.zeros_like(r), r], dim=1).reshape(-1, *r.shape[1:]) for r in down_res]
         mid_res = torch.stack([torch.zeros_like(mid_res), mid_res], dim=1).reshape(-1, *mid_res.shape[1:])
         return down_res, mid_res
+
+    def _controlnet_shares_cond(self):
+        """True when every ControlNet of the runner accepts fewer conditioning images than batch items (the native engines do)."""
+        cn = getattr(self, 'controlnet', None)
+        nets = getattr(cn, 'nets', [cn] if cn is not None else [])
+        return len(nets) > 0 and all(getattr(n, 'shares_cond', False) for n in nets)
+
+    @staticmethod
+    def _cat_shared_cond(bs):
+        """Fused conditioning batch of the ControlNets.  The reference builds the CFG halves of the control images from the SAME tensors
+        (mvedit_3d_pipeline.py:1232, :1417: `ctrl_images.split(diff_bs) * 2`): when the second half of the list is the first half again (object
+        identity, not a data comparison) only one half is concatenated, and the engines run the conditioning embedding once for both halves of
+        the batch (ControlNetEngine.run: item b uses image b mod len(cond); bit-identical to repeating the images)."""
+        if bs[0] is None:
+            return None
+        bs = list(bs)
+        n = len(bs) // 2
+        if len(bs) % 2 == 0 and n > 0 and all(bs[i] is bs[i + n] for i in range(n)):
+            bs = bs[:n]
+        return torch.cat(bs, dim=0)
 
     def _sub_controlnet(self, nets):
         """MultiControlNetModel(self.controlnet.nets[a:b]) of the reference, without importing diffusers here."""

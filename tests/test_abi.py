@@ -188,3 +188,30 @@ def test_residual_pair_is_a_plan_option(lib):
     vae = AutoencoderKLEngine(dict(SD_VAE_CONFIG), torch.float16, 'cpu')
     with pytest.raises(lib.MveError):
         lib.call('mve_unet_set_residual_mode', vae.decoder._h, 1)
+
+
+def test_controlnet_shared_conditioning_is_a_plan_option(lib):
+    """mve_controlnet_set_cond_repeat (plan-time only, no GPU): with R = 2 the conditioning embedding is planned for half the batch (its conv flops
+    halve, conv_in runs once per half), everything else is unchanged; UNet handles refuse the option."""
+    import torch
+    from mvedit_amd.controlnet import ControlNetEngine
+    from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG
+    cn = ControlNetEngine(SD15_CONFIG, torch.float16, device='cpu')
+    rep = lib.raw('mve_controlnet_set_cond_repeat')
+    a = cn.plan(4, 64, 64, 77)
+    emb_a = sum(f for _, _, f, lab in cn.op_table() if lab == 'cond_embedding.conv')
+    n_in_a = sum(lab == 'conv_in + cond_embedding' for _, _, _, lab in cn.op_table())
+    assert rep(cn._h, 2) == 1
+    b = cn.plan(4, 64, 64, 77)
+    emb_b = sum(f for _, _, f, lab in cn.op_table() if lab == 'cond_embedding.conv')
+    n_in_b = sum(lab == 'conv_in + cond_embedding' for _, _, _, lab in cn.op_table())
+    assert n_in_a == 1 and n_in_b == 2 and abs(emb_a - 2 * emb_b) <= 1e-9 * emb_a
+    assert abs((a['flops']['conv3x3'] - b['flops']['conv3x3']) - emb_b) <= 1e-9 * emb_a and a['flops']['linear'] == b['flops']['linear']
+    assert b['workspace_bytes'] <= a['workspace_bytes']
+    assert rep(cn._h, 3) == 2
+    with pytest.raises(lib.MveError):
+        cn.plan(4, 64, 64, 77)                                   # 4 items, 3 shares
+    assert rep(cn._h, 1) == 3 and cn.plan(4, 64, 64, 77)['flops'] == a['flops']
+    unet = UNet2DConditionEngine(SD15_CONFIG, torch.float16, device='cpu')
+    with pytest.raises(lib.MveError):
+        lib.call('mve_controlnet_set_cond_repeat', unet._h, 2)

@@ -114,3 +114,52 @@ def test_get_noise_pred_with_native_controlnets(lib):
     lat2 = torch.randn(2 * V, 4, 2 * S, S, generator=g).half().cuda()
     out2 = p.get_noise_pred([lat2], [emb.cuda()], [img.cuda()], [dep.cuda()], 500, 0.6, 0.4, 4.0)
     assert out2.shape == (V, 4, S, S) and torch.isfinite(out2).all()
+
+
+@pytest.mark.gpu
+def test_shared_conditioning_images_are_bit_identical_to_repeated_ones(lib):
+    """mve_controlnet_set_cond_repeat (ControlNetEngine.run with fewer conditioning images than batch items): under classifier-free guidance both
+    halves of the batch carry the same control images (mvedit_3d_pipeline.py:1232, `ctrl_images.split(diff_bs) * 2`); the embedding then runs once.
+    Engine level: every output equals the repeated-image call bit for bit.  Mixin level: the reference's list-times-two call gives the same noise
+    prediction as explicitly repeated tensors, and a list whose halves are different objects is not shared."""
+    from mvedit_amd.controlnet import ControlNetEngine, MultiControlNetEngine
+    from mvedit_amd.pipelines import Adapter3DMixin
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg, dtype, V, S = U.TINY, torch.float16, 3, 16
+    sd, x, ctx, cond = _case(cfg, 2 * V, S, 7)
+    eng = ControlNetEngine.from_state_dict(sd, cfg, dtype)
+    half = cond[:V].cuda().half()
+    rep = torch.cat([half, half], 0)
+    d1, m1 = eng(x.cuda().half(), 500, ctx.cuda().half(), rep, 0.7)
+    d1, m1 = [t.clone() for t in d1], m1.clone()
+    d2, m2 = eng(x.cuda().half(), 500, ctx.cuda().half(), half, 0.7)
+    assert torch.equal(m1, m2) and all(torch.equal(a, b) for a, b in zip(d1, d2))
+    assert lib.raw('mve_controlnet_set_cond_repeat')(eng._h, 0) == 2          # the plan option the last call left
+    d3, m3 = eng(x.cuda().half(), 500, ctx.cuda().half(), rep, 0.7)           # and back
+    assert torch.equal(m1, m3) and lib.raw('mve_controlnet_set_cond_repeat')(eng._h, 0) == 1
+    with pytest.raises(AssertionError):
+        eng(x.cuda().half(), 500, ctx.cuda().half(), cond[:4].cuda().half(), 0.7)      # 4 images for 6 items
+
+    class Pipe(Adapter3DMixin):
+        pass
+    p = Pipe()
+    p.unet = UNet2DConditionEngine.from_state_dict({k: v.half().float() for k, v in U.make_state_dict(cfg, seed=21).items()}, cfg, dtype)
+    p.controlnet = MultiControlNetEngine([eng, ControlNetEngine.from_state_dict(_case(cfg, 1, S, 8)[0], cfg, dtype)])
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(2 * V, 4, S, S, generator=g).half().cuda()
+    emb = torch.randn(2 * V, 77, 768, generator=g).half().cuda()
+    dep = torch.rand(V, 3, 8 * S, 8 * S, generator=g).half().cuda()
+    chunks = lambda t: list(t.split(2))
+    shared = p.get_noise_pred(chunks(lat), chunks(emb), chunks(half) * 2, chunks(dep) * 2, 500, 0.6, 0.4, 4.0)
+    calls = []
+    run0 = ControlNetEngine.run
+    try:
+        ControlNetEngine.run = lambda self, s_, t_, e_, c_, *a, **k: (calls.append(c_.shape[0]), run0(self, s_, t_, e_, c_, *a, **k))[1]
+        explicit = p.get_noise_pred(chunks(lat), chunks(emb), chunks(half) + chunks(half.clone()), chunks(dep) + chunks(dep.clone()), 500, 0.6, 0.4, 4.0)
+        assert calls == [2 * V, 2 * V]                                         # different objects: nothing is assumed about their contents
+        calls.clear()
+        p.get_noise_pred(chunks(lat), chunks(emb), chunks(half) * 2, chunks(dep) * 2, 500, 0.6, 0.4, 4.0)
+        assert calls == [V, V]
+    finally:
+        ControlNetEngine.run = run0
+    assert torch.equal(shared, explicit)
