@@ -139,13 +139,15 @@ class Adapter3DMixin:
         """MultiControlNetModel(self.controlnet.nets[a:b]) of the reference, without importing diffusers here."""
         return type(self.controlnet)(nets)
 
-    def _maybe_fuse(self, *batch_lists):
-        """Concatenate the diff_bs chunks into one batch when shapes allow (see the module docstring)."""
+    def _maybe_fuse(self, *batch_lists, cond=()):
+        """Concatenate the diff_bs chunks into one batch when shapes allow (see the module docstring).  `cond`: positions of the lists that are
+        ControlNet conditioning images -- those go through _cat_shared_cond when the ControlNets accept shared images."""
         lat = batch_lists[0]
         if not (self.fuse_chunks and len(lat) > 1 and len({tuple(b.shape[1:]) for b in lat}) == 1):
             return batch_lists
-        cat = lambda bs: None if bs is None else ([None] if bs[0] is None else [torch.cat(list(bs), dim=0)])
-        return tuple(cat(b) for b in batch_lists)
+        shared = self._controlnet_shares_cond()
+        cat = lambda bs, c: None if bs is None else ([None] if bs[0] is None else [self._cat_shared_cond(bs) if (c and shared) else torch.cat(list(bs), dim=0)])
+        return tuple(cat(b, i in cond) for i, b in enumerate(batch_lists))
 
     def get_noise_pred_p1(self, latent_batches, prompt_embeds_batches, t, guidance_scale, ctrl_depths_batches=None,
                           depth_weight=None, extra_control_batches=None, cond_noisy_latent_batches=None,
@@ -153,7 +155,7 @@ class Adapter3DMixin:
         extra_control_batches = extra_control_batches or []
         if added_cond_kwargs_batches is None:
             fused = self._maybe_fuse(latent_batches, prompt_embeds_batches, ctrl_depths_batches, cond_noisy_latent_batches,
-                                     *extra_control_batches)
+                                     *extra_control_batches, cond=(2,) + tuple(range(4, 4 + len(extra_control_batches))))
             latent_batches, prompt_embeds_batches, ctrl_depths_batches, cond_noisy_latent_batches = fused[:4]
             extra_control_batches = list(fused[4:])
         n = len(latent_batches)
@@ -202,7 +204,7 @@ class Adapter3DMixin:
                           added_cond_kwargs_batches=None, guess_mode=False, adapter_scale=None, ctrl_text_embedding=True):
         if len(dec_args) == 1 and len(latent_batches) > 1:       # pass 1 fused the chunks: fuse the same way
             latent_batches, prompt_embeds_batches, ctrl_images_batches, ctrl_depths_batches = self._maybe_fuse(
-                latent_batches, prompt_embeds_batches, ctrl_images_batches, ctrl_depths_batches)
+                latent_batches, prompt_embeds_batches, ctrl_images_batches, ctrl_depths_batches, cond=(2, 3))
         n = len(latent_batches)
         ctrl_depths_batches = ctrl_depths_batches or [None] * n
         noise_pred = []

@@ -55,3 +55,52 @@ def test_two_pass_equals_reference_output(monkeypatch, name, fuse):
         noise2 = pipe.get_noise_pred_p2(dec_args=dec_args, dec_kwargs=dec_kwargs, **kw['p2'])
     np.testing.assert_allclose(noise1.numpy(), G[f'2pass_{name}_p1'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(noise2.numpy(), G[f'2pass_{name}_p2'], rtol=1e-5, atol=1e-6)
+
+
+class SharingNet(stubs.StubNet):
+    shares_cond = True           # like mvedit_amd.controlnet.ControlNetEngine: fewer conditioning images than batch items are tiled over the batch
+
+
+class SharingMulti(stubs.StubMulti):
+    """StubMulti whose nets accept B / R conditioning images (item b uses image b mod len(cond)); records the conditioning batch sizes it saw."""
+    seen = []
+
+    def __call__(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, **kw):
+        b = sample.shape[0]
+        SharingMulti.seen.append([c.shape[0] for c in controlnet_cond])
+        tiled = [c if c.shape[0] == b else c.repeat(b // c.shape[0], 1, 1, 1) for c in controlnet_cond]
+        return super().__call__(sample, timestep, encoder_hidden_states, tiled, conditioning_scale, **kw)
+
+
+def test_shared_control_images_of_the_cfg_halves_keep_the_reference_output(monkeypatch):
+    """The reference builds the control-image lists of the two CFG halves from the same tensors (`x.split(diff_bs) * 2`,
+    mvedit_3d_pipeline.py:1232 / :1417).  With ControlNets that accept shared images the fused walk hands over ONE half (object identity of the
+    list halves, no data comparison) -- in the 2-pass methods too -- and the noise predictions stay the reference's own (golden outputs of
+    lib/pipelines/adapter3d_mixin.py over the same stand-ins).  Lists whose halves are different objects are passed whole."""
+    import mvedit_amd.pipelines.adapter3d_mixin as M
+    monkeypatch.setattr(M, 'unet_enc', stubs.stub_unet_enc)
+    monkeypatch.setattr(M, 'unet_dec', stubs.stub_unet_dec)
+    kw = stubs.cases_2pass()['plain']
+    V = 4
+    halves = lambda batches: tuple(batches[:len(batches) // 2]) * 2          # same data as the case (V even: the chunks do not straddle the halves)
+    p1, p2 = dict(kw['p1']), dict(kw['p2'])
+    for d, keys in ((p1, ('ctrl_depths_batches',)), (p2, ('ctrl_images_batches', 'ctrl_depths_batches'))):
+        for k in keys:
+            assert all(torch.equal(a, b) for a, b in zip(halves(d[k]), d[k]))
+            d[k] = halves(d[k])
+    p1['extra_control_batches'] = [halves(e) for e in p1['extra_control_batches']]
+    pipe = Pipe2(True, 3)
+    pipe.controlnet = SharingMulti([SharingNet(k) for k in range(3)])
+    SharingMulti.seen = []
+    with torch.no_grad():
+        noise1, dec_args, dec_kwargs = pipe.get_noise_pred_p1(**p1)
+        noise2 = pipe.get_noise_pred_p2(dec_args=dec_args, dec_kwargs=dec_kwargs, **p2)
+    np.testing.assert_allclose(noise1.numpy(), G['2pass_plain_p1'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(noise2.numpy(), G['2pass_plain_p2'], rtol=1e-5, atol=1e-6)
+    assert SharingMulti.seen == [[V, V], [V, V]]                             # pass 1: depth + extra; pass 2: tile + depth -- one half each
+    SharingMulti.seen = []
+    with torch.no_grad():                                                    # the case as committed: concatenated-then-split tensors, different objects
+        noise1, dec_args, dec_kwargs = pipe.get_noise_pred_p1(**kw['p1'])
+        pipe.get_noise_pred_p2(dec_args=dec_args, dec_kwargs=dec_kwargs, **kw['p2'])
+    assert SharingMulti.seen == [[2 * V, 2 * V], [2 * V, 2 * V]]
+    np.testing.assert_allclose(noise1.numpy(), G['2pass_plain_p1'], rtol=1e-5, atol=1e-6)
