@@ -33,3 +33,25 @@ def test_phase_weights_are_tap_sums_with_one_rounding():
     q = UO.quantizer(torch.float16)
     w4q = UO.upsample_phase_weights(w, q)
     assert all(torch.equal(w4q[py][px], q(w4[py][px])) for py in (0, 1) for px in (0, 1))
+
+
+@pytest.mark.parametrize('B,H,W,C', [(1, 1, 1, 8), (2, 4, 8, 16), (3, 8, 2, 24), (2, 2, 256, 8)])
+def test_grouped_output_rows_address_the_upsampled_nhwc_image(B, H, W, C):
+    """The addressing contract of mve_upsample_conv_phases (include/mvedit_amd.h, GemmParams::orow_* / ConvGeom::phase_rows in csrc/gemm_shared.h),
+    restated in integers: row m of the one-launch form (R = B H W rows per phase, m = ph R + (b H + i) W + j) starts at element
+        mm * ldc + ((mm >> log2 W) + (ph >> 1)) * extra + (ph & 1) * ldc / 2,   mm = m - ph R, ldc = 2 C, extra = 2 W C
+    and that is pixel (b, 2 i + (ph >> 1), 2 j + (ph & 1)) of the dense [B][2H][2W][C] output -- every output element exactly once."""
+    lw = W.bit_length() - 1
+    assert 1 << lw == W
+    R, ldc, extra = B * H * W, 2 * C, 2 * W * C
+    seen = torch.zeros(B * 4 * H * W * C, dtype=torch.int32)
+    for m in range(4 * R):
+        ph = int(m >= R) + int(m >= 2 * R) + int(m >= 3 * R)
+        mm = m - ph * R
+        off = mm * ldc + ((mm >> lw) + (ph >> 1)) * extra + (ph & 1) * (ldc >> 1)
+        b, r = divmod(mm, H * W)
+        i, j = divmod(r, W)
+        want = (((b * 2 * H) + 2 * i + (ph >> 1)) * 2 * W + 2 * j + (ph & 1)) * C
+        assert off == want, (m, ph, b, i, j)
+        seen[off:off + C] += 1
+    assert bool((seen == 1).all())
