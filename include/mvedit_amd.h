@@ -239,8 +239,9 @@ MVE_API int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* 
  *          storage precision of the weights, not bit for bit (tests/test_unet_ops.py pins both the exact identity on the rounded phase weights and
  *          the distance to the 3 x 3 form; end to end: tests/rounding_budget_experiment.py --phase).
  *   d_out: [B][2 Hs][2 Ws][Cout] NHWC, dense; d_out_lo (NULL or same shape): the low half in residual_pair mode.
- * Needs C % 64 == 0, Cout a multiple of 128, Ws a power of two, B Hs Ws >= 64 (mve_upsample_conv_phases_supported = 1); four launches of the
- * ping-pong kernel (2 x 2 window, grouped output rows), K slices as for any conv of that shape (workspace: *_workspace_bytes). */
+ * Needs C % 64 == 0, Cout a multiple of 128, Ws a power of two, B Hs Ws >= 64 (mve_upsample_conv_phases_supported = 1); one launch of the
+ * ping-pong kernel (2 x 2 window, grouped output rows) for the four phases where B Hs Ws is a multiple of 256, four launches otherwise; K slices by
+ * the conv slice rule with 4 Hs Ws rows per image -- batch independent (workspace: *_workspace_bytes). */
 MVE_API int mve_upsample_conv_phases_supported(int C, int Cout, int B, int Hs, int Ws);
 /* Where B Hs Ws is a multiple of 256 the four phases run as ONE launch of 4 B Hs Ws rows (the phases share the chip like the tiles of any conv: 64
  * images at the 8 x 8 level = one block per CU in one accumulation chain instead of 4 x (64 tiles x 4 K slices + reducer)); same arithmetic per

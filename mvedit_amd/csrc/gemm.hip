@@ -709,9 +709,9 @@ int mve_conv3x3_pair(int dtype, const void* x1, int C1, const void* x2, int C2, 
  * source pixel add up: 4 / 9 of the multiply-adds of the conv over the upsampled image, and the zero padding of the upsampled image is the zero
  * padding of the source.  W4 = the summed taps [phase = 2 py + px][Cout][C / 64][2][2][64] (mve_pack_upsample_phase_weights: summed in fp32, ONE
  * rounding to the storage type -- a rounding the 3 x 3 form does not have: the two forms agree to the storage precision of the weights, not bit
- * for bit).  Each phase is one launch of the ping-pong kernel with a 2 x 2 window (ConvGeom::kw) that writes its quarter of the [B][2H][2W][Cout]
- * output through the grouped output rows of GemmParams::orow_*.  Slice policy as in launch_gemm. */
-
+ * for bit).  A phase is a launch of the ping-pong kernel with a 2 x 2 window (ConvGeom::kw) that writes its quarter of the [B][2H][2W][Cout]
+ * output through the grouped output rows of GemmParams::orow_*; where a phase fills whole 256-row tiles the four phases are ONE launch
+ * (ConvGeom::phase_rows).  K slices: launch_gemm's policy with the image's 4 Hs Ws rows as the rule's rows per image. */
 
 int mve_pack_upsample_phase_weights(int src_dtype, int dst_dtype, const void* w_oihw, int Cout, int C, void* W4, void* stream) {
     MVE_CHECK(w_oihw && W4 && Cout > 0 && C > 0 && C % 64 == 0, MVE_ERR_ARG, "pack_upsample_phase_weights: needs C %% 64 == 0 (Cout=%d C=%d)", Cout, C);
