@@ -163,10 +163,3 @@ def test_shared_conditioning_images_are_bit_identical_to_repeated_ones(lib):
     finally:
         ControlNetEngine.run = run0
     assert torch.equal(shared, explicit)
-    # the 2-pass methods (adapter3d_mixin.py:137-317) on the same engines: depth net in pass 1, tile + depth in pass 2
-    two_pass = []
-    for imgs, deps in ((chunks(half) * 2, chunks(dep) * 2), (chunks(half) + chunks(half.clone()), chunks(dep) + chunks(dep.clone()))):
-        n1, dec_args, dec_kwargs = p.get_noise_pred_p1(chunks(lat), chunks(emb), 500, 4.0, ctrl_depths_batches=deps, depth_weight=0.4)
-        two_pass.append((n1, p.get_noise_pred_p2(chunks(lat), chunks(emb), dec_args, dec_kwargs, 500, 4.0, imgs, 0.6, ctrl_depths_batches=deps,
-                                                 depth_weight=0.4)))
-    assert torch.equal(two_pass[0][0], two_pass[1][0]) and torch.equal(two_pass[0][1], two_pass[1][1])
