@@ -508,12 +508,12 @@ template <class Tag>
 int launch_phase(GemmParams q, hipStream_t s) {
     const int minb = gemm_big_min_blocks() > 0 ? gemm_big_min_blocks() : 256;
     if (q.splitk > 1 && q.N % 320 != 0) q.splitk = 1;         // (only the 320-wide tile cuts K)
-    if (q.splitk > 1) {
+    // (strict mode, MVE_GEMM_STRICT_SPLITK: the rule's slices run as real slices + reducer at any batch -- the path small batches take anyway; the
+    // in-block slice emulation of the 3 x 3 convs is not instantiated for this form)
+    if (q.splitk > 1 && !gemm_strict_splitk()) {
         const long long t1 = tile256_blocks(q.M, q.N, 1);
-        if (t1 >= minb) {                                     // the un-split launch fills the chip
-            if (gemm_strict_splitk() && !q.out_lo) q.splitk_seq = q.splitk;
-            if (!gemm_strict_splitk() || !q.out_lo) q.splitk = 1;
-        } else if (!gemm_strict_splitk() && q.splitk > 2 && t1 > 0 && t1 * q.splitk >= 2 * minb) {
+        if (t1 >= minb) q.splitk = 1;                         // the un-split launch fills the chip: one accumulation chain
+        else if (q.splitk > 2 && t1 > 0 && t1 * q.splitk >= 2 * minb) {
             const int few = (int)((minb + t1 - 1) / t1);
             q.splitk = few < 2 ? 2 : (few < q.splitk ? few : q.splitk);
         }
