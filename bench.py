@@ -50,8 +50,10 @@ def parse():
                          'reference-view pairing of adapter3d_mixin.py:86-94 ([b, 4, 128, 64] latents = 4V forwards, self-attention over 2 x 4096 '
                          'tokens); zero123pp: BASELINE config 2, one Zero123++ denoise step (SD-2.1 on the 120x80 latent of six 320^2 views, '
                          'reference-only attention written by a 40x40 condition pass, CFG pair)')
-    ap.add_argument('--residual-pair', action='store_true', help='time the headline with the residual stream carried as an unrounded (hi, lo) pair '
-                    '(UNet2DConditionEngine.set_residual_pair: end-to-end error below north_star\'s 1e-3); by default that mode is reported as an extra workload')
+    ap.add_argument('--plain-stream', action='store_true', help='time the headline with the 16-bit residual stream of the reference\'s half modules '
+                    '(UNet2DConditionEngine.set_residual_pair(False): 1.2e-3 from fp32 arithmetic, outside north_star\'s 1e-3).  The DEFAULT since round 5 is '
+                    'the engine\'s default mode: the stream as an unrounded (hi, lo) pair, 8.7e-4; the plain mode is reported as an extra workload')
+    ap.add_argument('--residual-pair', action='store_true', help='(accepted for older command lines: the pair is the default now)')
     ap.add_argument('--no-extra', action='store_true', help='skip the compact extra workloads (use_reference, zero123pp, bf16, residual pair) and the outer-step figures')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the NeRF / raster / back-projection figures')
@@ -61,29 +63,34 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, dtype=torch.float16, latent_hw=(LATENT, LATENT), B=1, n_img=1, repeats=3):
-    """Oracle (kind "port") on the host cores: one forward of one image, fp32 arithmetic over the engine's (16-bit rounded) weights.
+def cpu_baseline(cfg, dtype=torch.float16, latent_hw=(LATENT, LATENT), B=1, n_img=1, repeats=3, x=None, ctx=None, t=499):
+    """Oracle (kind "port") on the host cores: a forward of B images, fp32 arithmetic over the engine's (16-bit rounded) weights.
     Returns the baseline record and (x, ctx, out) so that the same forward can be compared with the HIP engine (the oracle as checker).
-    The ONLY function of this file that touches oracle/ (tests/test_abi.py).  B / n_img / repeats = 1: the checker leg of the extra workloads
-    (one forward of a CFG pair, or of a (reference, view) pair under cross-image attention), not a baseline figure."""
+    The ONLY function of this file that touches oracle/ (tests/test_abi.py).  x / ctx given: those rows (the headline passes rows of the TIMED
+    batch, so that the checker sees the launch decisions the timed batch takes); else seeded random inputs.  B / n_img / repeats = 1: the checker
+    leg of the extra workloads (one forward of a CFG pair, or of a (reference, view) pair under cross-image attention), not a baseline figure."""
     from oracle import unet_oracle as U
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     sd = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=1234).items()}
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, 4, *latent_hw, generator=g).to(dtype).float()
-    ctx = torch.randn(B, CTX_LEN, cfg['cross_attention_dim'], generator=g).to(dtype).float()
+    if x is None:
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(B, 4, *latent_hw, generator=g).to(dtype).float()
+        ctx = torch.randn(B, CTX_LEN, cfg['cross_attention_dim'], generator=g).to(dtype).float()
+    else:
+        x, ctx = x.detach().float().cpu(), ctx.detach().float().cpu()
+        B, latent_hw = x.shape[0], tuple(x.shape[2:])
     dts = []
     with torch.no_grad():
         for _ in range(repeats):                 # ~10 s of host work in total: a bounded sample, not the full step
             t0 = time.perf_counter()
-            out = U.unet_forward(sd, cfg, x, 499, ctx, n_img)
+            out = U.unet_forward(sd, cfg, x, t, ctx, n_img)
             dts.append(time.perf_counter() - t0)
-    dt = min(dts)
+    dt = min(dts) / B
     rec = dict(value=None, unit='denoise-steps/s', cores=threads, kind='port', seconds_per_forward=round(dt, 3),
-               sample=f'1 UNet forward (1 image, {latent_hw[0]}x{latent_hw[1]} latent, fp32 torch oracle), best of 3: {dt:.2f} s; scaled linearly '
-                      'to the forwards of a step')
+               sample=f'{B} UNet forward(s) in one call ({latent_hw[0]}x{latent_hw[1]} latent, fp32 torch oracle), best of {repeats}: {dt:.2f} s per forward; '
+                      'scaled linearly to the forwards of a step')
     return rec, (x, ctx, out)
 
 
@@ -417,7 +424,8 @@ def measure_workload(dev, wl, dtype, residual_pair, steps=3, warmup=1, parity_re
     dom = 'gemm' if gemm_ms >= cls_ms.get('attention', 0.0) else 'attention'
     ach = (gemm_fl / gemm_ms if dom == 'gemm' else cls_fl['attention'] / cls_ms['attention']) / 1e9
     total_fl = sum(cls_fl.values())
-    rec = dict(workload=wl + (' + residual pair' if residual_pair else ''), dtype='f16' if dtype == torch.float16 else 'bf16', steps=steps,
+    rec = dict(workload=wl + ('' if residual_pair else ' + plain 16-bit residual stream (the reference\'s rounding points)'), residual_stream='pair' if residual_pair else '16-bit',
+               dtype='f16' if dtype == torch.float16 else 'bf16', steps=steps,
                ms_per_step=round(ms_per_step, 3), value=round(1e3 / ms_per_step, 4), unit='denoise-steps/s', forwards_per_step=forwards,
                model_tflops_per_s=round(total_fl / ms_per_step / 1e9, 1),
                roofline=dict(bound='mfma', kernel='k_gemm_pp (conv3x3 + linear)' if dom == 'gemm' else 'k_attention3 / k_attention2', achieved=round(ach, 1),
@@ -499,13 +507,23 @@ def outer_step(dev, n_optim_timed=24):
     ctrl_dep = torch.rand(V, 3, S, S, generator=g).to(dev, f16)
     two = lambda x: torch.cat([x, x], 0)
     t_step = torch.full((2 * V,), 499.0, device=dev)
-    # the reference's call (mvedit_3d_pipeline.py:1226-1249, diff_bs 6): latents and embeddings of both CFG halves in chunks of 6, the control
-    # images of the second half being the SAME tensors as the first (`.split(diff_bs) * 2`); the mixin fuses the chunks into one 64-image launch
-    # and the ControlNet engines embed each control image once for both halves
+    # the reference's call, exactly as its ordinary (not use_reference) 1-pass branch builds the lists (mvedit_3d_pipeline.py:1236-1249, diff_bs 6):
+    # `torch.cat([x] * 2).split(diff_bs)` for the latents AND the control images -- 11 chunks of <= 6, the sixth straddling the CFG halves.  The
+    # mixin fuses the chunks into one 64-image launch; Adapter3DMixin._cat_shared_cond views the control chunks as one tensor again, finds its
+    # halves equal (one device comparison) and hands over one half: the ControlNet engines embed each control image once for both halves.
+    # (round 4 timed `x.split(diff_bs) * 2` control lists against same-shape latents, a combination the reference never builds.)
     DIFF_BS = 6
-    ms, noise = timed(lambda: pipe.get_noise_pred(list(two(lat).split(DIFF_BS)), list(ctx.split(DIFF_BS)), list(ctrl_img.split(DIFF_BS)) * 2,
-                                                  list(ctrl_dep.split(DIFF_BS)) * 2, t_step, 1.0, 1.0, GUIDANCE))
+    mk = lambda: (list(two(lat).split(DIFF_BS)), list(ctx.split(DIFF_BS)), list(two(ctrl_img).split(DIFF_BS)), list(two(ctrl_dep).split(DIFF_BS)))
+    lists = mk()
+    assert len({len(x) for x in lists}) == 1
+    ms, noise = timed(lambda: pipe.get_noise_pred(*lists, t_step, 1.0, 1.0, GUIDANCE))
     out['noise_pred_unet_2_controlnets_ms'] = round(ms, 2)
+    pipe.detect_repeated_cond = False                                      # the same call without the recognition: every control image embedded twice
+    ms2, noise2 = timed(lambda: pipe.get_noise_pred(*lists, t_step, 1.0, 1.0, GUIDANCE))
+    pipe.detect_repeated_cond = True
+    out['noise_pred_unet_2_controlnets_unshared_ms'] = round(ms2, 2)
+    out['noise_pred_shared_equals_unshared'] = bool(torch.equal(noise, noise2))
+    del noise2, lists
 
     def decode():
         x0 = predict_x0(lat, noise, 0.6, 0.8) / 0.18215
@@ -624,6 +642,33 @@ def outer_step(dev, n_optim_timed=24):
     return out
 
 
+def scaling_projection(eng, dev, dtype, ms_full):
+    """The forward a rank of an N-GPU job runs (64 / N images), timed on THIS GPU with the headline engine, and what strong scaling that projects
+    before / after the step's all-gather (128 MiB of maps over 7 xGMI links: ~0.4 ms assumed, measured by `collectives` when N > 1)."""
+    rows = {}
+    g = torch.Generator().manual_seed(1)
+    for n in (2, 4, 8):
+        B = 2 * VIEWS // n
+        x = torch.randn(B, 4, LATENT, LATENT, generator=g).to(dev, dtype)
+        c = torch.randn(B, CTX_LEN, 768, generator=g).to(dev, dtype)
+        t = torch.full((B,), 499.0, device=dev)
+        eng._set_attention(None, B, LATENT, LATENT)
+        for _ in range(2):
+            eng._run(0, x, t, c, 1, None, None, None)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            for _ in range(4):
+                eng._run(0, x, t, c, 1, None, None, None)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 4 * 1e3)
+        rows[str(n)] = dict(images_per_rank=B, ms=round(best, 3), speedup_before_collectives=round(ms_full / best, 2),
+                            speedup_with_all_gather=round(ms_full / (best + 0.4), 2))
+    return dict(per_n_gpus=rows, all_gather_ms_assumed=0.4, base_ms=round(ms_full, 3),
+                note='one rank\'s share of the 32-view step on this box (tools/scale_preview.py); north_star target at N = 8: >= 6x')
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -659,7 +704,8 @@ def main():
     sd = U.make_state_dict(cfg, seed=1234, dtype=dtype)
     eng = UNet2DConditionEngine.from_state_dict(sd, cfg, dtype, dev)
     del sd
-    eng.set_residual_pair(bool(args.residual_pair))
+    pair_mode = not args.plain_stream
+    eng.set_residual_pair(pair_mode)                      # (the engine's default mode; --plain-stream: the reference's rounding points)
     if os.environ.get('MVE_BENCH_GRAPH') == '1':          # experiment: hipGraph replay of the forward (off by default)
         eng.enable_graph(True)
         side = torch.cuda.Stream(dev)                      # stream capture is not allowed on the legacy default stream
@@ -674,6 +720,7 @@ def main():
     maps_local = torch.zeros(v_loc, 8, 8 * LATENT, 8 * LATENT, device=dev, dtype=torch.float16) if shards else None
     gathered = torch.empty(V, 8, 8 * LATENT, 8 * LATENT, device=dev, dtype=torch.float16) if shards else None
     optabs = [None] * len(passes)
+    last_raw = [None]                 # the UNet output of the most recent step, all 2 v_loc rows (the checker leg compares rows of the TIMED batch)
 
     def step(profile):
         """-> (noise prediction, [per-op milliseconds of every pass] or None)"""
@@ -690,6 +737,7 @@ def main():
                 mss.append(ms)
             else:
                 out = eng._run(0, x_, t_, c_, n_, None, None, None)
+        last_raw[0] = out
         if wl == 'use_reference':
             out = out.view(-1, 2, *out.shape[1:])[:, 1]                                  # the view's half of every pair
         half = out.shape[0] // 2
@@ -720,6 +768,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timed_rows = None
+    if rank == 0 and wl == 'mvedit32' and last_raw[0] is not None:
+        # rows of the LAST TIMED step's batch for the checker leg: view 0's unconditional and text rows (rows 0 and v_loc of [uncond | text])
+        timed_rows = ([0, v_loc], last_raw[0][[0, v_loc]].float().cpu())
+    # the same K steps once more WITHOUT per-op HIP events (the events run inside the timed steps at N = 1)
+    ms_no_events = None
+    if world == 1 and not args.no_op_timing:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        torch.cuda.synchronize()
+        ms_no_events = (time.perf_counter() - t1) / args.steps * 1e3
     # socket power / clock: sampled over EXTRA untimed steps right after the timed region (rocm-smi queries the SMU; nothing that is not the
     # workload runs next to the timed steps).  Every rank runs the extra steps (they contain the step's collective); rank 0 samples.
     sampler = PowerSampler() if rank == 0 else None
@@ -856,41 +917,69 @@ def main():
                 roof['clock'] = clk
             except Exception as e:      # informational only
                 roof['clock'] = {'error': repr(e)[:200]}
+        if ms_no_events is not None:
+            line['op_timing'] = dict(ms_per_step_with_per_op_events=round(ms_per_step, 3), ms_per_step_without=round(ms_no_events, 3),
+                                     note='the timed region carries one HIP event pair per op at N = 1 (the roofline figures come from them); the same K steps '
+                                          'again, right after, without them')
         if world == 1 and not args.no_cpu_baseline:
             hw = (120, 80) if wl == 'zero123pp' else (LATENT, LATENT)
-            base, (bx, bctx, bout) = cpu_baseline(cfg, dtype, hw)
+            if timed_rows is not None:
+                # the checker reads ROWS OF THE TIMED BATCH: the fp32 oracle runs the two items alone (B = 2, ~2 x 3 s per
+                # repeat on the host cores -- also the cpu_baseline sample), the engine's rows come out of the last timed 64-image step, i.e. from
+                # the launch decisions only that batch takes (un-split accumulation chains, reduced slice counts: csrc/gemm.hip launch_gemm)
+                ridx, got_rows = timed_rows
+                x_all, _, c_all, _, _ = passes[0]
+                base, (bx, bctx, bout) = cpu_baseline(cfg, dtype, hw, x=x_all[ridx], ctx=c_all[ridx], repeats=2)
+            else:
+                base, (bx, bctx, bout) = cpu_baseline(cfg, dtype, hw)
             nfw = 2 if wl == 'zero123pp' else forwards      # (zero123pp: the 40x40 condition pass is ~1/6 of the main pass; counted as part of it)
             base['value'] = 1.0 / (nfw * base['seconds_per_forward'])
             base['unit'] = 'denoise-steps/s' + ('' if wl == 'zero123pp' else ' (32 views)')
             base['sample'] += f' ({nfw})'
             line['cpu_baseline'] = base
-            # the oracle as checker: the same single forward through the HIP engine, against the fp32 oracle (north_star: 1e-3 rel fp16)
+            # the oracle as checker (north_star: 1e-3 rel fp16)
             try:
-                eng._set_attention(None, 1, hw[0], hw[1])
-                got = eng._run(0, bx.to(dev, dtype), torch.full((1,), 499.0, device=dev), bctx.to(dev, dtype), 1, None, None, None).float().cpu()
-                rel = float((got - bout).norm() / bout.norm())
-                line['parity'] = dict(rel_l2_vs_fp32_oracle=round(rel, 6), shape=[1, 4, hw[0], hw[1]], north_star_bar=1e-3,
-                                      note='one forward at the benchmark latent size; the oracle runs fp32 arithmetic over the same 16-bit weights. '
-                                           'tests/test_unet.py holds the per-kernel 1e-3 bar and the end-to-end comparison against the 16-bit-emulating oracle')
+                if timed_rows is not None:
+                    per_row = [float((got_rows[k] - bout[k]).norm() / bout[k].norm()) for k in range(len(ridx))]
+                    rel = float((got_rows - bout).norm() / bout.norm())
+                    line['parity'] = dict(rel_l2_vs_fp32_oracle=round(rel, 6), per_row=[round(v, 6) for v in per_row], rows_of_the_timed_batch=ridx,
+                                          shape=[len(ridx), 4, hw[0], hw[1]], batch=int(x_all.shape[0]), north_star_bar=1e-3,
+                                          within_bar=bool(max(per_row) <= 1e-3),
+                                          note='rows of the last TIMED step\'s UNet output (view 0: unconditional and text row of the 2V-image batch) against '
+                                               'fp32 oracle forwards of the same two items over the same 16-bit weights; tests/test_unet.py holds the same '
+                                               'comparison at B = 64 and the per-kernel 1e-3 bars')
+                else:
+                    eng._set_attention(None, 1, hw[0], hw[1])
+                    got = eng._run(0, bx.to(dev, dtype), torch.full((1,), 499.0, device=dev), bctx.to(dev, dtype), 1, None, None, None).float().cpu()
+                    rel = float((got - bout).norm() / bout.norm())
+                    line['parity'] = dict(rel_l2_vs_fp32_oracle=round(rel, 6), shape=[1, 4, hw[0], hw[1]], north_star_bar=1e-3,
+                                          note='one forward at the benchmark latent size; the oracle runs fp32 arithmetic over the same 16-bit weights')
             except Exception as e:
                 line['parity'] = {'error': repr(e)[:300]}
-        line['config']['residual_stream'] = 'unrounded (hi, lo) pair' if args.residual_pair else '16-bit (as the reference)'
-        phases = not args.residual_pair and os.environ.get('MVE_UPSAMPLE_PHASES', '1') != '0'
+        line['config']['residual_stream'] = ('unrounded (hi, lo) pair of 16-bit tensors (the engine\'s default mode; end-to-end error inside north_star\'s 1e-3)'
+                                             if pair_mode else '16-bit, rounded after every block (the reference\'s half modules)')
+        phases = os.environ.get('MVE_UPSAMPLE_PHASES', '1') != '0'
         line['config']['upsample2d'] = ('four 2x2 phase convs over the source (summed 3x3 taps rounded once to the storage type; 4/9 of the multiply-adds)'
                                         if phases else '3x3 conv over the nearest-upsampled image (as the reference)')
-        if world == 1 and not args.no_extra and wl == 'mvedit32' and dtype == torch.float16 and not args.residual_pair:
+        if world == 1 and wl == 'mvedit32' and not args.no_extra:
+            # what one rank of an N-GPU job runs (32 views x CFG / N images), on this box: the projection the first real SCALE file is to be read against
+            try:
+                line['scaling_projection'] = scaling_projection(eng, dev, dtype, ms_no_events or ms_per_step)
+            except Exception as e:
+                line['scaling_projection'] = {'error': repr(e)[:300]}
+        if world == 1 and not args.no_extra and wl == 'mvedit32' and dtype == torch.float16 and pair_mode:
             # the other configurations BASELINE.json names, and the two other numeric modes, as compact driver-visible lines (3 steps each)
             del eng
             torch.cuda.empty_cache()
             extras = []
             head_ref = (bx, bctx, bout, 1) if (not args.no_cpu_baseline and 'parity' in line and 'error' not in line['parity']) else None
-            for (wl2, dt2, pair2) in (('mvedit32', torch.float16, True), ('use_reference', torch.float16, False), ('zero123pp', torch.float16, False),
-                                      ('mvedit32', torch.bfloat16, False)):
+            for (wl2, dt2, pair2) in (('mvedit32', torch.float16, False), ('use_reference', torch.float16, True), ('zero123pp', torch.float16, True),
+                                      ('mvedit32', torch.bfloat16, True)):
                 try:
                     ref = None
                     if not args.no_cpu_baseline:
                         if wl2 == 'mvedit32' and dt2 == torch.float16:
-                            ref = head_ref
+                            ref = head_ref           # (the two rows of the headline's checker, here as a B = 2 forward of the plain-stream engine)
                         elif wl2 == 'mvedit32':
                             ref = cpu_baseline(dict(SD15_CONFIG), dt2, (LATENT, LATENT), repeats=1)[1] + (1,)
                         elif wl2 == 'use_reference':

@@ -69,6 +69,10 @@ class ControlNetEngine(UNet2DConditionEngine):
         # fewer conditioning images than batch items: item b uses image b mod len(cond) (the two halves of a CFG batch share their control
         # images, mvedit_3d_pipeline.py:1232) and the conditioning embedding runs once per image -- bit-identical to repeating the images
         assert B % cond.shape[0] == 0, f'{cond.shape[0]} conditioning images for a batch of {B}'
+        if cond.shape[0] < B and self.residual_pair:
+            # the plan shares one embedding among R batch items through the conv_in epilogue's residual slot, which the pair mode's conv_in
+            # (output = a stream pair) does not have: repeat the images instead (same values, R embeddings)
+            cond = cond.repeat(B // cond.shape[0], 1, 1, 1)
         _lib.raw('mve_controlnet_set_cond_repeat')(self._h, B // cond.shape[0])
         t = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
         t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()

@@ -217,6 +217,30 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // residual_pair launches (a low half comes in or goes out): the accumulators START from the residual, hi + lo (exact in fp32), exactly as the
+    // PAIR instantiation of k_gemm_pp does -- residual + sum_k a w, then + bias -- so that a pair launch rounds identically on every tile the
+    // dispatcher may pick (batch / partition invariance in the executor's default mode).  A split-K slice starts from zero: the reducer adds it.
+    const bool res_in_acc = (p.residual_lo || p.out_lo) && p.residual && p.splitk <= 1 && !p.res_after_scale;      // uniform
+    if (res_in_acc) {
+        typedef T T4 __attribute__((ext_vector_type(4)));
+        const T* rh = reinterpret_cast<const T*>(p.residual);
+        const T* rl = reinterpret_cast<const T*>(p.residual_lo);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+                n = n + 4 <= p.N ? n : 0;                     // (a dead column group of the last tile: never stored)
+                const size_t ro = (size_t)m * p.ldr + n;
+                const T4 h = *reinterpret_cast<const T4*>(rh + ro);
+                const T4 l = rl ? *reinterpret_cast<const T4*>(rl + ro) : T4{};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][i][e] = Tag::to_f32(h[e]) + Tag::to_f32(l[e]);
+            }
+        }
+    }
 
     dma_tile(kt_begin, 0);
     __syncthreads();
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
                     *reinterpret_cast<f32x4*>(pp + 4) = f32x4{v[4], v[5], v[6], v[7]};
                     continue;
                 }
-                gemm_epilogue_store<Tag>(p, m, n, v);
+                gemm_epilogue_store<Tag>(p, m, n, v, res_in_acc);
             }
             __syncthreads();
         }
@@ -305,8 +329,13 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
 }
 
 // Split K at the deep UNet levels, where one image contributes only a few output tiles (8x8 / 16x16 latents) but K is
-// 9*1280..9*2560.  The slice count is a function of (rows per image, N, K) ONLY -- never of the batch -- so that a view gets
-// bit-identical results whether it is denoised alone, in a chunk, or on another GPU (batch / partition invariance).
+// 9*1280..9*2560.  The RULE below is a function of (rows per image, N, K) only -- never of the batch.  What a launch actually runs with is the
+// rule's count only while the launch is small: launch_gemm (below) runs ONE accumulation chain where the un-split launch fills the chip and
+// `ceil(256 / tiles)` slices where the rule would over-fill it, so the effective count falls with the rows of the launch
+// (mve_gemm_effective_splitk; 16 x 16 level: 4 slices up to 16 images, 2 at 32, 1 from 64; 8 x 8 level: 8 / 4 / 2 / 1 slices at <= 32 / 64 / 128 /
+// 256 images).  A view therefore gets bit-identical results alone, in a chunk or on another rank AS LONG AS those launches take the same decision
+// (all small batches do); MVE_GEMM_STRICT_SPLITK=1 / mve_gemm_tune bit 30 / mvedit_amd.parallel.set_partition_invariant() make every launch
+// round as the rule's slices, at any batch (tests/test_abi.py::test_effective_splitk_by_batch).
 int g_splitk_policy = -1;      // MVE_GEMM_SPLITK: 1 (default) = the rule below; 0 = never split (A/B: what the slices cost at a given batch)
 int choose_splitk(int rows_per_image, int N, int K) {
     if (g_splitk_policy < 0) {
@@ -735,6 +764,11 @@ int mve_upsample_conv_phases_supported(int C, int Cout, int B, int Hs, int Ws) {
     if (C <= 0 || C % 64 != 0 || Cout <= 0 || B <= 0 || Hs <= 0 || Ws <= 0 || (Ws & (Ws - 1)) != 0) return 0;
     if (Cout % 320 != 0 && Cout % 256 != 0 && Cout % 128 != 0) return 0;
     if (!gemm_pp_on() || (long long)B * Hs * Ws < 64 || (long long)B * Hs * Ws > 0x7fffffffll / 4) return 0;
+    // the ping-pong kernel addresses its source and its weights through 32-bit buffer offsets (gemm_pp.hip: pp_fits / pp_eligible): a larger
+    // launch (a VAE decode of >= 128 images at the 256-channel upsampler) keeps the 3 x 3 form, which falls back to the other 256-row loops
+    const unsigned long long lim = 0xFFFFFF00ull - 65536ull;
+    if (((unsigned long long)B * Hs * Ws + 2ull * Ws + 4) * (unsigned long long)C * 2 >= lim) return 0;
+    if ((unsigned long long)Cout * 4 * C * 2 >= lim) return 0;
     return 1;
 }
 

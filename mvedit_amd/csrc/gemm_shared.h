@@ -161,8 +161,9 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
 
 // The fused epilogue on 8 consecutive output columns (n % 8 == 0) of row m: bias, per-image row vector (time embedding),
 // GEGLU, residual, output scale, storage-dtype (or fp32) store.  Shared by the GEMM kernels and the split-K reducer.
+// res_done: the caller's accumulators started from the residual (pair launches of the 128-row kernel): nothing to read or add here.
 template <class Tag>
-__device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, int n, float (&v)[8]) {
+__device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, int n, float (&v)[8], bool res_done = false) {
     typedef typename Tag::T T;
     typedef typename Tag::V8 V8;
     typedef T T4 __attribute__((ext_vector_type(4)));
@@ -187,6 +188,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, 
         return;
     }
     V8 rr = {};
+    if (res_done) { gemm_epilogue_tail<Tag, true, true>(p, m, n, v, rr); return; }
     if (p.residual) rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
     gemm_epilogue_tail<Tag>(p, m, n, v, rr);
 }

@@ -21,6 +21,21 @@ def partition_views(num_views, world_size, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def set_partition_invariant(flag=True):
+    """Bitwise equality of a view's result across ANY partition -- one GPU with 64 images against 8 ranks with 8 -- needs the strict K-slice mode
+    of the GEMM dispatcher (mve_gemm_tune bit 30 / MVE_GEMM_STRICT_SPLITK=1: every launch rounds as the slice rule's slices, whatever the batch;
+    about 3.8 ms per 64-image step on one GPU, nothing on launches that split anyway).  Without it the slice count of the deep levels depends on
+    how many rows a launch has (csrc/gemm.hip: launch_gemm -- one chain where the launch fills the chip, `ceil(256 / tiles)` slices at the 8 x 8
+    level: 8 slices at 8 images, 4 at 64, 2 at 128, 1 at 256), so results agree bitwise only among ranks / batches that take the same decisions:
+    every rank of an N-GPU job whose shards are equal does, a 1-GPU run of the whole batch does not.  The values differ by fp32 summation order
+    only (tests/test_unet_ops.py::test_unsplit_chain_vs_sliced_sum).  Returns the previous setting."""
+    from . import _lib
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    tune((old | (1 << 30)) if flag else (old & ~(1 << 30)))
+    return bool(old & (1 << 30))
+
+
 def _dist_on():
     return dist.is_available() and dist.is_initialized()
 

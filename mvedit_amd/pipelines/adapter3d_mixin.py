@@ -121,18 +121,45 @@ class Adapter3DMixin:
         nets = getattr(cn, 'nets', [cn] if cn is not None else [])
         return len(nets) > 0 and all(getattr(n, 'shares_cond', False) for n in nets)
 
+    detect_repeated_cond = True      # one device comparison + host read per fused call (see _cat_shared_cond); False: object identity only
+
     @staticmethod
-    def _cat_shared_cond(bs):
-        """Fused conditioning batch of the ControlNets.  The reference builds the CFG halves of the control images from the SAME tensors
-        (mvedit_3d_pipeline.py:1232, :1417: `ctrl_images.split(diff_bs) * 2`): when the second half of the list is the first half again (object
-        identity, not a data comparison) only one half is concatenated, and the engines run the conditioning embedding once for both halves of
-        the batch (ControlNetEngine.run: item b uses image b mod len(cond); bit-identical to repeating the images)."""
+    def _as_one_tensor(bs):
+        """Chunks that are consecutive views of ONE storage -- what `x.split(diff_bs)` returns -- as that tensor again, without a copy; else None."""
+        b0 = bs[0]
+        if b0.dim() == 0 or not b0.is_contiguous():
+            return None
+        st, off, total = b0.untyped_storage().data_ptr(), b0.storage_offset(), 0
+        for b in bs:
+            if (b.dtype != b0.dtype or b.shape[1:] != b0.shape[1:] or not b.is_contiguous() or b.untyped_storage().data_ptr() != st
+                    or b.storage_offset() != off):
+                return None
+            off += b.numel()
+            total += b.shape[0]
+        return torch.as_strided(b0, (total,) + tuple(b0.shape[1:]), b0.stride(), b0.storage_offset())
+
+    def _cat_shared_cond(self, bs):
+        """Fused conditioning batch of the ControlNets.  The reference builds the CFG halves of the control images from the same data, in two forms:
+        `ctrl_images.split(diff_bs) * 2` (mvedit_3d_pipeline.py:1232, :1417 -- the use_reference branch and the 2-pass methods): the second half of
+        the list IS the first half (object identity, nothing is read); and `torch.cat([ctrl_images] * 2).split(diff_bs)` (:1238-1241, the ordinary
+        1-pass branch): the chunks are consecutive views of one tensor whose halves hold the same values -- recognised by viewing the chunks as
+        that tensor again (no copy) and comparing its halves on the device (`torch.equal`: ~50 MB read + one host read per call of a >= 100 ms
+        step; `detect_repeated_cond = False` turns the comparison off).  Either way only ONE half is handed over, and the engines run the
+        conditioning embedding once for both halves of the batch (ControlNetEngine.run: item b uses image b mod len(cond); bit-identical to
+        repeating the images).  Anything else is concatenated whole."""
         if bs[0] is None:
             return None
         bs = list(bs)
         n = len(bs) // 2
         if len(bs) % 2 == 0 and n > 0 and all(bs[i] is bs[i + n] for i in range(n)):
-            bs = bs[:n]
+            return torch.cat(bs[:n], dim=0)
+        if self.detect_repeated_cond and len(bs) > 1:
+            full = self._as_one_tensor(bs)
+            if full is not None and full.shape[0] >= 2 and full.shape[0] % 2 == 0:
+                h = full.shape[0] // 2
+                if torch.equal(full[:h], full[h:]):
+                    return full[:h]
+                return full
         return torch.cat(bs, dim=0)
 
     def _sub_controlnet(self, nets):

@@ -63,8 +63,6 @@ class UNet2DConditionEngine:
                   arr(c['transformer_layers']), c['cross_attention_dim'], c['norm_num_groups'], float(c['norm_eps']),
                   int(c['use_linear_projection']))
         self._ws = None
-        if os.environ.get('MVE_RESIDUAL_PAIR') == '1':
-            _lib.raw('mve_unet_set_residual_mode')(self._h, 1)
         self._ip = (0, 1.0)          # IP-Adapter: (num_tokens, scale); see set_ip_adapter
         self._ref_keep = None
         # the attributes the reference's pipelines / runner read from a diffusers model
@@ -85,8 +83,9 @@ class UNet2DConditionEngine:
     def set_residual_pair(self, flag=True):
         """Carry the residual stream (x + f(x) of ResnetBlock2D / BasicTransformerBlock / Transformer2DModel) as an unrounded (hi, lo) pair of 16-bit
         tensors instead of rounding it after every block as the reference's half modules do (mve_unet_set_residual_mode): the end-to-end error
-        against fp32 arithmetic falls below north_star's 1e-3 (1.23e-3 without) for 4 more bytes per stream element and pass.  Off by default; the
-        environment variable MVE_RESIDUAL_PAIR=1 turns it on for every engine.  Returns the previous setting."""
+        against fp32 arithmetic falls below north_star's 1e-3 (1.23e-3 without) for 4 more bytes per stream element and pass.  ON by default for
+        the UNet since round 5 (the native handle is created in this mode; MVE_RESIDUAL_PAIR=0 in the environment or set_residual_pair(False)
+        give the reference's rounding points); a ControlNetEngine keeps the 16-bit stream unless asked.  Returns the previous setting."""
         return bool(_lib.raw('mve_unet_set_residual_mode')(self._h, int(bool(flag))))
 
     @property

@@ -37,6 +37,7 @@ def run(sd, cfg, x, t, ctx, q, engine=True, phase_ups=False, **off):
     c = UO._Ctx(sd, cfg, q, None)
 
     def conv(h, name, stride=1, padding=1, qq=None):
+        S.where = name
         return (qq or S.mm)(F.conv2d(h, c.w(name + '.weight'), c.w(name + '.bias'), stride=stride, padding=padding))
 
     def linear(h, name, bias=True, qq=None):
@@ -44,6 +45,7 @@ def run(sd, cfg, x, t, ctx, q, engine=True, phase_ups=False, **off):
 
     def resnet(p, xs, temb):
         g, eps = cfg['norm_num_groups'], cfg['norm_eps']
+        S.where = p           # (site selectors of derived experiments look at the block they are in)
         xin = S.bin(xs)
         h = S.norm(F.silu(F.group_norm(xin, g, c.w(p + '.norm1.weight'), c.w(p + '.norm1.bias'), eps)))
         tt = F.linear(q(F.silu(temb)), c.w(p + '.time_emb_proj.weight'), c.w(p + '.time_emb_proj.bias'))       # fp32 row vector in the engine
@@ -72,6 +74,7 @@ def run(sd, cfg, x, t, ctx, q, engine=True, phase_ups=False, **off):
 
     def transformer(p, xs, cx, heads, layers):
         B, C, H, W = xs.shape
+        S.where = p
         h = S.norm(F.group_norm(S.bin(xs), cfg['norm_num_groups'], c.w(p + '.norm.weight'), c.w(p + '.norm.bias'), 1e-6))
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = S.res(F.linear(h, c.w(p + '.proj_in.weight').flatten(1), c.w(p + '.proj_in.bias')))          # starts the block's stream
@@ -87,7 +90,7 @@ def run(sd, cfg, x, t, ctx, q, engine=True, phase_ups=False, **off):
             f = S.act(val * F.gelu(gate))
             h = S.res(h + r(F.linear(f, c.w(b + '.ff.net.2.weight'), c.w(b + '.ff.net.2.bias'))))
         # proj_out reads the stream as an MFMA operand: the 16-bit half
-        o = F.linear(q(h) if S.res is ident else h, c.w(p + '.proj_out.weight').flatten(1), c.w(p + '.proj_out.bias'))
+        o = F.linear(q(h), c.w(p + '.proj_out.weight').flatten(1), c.w(p + '.proj_out.bias'))
         o = o.reshape(B, H, W, C).permute(0, 3, 1, 2)
         return S.res(r(o) + xs)
 
@@ -100,7 +103,7 @@ def run(sd, cfg, x, t, ctx, q, engine=True, phase_ups=False, **off):
     h = conv(sample, 'conv_in', qq=S.res)
     res = [h]
     # a stream tensor consumed as an MFMA operand (down / upsampler convs, conv_shortcut, skip concat) is the 16-bit half
-    op = lambda v: q(v) if S.res is ident else v
+    op = q        # (idempotent on an already rounded stream)
     for i in range(n_lv):
         for j in range(cfg['layers_per_block']):
             h = resnet(f'down_blocks.{i}.resnets.{j}', h, emb)
@@ -123,9 +126,11 @@ def run(sd, cfg, x, t, ctx, q, engine=True, phase_ups=False, **off):
         if i < n_lv - 1:
             if phase_ups:
                 nm = f'up_blocks.{i}.upsamplers.0.conv'
+                S.where = nm
                 h = S.res(upsample_conv_phases(op(h), c.w(nm + '.weight'), c.w(nm + '.bias'), q))
             else:
                 h = conv(F.interpolate(op(h), scale_factor=2.0, mode='nearest'), f'up_blocks.{i}.upsamplers.0.conv', qq=S.res)
+    S.where = 'conv_norm_out'
     h = S.norm(F.silu(F.group_norm(S.bin(h), cfg['norm_num_groups'], c.w('conv_norm_out.weight'), c.w('conv_norm_out.bias'), cfg['norm_eps'])))
     return F.conv2d(h, c.w('conv_out.weight'), c.w('conv_out.bias'), padding=1)
 

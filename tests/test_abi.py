@@ -167,23 +167,49 @@ def test_upsample_phase_conv_shape_rule():
     assert _lib.raw('mve_upsample_conv_phases_workspace_bytes')(1280, 1280, 2, 8, 8) == _lib.raw("mve_gemm_workspace_bytes")(4 * 128, 1280, 5120, 4 * 64)
 
 
+def test_effective_splitk_by_batch(lib):
+    """the K-slice count a launch RUNS with depends on its rows, not only on the rule (rows per image, N, K).  Pin the decisions at
+    the batches that matter -- 8 images (a rank of an 8-GPU job), 64 (one GPU, the benchmark), 128, 256 -- in the default and in the strict mode
+    (MVE_GEMM_STRICT_SPLITK / mve_gemm_tune bit 30 / parallel.set_partition_invariant), which reports the rule's count at every batch."""
+    from mvedit_amd import parallel
+    esk = lib.raw('mve_gemm_effective_splitk')
+    shapes = dict(conv_16x16=(256, 1280, 9 * 1280), conv_8x8=(64, 1280, 9 * 1280), conv_32x32=(1024, 640, 9 * 640), ff_out_8x8=(64, 1280, 5120))
+    got = {k: [esk(B * r, N, K, r) for B in (2, 8, 32, 64, 128, 256)] for k, (r, N, K) in shapes.items()}
+    assert got['conv_16x16'] == [4, 4, 2, 1, 1, 1]
+    assert got['conv_8x8'] == [8, 8, 8, 4, 2, 1]
+    assert got['conv_32x32'] == [2, 2, 1, 1, 1, 1]
+    assert got['ff_out_8x8'] == [8, 8, 8, 4, 2, 1]
+    assert parallel.set_partition_invariant(True) is False
+    try:
+        strict = {k: [esk(B * r, N, K, r) for B in (2, 8, 32, 64, 128, 256)] for k, (r, N, K) in shapes.items()}
+        assert all(len(set(v)) == 1 for v in strict.values()), strict      # the rule's count at every batch
+        assert [v[0] for v in strict.values()] == [4, 8, 2, 8]
+    finally:
+        assert parallel.set_partition_invariant(False) is True
+    assert esk(64 * 256, 1280, 9 * 1280, 256) == 1
+
+
 def test_residual_pair_is_a_plan_option(lib):
-    """mve_unet_set_residual_mode (plan-time only, no GPU): the pair mode doubles the residual-stream tensors of the workspace, keeps the op list,
-    round-trips, and is refused by the non-UNet executors."""
+    """mve_unet_set_residual_mode (plan-time only, no GPU): the pair mode -- the UNet's DEFAULT since round 5 -- doubles the residual-stream tensors
+    of the workspace, keeps the op list, round-trips, and is refused by the non-UNet executors; ControlNet handles start with the 16-bit stream."""
     import torch
     from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG
     eng = UNet2DConditionEngine(SD15_CONFIG, torch.float16, device='cpu')
-    a = eng.plan(2, 64, 64, 77)
-    assert eng.residual_pair is False and eng.set_residual_pair(True) is False and eng.residual_pair is True
-    ups_a = [(lab, fl) for _, _, fl, lab in eng.op_table() if lab.startswith('upsample+conv')]
+    assert eng.residual_pair is True                                # the default: end-to-end error inside north_star's 1e-3
     b = eng.plan(2, 64, 64, 77)
     ups_b = [(lab, fl) for _, _, fl, lab in eng.op_table() if lab.startswith('upsample+conv')]
-    # the default plan runs Upsample2D as four 2 x 2 phase convs (4 / 9 of the multiply-adds); the pair (accuracy) mode keeps the reference's 3 x 3 form
-    assert [l for l, _ in ups_a] == ['upsample+conv (4 phases)'] * 3 and [l for l, _ in ups_b] == ['upsample+conv'] * 3
+    assert eng.set_residual_pair(False) is True and eng.residual_pair is False
+    a = eng.plan(2, 64, 64, 77)
+    ups_a = [(lab, fl) for _, _, fl, lab in eng.op_table() if lab.startswith('upsample+conv')]
+    # either mode runs Upsample2D as four 2 x 2 phase convs (4 / 9 of the multiply-adds; the summed-weight rounding fits the pair mode's budget:
+    # tests/rounding_budget_experiment.py --phase)
+    assert [l for l, _ in ups_a] == ['upsample+conv (4 phases)'] * 3 and [l for l, _ in ups_b] == ['upsample+conv (4 phases)'] * 3
     assert [f for _, f in ups_a] == [f for _, f in ups_b]          # the plan prices an op at the reference's form of it (SURVEY.md 8(d)) either way
     assert b['n_ops'] == a['n_ops'] and b['flops'] == a['flops']
     assert a['workspace_bytes'] < b['workspace_bytes'] < 2 * a['workspace_bytes']
-    assert eng.set_residual_pair(False) is True and eng.plan(2, 64, 64, 77)['workspace_bytes'] == a['workspace_bytes']
+    assert eng.set_residual_pair(True) is False and eng.plan(2, 64, 64, 77)['workspace_bytes'] == b['workspace_bytes']
+    from mvedit_amd.controlnet import ControlNetEngine
+    assert ControlNetEngine(SD15_CONFIG, torch.float16, device='cpu').residual_pair is False
     from mvedit_amd.vae import AutoencoderKLEngine, SD_VAE_CONFIG
     vae = AutoencoderKLEngine(dict(SD_VAE_CONFIG), torch.float16, 'cpu')
     with pytest.raises(lib.MveError):

@@ -160,6 +160,18 @@ def test_shared_conditioning_images_are_bit_identical_to_repeated_ones(lib):
         calls.clear()
         p.get_noise_pred(chunks(lat), chunks(emb), chunks(half) * 2, chunks(dep) * 2, 500, 0.6, 0.4, 4.0)
         assert calls == [V, V]
+        # round 5: the form of the reference's ordinary branch -- `torch.cat([x] * 2).split(diff_bs)`, views of one tensor with equal halves -- is
+        # recognised too (Adapter3DMixin._cat_shared_cond: one device comparison of the halves)
+        calls.clear()
+        cat_split = p.get_noise_pred(chunks(lat), chunks(emb), chunks(torch.cat([half] * 2)), chunks(torch.cat([dep] * 2)), 500, 0.6, 0.4, 4.0)
+        assert calls == [V, V]
     finally:
         ControlNetEngine.run = run0
-    assert torch.equal(shared, explicit)
+    assert torch.equal(shared, explicit) and torch.equal(shared, cat_split)
+    # the 2-pass methods (adapter3d_mixin.py:137-317) on the same engines: depth net in pass 1, tile + depth in pass 2 (restored in round 5)
+    two_pass = []
+    for imgs, deps in ((chunks(half) * 2, chunks(dep) * 2), (chunks(half) + chunks(half.clone()), chunks(dep) + chunks(dep.clone()))):
+        n1, dec_args, dec_kwargs = p.get_noise_pred_p1(chunks(lat), chunks(emb), 500, 4.0, ctrl_depths_batches=deps, depth_weight=0.4)
+        two_pass.append((n1, p.get_noise_pred_p2(chunks(lat), chunks(emb), dec_args, dec_kwargs, 500, 4.0, imgs, 0.6, ctrl_depths_batches=deps,
+                                                 depth_weight=0.4)))
+    assert torch.equal(two_pass[0][0], two_pass[1][0]) and torch.equal(two_pass[0][1], two_pass[1][1])

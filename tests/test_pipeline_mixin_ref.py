@@ -98,9 +98,52 @@ def test_shared_control_images_of_the_cfg_halves_keep_the_reference_output(monke
     np.testing.assert_allclose(noise1.numpy(), G['2pass_plain_p1'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(noise2.numpy(), G['2pass_plain_p2'], rtol=1e-5, atol=1e-6)
     assert SharingMulti.seen == [[V, V], [V, V]]                             # pass 1: depth + extra; pass 2: tile + depth -- one half each
+    # the case as committed: `torch.cat([x] * 2).split(diff_bs)` -- the form of the reference's ordinary 1-pass branch (mvedit_3d_pipeline.py:1238-1241):
+    # different objects, consecutive views of one tensor with equal halves.  Round 5: recognised (the chunks viewed as that tensor again + one
+    # comparison of its halves), unless the comparison is switched off; chunks that own their storage are never assumed to repeat
     SharingMulti.seen = []
-    with torch.no_grad():                                                    # the case as committed: concatenated-then-split tensors, different objects
+    with torch.no_grad():
         noise1, dec_args, dec_kwargs = pipe.get_noise_pred_p1(**kw['p1'])
-        pipe.get_noise_pred_p2(dec_args=dec_args, dec_kwargs=dec_kwargs, **kw['p2'])
-    assert SharingMulti.seen == [[2 * V, 2 * V], [2 * V, 2 * V]]
+        noise2 = pipe.get_noise_pred_p2(dec_args=dec_args, dec_kwargs=dec_kwargs, **kw['p2'])
+    assert SharingMulti.seen == [[V, V], [V, V]]
     np.testing.assert_allclose(noise1.numpy(), G['2pass_plain_p1'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(noise2.numpy(), G['2pass_plain_p2'], rtol=1e-5, atol=1e-6)
+    for variant in ('off', 'clones', 'halves_differ'):
+        q1, q2 = dict(kw['p1']), dict(kw['p2'])
+        if variant == 'clones':
+            for d, keys in ((q1, ('ctrl_depths_batches',)), (q2, ('ctrl_images_batches', 'ctrl_depths_batches'))):
+                for k in keys:
+                    d[k] = tuple(b.clone() for b in d[k])
+            q1['extra_control_batches'] = [tuple(b.clone() for b in e) for e in q1['extra_control_batches']]
+        if variant == 'halves_differ':
+            x = torch.cat(list(q2['ctrl_images_batches'])).clone()
+            x[-1] += 1.0
+            q2['ctrl_images_batches'] = x.split(q2['ctrl_images_batches'][0].shape[0])
+        pipe.detect_repeated_cond = variant != 'off'
+        SharingMulti.seen = []
+        with torch.no_grad():
+            n1, da, dk = pipe.get_noise_pred_p1(**q1)
+            pipe.get_noise_pred_p2(dec_args=da, dec_kwargs=dk, **q2)
+        pipe.detect_repeated_cond = True
+        assert SharingMulti.seen == ([[V, V], [2 * V, V]] if variant == 'halves_differ' else [[2 * V, 2 * V], [2 * V, 2 * V]]), (variant, SharingMulti.seen)
+        np.testing.assert_allclose(n1.numpy(), G['2pass_plain_p1'], rtol=1e-5, atol=1e-6)
+
+
+def test_chunks_viewed_as_one_tensor():
+    """Adapter3DMixin._as_one_tensor: `x.split(n)` chunks (ragged last chunk, a chunk straddling the CFG halves) give x back without a copy; anything
+    else -- reordered, cloned, strided, mixed dtypes -- gives None."""
+    from mvedit_amd.pipelines import Adapter3DMixin as A
+    x = torch.arange(64 * 3 * 2 * 2, dtype=torch.float32).reshape(64, 3, 2, 2)
+    for n in (6, 8, 64, 5):
+        y = A._as_one_tensor(list(x.split(n)))
+        assert y is not None and y.data_ptr() == x.data_ptr() and torch.equal(y, x)
+    ch = list(x.split(6))
+    assert A._as_one_tensor(ch[1:]) is not None and torch.equal(A._as_one_tensor(ch[1:]), x[6:])
+    assert A._as_one_tensor([ch[1], ch[0]]) is None
+    assert A._as_one_tensor([ch[0], ch[1].clone()]) is None
+    assert A._as_one_tensor([ch[0], ch[2]]) is None                        # a gap
+    assert A._as_one_tensor(list(x[:, :, :1].split(6))) is None            # not contiguous
+    assert A._as_one_tensor([ch[0], ch[1].double()]) is None
+    two = torch.cat([x[:32]] * 2)
+    assert torch.equal(A()._cat_shared_cond(list(two.split(6))), x[:32])   # 11 chunks, the sixth straddles the halves
+    assert A()._cat_shared_cond(list(x.split(6))).shape[0] == 64           # halves differ: whole
