@@ -88,9 +88,13 @@ __global__ __launch_bounds__(NT) void k_axpy_pair(const typename Tag::T* __restr
     V8 o, ol;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float v = (Tag::to_f32(va[e]) + Tag::to_f32(vl[e])) + alpha * Tag::to_f32(vb[e]);
+        const float add = alpha * Tag::to_f32(vb[e]);
+        const float v = (Tag::to_f32(va[e]) + Tag::to_f32(vl[e])) + add;
         o[e] = Tag::from_f32(v);
         ol[e] = Tag::from_f32(v - Tag::to_f32(o[e]));
+        // adding nothing must change nothing, bit for bit (unet_dec without ControlNet feeds zero residuals through this kernel): re-splitting
+        // hi + lo can move hi by one step when |lo| rounded up to exactly half a step of an odd hi
+        if (add == 0.f) { o[e] = va[e]; ol[e] = vl[e]; }
     }
     reinterpret_cast<V8*>(y)[i] = o;
     reinterpret_cast<V8*>(yl)[i] = ol;

@@ -73,10 +73,11 @@ def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, o
 
 
 def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec=None, residual=None, flags=0,
-            out_scale=1.0, splitk=True):
+            out_scale=1.0, splitk=True, residual_lo=None, pair_out=False):
     """x1 [B*H*W, C1] (+ x2 [B*H*W, C2]) NHWC, w [Cout,3,3,C1+C2] -> ([B*Ho*Wo, Cout], Ho, Wo).
-    With flags & W_CHUNK64 the weight is [Cout, (C1+C2)/64, 3, 3, 64] (see pack_conv_weight)."""
-    _chk16(x1, x2, w, residual)
+    With flags & W_CHUNK64 the weight is [Cout, (C1+C2)/64, 3, 3, 64] (see pack_conv_weight).
+    residual_lo / pair_out: the residual-pair entry point (mve_conv3x3_pair) -> ((out, out_lo), Ho, Wo) with pair_out."""
+    _chk16(x1, x2, w, residual, residual_lo)
     C1 = x1.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
     Cout = w.shape[0]
@@ -85,6 +86,15 @@ def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec
     Ho, Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
     out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32 if flags & OUT_F32 else x1.dtype, device=x1.device)
     ws, ws_bytes = _splitk_ws(B * Ho * Wo, Cout, 9 * (C1 + C2), x1.device, Ho * Wo if splitk else 0)
+    if residual_lo is not None or pair_out:
+        out_lo = torch.empty_like(out) if pair_out else None
+        with torch.cuda.device(x1.device):
+            _lib.call('mve_conv3x3_pair', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x2), C2, B, H, W, stride, int(bool(upsample)),
+                      _lib.ptr(w), Cout, _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(rowvec),
+                      rowvec.stride(0) if rowvec is not None else 0, _lib.ptr(residual),
+                      residual.stride(0) if residual is not None else 0, int(flags), float(out_scale), _lib.ptr(ws), ws_bytes,
+                      _lib.ptr(residual_lo), _lib.ptr(out_lo), _s(x1))
+        return ((out, out_lo) if pair_out else out), Ho, Wo
     with torch.cuda.device(x1.device):
         _lib.call('mve_conv3x3', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x2), C2, B, H, W, stride, int(bool(upsample)),
                   _lib.ptr(w), Cout, _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(rowvec),
@@ -93,9 +103,10 @@ def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec
     return out, Ho, Wo
 
 
-def conv3x3_shortcut(x1, w, B, H, W, x3, x4=None, bias=None, bias2=None, residual=None, splitk=True):
+def conv3x3_shortcut(x1, w, B, H, W, x3, x4=None, bias=None, bias2=None, residual=None, splitk=True, pair_out=False):
     """ResnetBlock2D tail in one launch: conv3x3(x1) + conv1x1(cat[x3, x4]) + bias + bias2 (+ residual).
-    w [Cout, 9*C1 + C3 + C4]: 3x3 part in the channel-slab-major order of pack_conv_weight(..., True), then the 1x1 matrix."""
+    w [Cout, 9*C1 + C3 + C4]: 3x3 part in the channel-slab-major order of pack_conv_weight(..., True), then the 1x1 matrix.
+    pair_out (no residual): mve_conv3x3_shortcut_pair -> (out, out_lo)."""
     _chk16(x1, x3, x4, w, residual)
     C1, C3 = x1.shape[1], x3.shape[1]
     C4 = x4.shape[1] if x4 is not None else 0
@@ -103,6 +114,13 @@ def conv3x3_shortcut(x1, w, B, H, W, x3, x4=None, bias=None, bias2=None, residua
     assert w.numel() == Cout * (9 * C1 + C3 + C4)
     out = torch.empty(B * H * W, Cout, dtype=x1.dtype, device=x1.device)
     ws, ws_bytes = _splitk_ws(B * H * W, Cout, 9 * C1 + C3 + C4, x1.device, H * W if splitk else 0)
+    if pair_out:
+        assert residual is None
+        out_lo = torch.empty_like(out)
+        with torch.cuda.device(x1.device):
+            _lib.call('mve_conv3x3_shortcut_pair', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x3), C3, _lib.ptr(x4), C4, B, H, W, _lib.ptr(w), Cout,
+                      _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(bias2), 0, 1.0, _lib.ptr(ws), ws_bytes, _lib.ptr(out_lo), _s(x1))
+        return out, out_lo
     with torch.cuda.device(x1.device):
         _lib.call('mve_conv3x3_shortcut', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x3), C3, _lib.ptr(x4), C4, B, H, W, _lib.ptr(w), Cout,
                   _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(bias2), _lib.ptr(residual),

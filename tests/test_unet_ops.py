@@ -837,6 +837,65 @@ def test_gemm_residual_pair(lib, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_pair_launches_round_identically_on_every_tile(lib, dtype):
+    """Round 5: the residual pair is the executor's DEFAULT mode, so batch / partition invariance must hold in it: a pair launch gives the same
+    (hi, lo) BITS on the 256-row tile (k_gemm_pp<PAIR>: accumulators started from the residual) and on the 128-row kernel (round 5: started from
+    the residual too) -- dense GEMM, 3 x 3 conv with a residual pair, conv + fused shortcut, with a per-image row vector -- and the conv results
+    stay inside the 1e-3 bar of the fp32 reference.  Without a residual the high half is the plain launch's output bit for bit."""
+    from mvedit_amd import ops, _lib
+    tune = _lib.raw('mve_gemm_tune')
+    old = tune(-1)
+    g = torch.Generator().manual_seed(17)
+    try:
+        def both(fn):
+            outs = []
+            for word in (1, 0):                      # 256-row tile wherever it fits / 128-row kernel only
+                tune(word)
+                outs.append(fn())
+            return outs
+        # dense GEMM with a residual pair, bias
+        for (M, N, K) in [(4096, 320, 320), (2048, 640, 2560), (1024, 1280, 1280)]:
+            a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+            bias = rnd((N,), torch.float32, 3)
+            rh, rl = _split_pair(torch.randn(M, N, generator=g) * 3, dtype)
+            (h1, l1), (h0, l0) = both(lambda: ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=rh.cuda(), residual_lo=rl.cuda(), pair_out=True))
+            assert torch.equal(h1, h0) and torch.equal(l1, l0), ('gemm', M, N, K, int((h1 != h0).sum()), int((l1 != l0).sum()))
+        # 3 x 3 conv (slab-major weights) with a residual pair, bias and a per-image row vector
+        for (B, H, C, Cout) in [(4, 32, 320, 320), (2, 32, 640, 640), (16, 8, 1280, 1280)]:
+            x = rnd((B * H * H, C), dtype, 4)
+            w, fl = ops.pack_conv_weight(rnd((Cout, C, 3, 3), dtype, 5, (9 * C) ** -0.5))
+            bias, rv = rnd((Cout,), torch.float32, 6), rnd((B, Cout), torch.float32, 7)
+            r32 = torch.randn(B * H * H, Cout, generator=g) * 2
+            rh, rl = _split_pair(r32, dtype)
+            run = lambda: ops.conv3x3(x.cuda(), w.cuda(), B, H, H, bias=bias.cuda(), rowvec=rv.cuda(), residual=rh.cuda(), residual_lo=rl.cuda(),
+                                      flags=fl, splitk=False, pair_out=True)[0]
+            (h1, l1), (h0, l0) = both(run)
+            assert torch.equal(h1, h0) and torch.equal(l1, l0), ('conv', B, H, C, Cout, int((h1 != h0).sum()), int((l1 != l0).sum()))
+            xi = x.float().view(B, H, H, C).permute(0, 3, 1, 2)
+            wi = w.float().view(Cout, C // 64, 3, 3, 64).permute(0, 1, 4, 2, 3).reshape(Cout, C, 3, 3)
+            ref = F.conv2d(xi, wi, bias, padding=1) + rv[:, :, None, None]
+            ref = ref.permute(0, 2, 3, 1).reshape(B * H * H, Cout) + (rh.float() + rl.float())
+            got = h1.float().cpu() + l1.float().cpu()
+            assert float((got - ref).norm() / ref.norm()) < 1e-3, ('conv', B, H, C, Cout)
+            assert float((got - ref).abs().max() / ref.abs().max()) < (5e-5 if dtype == torch.float16 else 4e-4)
+        # conv + fused 1 x 1 shortcut, pair output, no residual: hi == the plain launch, lo is its rounding remainder
+        B, H, C1, C3, Cout = 4, 32, 640, 320, 640
+        h2, x3 = rnd((B * H * H, Cout), dtype, 8), rnd((B * H * H, C3), dtype, 9)
+        w3 = ops.pack_conv_weight(rnd((Cout, Cout, 3, 3), dtype, 10, (9 * Cout) ** -0.5))[0].reshape(Cout, -1)
+        wsc = rnd((Cout, C3), dtype, 11, C3 ** -0.5)
+        wcat = torch.cat([w3, wsc], 1).contiguous()
+        b2, bs = rnd((Cout,), torch.float32, 12), rnd((Cout,), torch.float32, 13)
+        (h1, l1), (h0, l0) = both(lambda: ops.conv3x3_shortcut(h2.cuda(), wcat.cuda(), B, H, H, x3.cuda(), bias=b2.cuda(), bias2=bs.cuda(), splitk=False, pair_out=True))
+        assert torch.equal(h1, h0) and torch.equal(l1, l0)
+        tune(1)
+        plain = ops.conv3x3_shortcut(h2.cuda(), wcat.cuda(), B, H, H, x3.cuda(), bias=b2.cuda(), bias2=bs.cuda(), splitk=False)
+        assert torch.equal(plain, h1)
+    finally:
+        tune(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 def test_norms_read_the_residual_pair(lib, dtype):
     """mve_groupnorm_silu_pair / mve_layernorm_pair: statistics and normalisation over hi + lo equal the plain kernels run on an input whose
     16-bit rounding is exact (lo = 0: bitwise), and track the fp32 reference of the unrounded input more closely than the rounded input does."""
