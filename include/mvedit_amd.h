@@ -253,18 +253,21 @@ MVE_API int mve_pack_upsample_phase_weights(int src_dtype, int dst_dtype, const 
 MVE_API int mve_upsample_conv_phases(int dtype, const void* d_x, int C, int B, int Hs, int Ws, const void* d_W4, int Cout, void* d_out,
                                      const float* d_bias, int flags, void* d_workspace, size_t workspace_bytes, void* d_out_lo, void* stream);
 
-/* ---- residual stream as an unrounded pair (round 4; the executor's `residual_pair` mode, mve_unet_set_residual_mode) -----------------------------
+/* ---- residual stream as an unrounded pair (the executor's `residual_pair` mode, mve_unet_set_residual_mode; round 4, the UNet's DEFAULT since round 5) ----
  * The reference's half-precision modules round the residual stream x + f(x) of ResnetBlock2D / BasicTransformerBlock / Transformer2DModel
  * (diffusers 0.27.2, driven from lib/models/architecture/diffusers.py:57-164) to 16 bits after every block: ~30 % of the end-to-end error against
  * fp32 arithmetic (tests/rounding_budget_experiment.py).  In pair mode a stream tensor is stored as hi = round16(x) -- what every MFMA operand
- * read sees, in the tensor's usual place -- and lo = round16(x - hi) in a companion tensor of the same shape: ~22 mantissa bits together.
- * The *_pair entry points are the plain ones plus the companions:
- *   d_residual_lo : low half of the residual ([M][ldr], NULL = the residual is `d_residual` alone); needs a residual added before the scale;
- *   d_out_lo      : receives round16(v - round16(v)) next to d_out = round16(v) ([M][ldc], NULL = not wanted); 16-bit non-GEGLU outputs only;
- *   d_x*_lo       : low halves of the normalised inputs (NULL = the input is the 16-bit tensor alone); statistics and the normalisation use hi + lo.
- * With both companions NULL every *_pair call IS the plain call.  The 256-row tile starts its accumulators from the residual pair (one fp32
- * addition order differs from the other kernels' (sum + bias) + residual), so in pair mode the 128-row and 256-row kernels agree to fp32 rounding,
- * not bitwise. */
+ * read sees, in the tensor's usual place -- and an 8-BIT low half in a companion tensor of the same shape, one byte per element:
+ *   lo8 = E5M2( 2^8 * (x - hi) )   (round to nearest even; OCP E5M2 = torch.float8_e5m2; x ~= hi + 2^-8 * lo8, ~14 mantissa bits for fp16 storage).
+ * Round 4 kept the low half in 16 bits; 8 bits lose nothing that the end-to-end error can see (8.6e-4 vs 8.7e-4 from fp32 arithmetic at the
+ * benchmark shape, 1.23e-3 without a low half) and halve its HBM traffic.  The *_pair entry points are the plain ones plus the companions:
+ *   d_residual_lo : lo8 of the residual ([M][ldr] BYTES, NULL = the residual is `d_residual` alone); needs a residual added before the scale;
+ *   d_out_lo      : receives lo8(v - round16(v)) next to d_out = round16(v) ([M][ldc] BYTES, NULL = not wanted); 16-bit non-GEGLU outputs only;
+ *   d_x*_lo       : lo8 of the normalised inputs (NULL = the input is the 16-bit tensor alone); statistics and the normalisation use hi + lo.
+ * With both companions NULL every *_pair call IS the plain call.  A pair launch that is not K-sliced starts its accumulators from the residual
+ * pair -- residual + sum_k a w, then + bias -- on EVERY tile the dispatcher may pick (round 5: the 128-row kernel too), so pair launches are
+ * bit-identical across tiles exactly as plain launches are (tests/test_unet_ops.py::test_pair_launches_round_identically_on_every_tile); a
+ * K-sliced launch adds the pair in the reducer. */
 MVE_API int mve_gemm_pair(int dtype, const void* d_A, int lda, const void* d_W, int ldw, void* d_out, int ldc,
                           int M, int N, int K, const float* d_bias, const float* d_rowvec, int ldrv, int rows_per_vec,
                           const void* d_residual, int ldr, int flags, float out_scale, void* d_workspace,
@@ -281,7 +284,8 @@ MVE_API int mve_groupnorm_silu_pair(int dtype, const void* d_x1, int C1, const v
                                     void* d_workspace, const void* d_x1_lo, const void* d_x2_lo, void* stream);
 MVE_API int mve_layernorm_pair(int dtype, const void* d_x, int ldx, void* d_y, int ldy, int M, int C,
                                const float* d_gamma, const float* d_beta, float eps, const void* d_x_lo, void* stream);
-/* (hi, lo) = pair of ((a_hi + a_lo) + alpha * b): the ControlNet residual added to a skip tensor of the stream (diffusers.py:110-121) */
+/* (hi, lo8) = pair of ((a_hi + a_lo) + alpha * b): the ControlNet residual added to a skip tensor of the stream (diffusers.py:110-121); the low halves
+ * are lo8 bytes; an all-zero addend leaves the pair untouched bit for bit */
 MVE_API int mve_axpy_pair(int dtype, const void* d_a, const void* d_a_lo, const void* d_b, float alpha, void* d_y, void* d_y_lo, size_t n, void* stream);
 
 /* Scaled-dot-product attention over packed projections (no head permutes):

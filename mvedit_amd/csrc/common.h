@@ -95,6 +95,42 @@ struct BF16Tag {
     }
 };
 
+// ---------------------------------------------------------------------------
+// The low half of a residual-stream pair: 8 bits per element (round 5; 16 bits in round 4).  A stream value v is stored as
+// hi = round16(v) -- the tensor every MFMA operand read sees -- plus lo8 = E5M2(2^8 (v - hi)) (v_cvt_pk_bf8_f32: round to nearest even; gfx950's
+// bf8 is the OCP E5M2, what torch.float8_e5m2 holds).  |v - hi| <= ulp(hi) / 2, so two mantissa bits of it leave hi + lo within 2^-3 of half a step:
+// ~3 more bits than hi alone, which is all the end-to-end budget needs (tests/rounding_budget_experiment.py --lo8: 8.6e-4 against 8.7e-4 with a
+// 16-bit low half, 1.23e-3 without one) at half the low half's HBM traffic.  The scale keeps the remainder of any |v| >= 2^-11 out of E5M2's
+// subnormals.  Four elements per dword, element e in byte e.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mve_lo8_pack4(float a, float b, float c, float d) {
+    int p = __builtin_amdgcn_cvt_pk_bf8_f32(a * 256.f, b * 256.f, 0, false);
+    p = __builtin_amdgcn_cvt_pk_bf8_f32(c * 256.f, d * 256.f, p, true);
+    return (unsigned)p;
+}
+__device__ __forceinline__ void mve_lo8_unpack4(unsigned p, float (&o)[4]) {
+    const auto a = __builtin_amdgcn_cvt_pk_f32_bf8((int)p, false), b = __builtin_amdgcn_cvt_pk_f32_bf8((int)p, true);
+    o[0] = a[0] * 0.00390625f; o[1] = a[1] * 0.00390625f; o[2] = b[0] * 0.00390625f; o[3] = b[1] * 0.00390625f;
+}
+// 8 consecutive elements: hi + lo (exact in fp32) from the 16-bit vector and the two lo8 dwords
+template <class Tag>
+__device__ __forceinline__ void mve_pair_load8(const typename Tag::V8& h, u32x2 l, float (&v)[8]) {
+    float a[4], b[4];
+    mve_lo8_unpack4(l[0], a);
+    mve_lo8_unpack4(l[1], b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = Tag::to_f32(h[e]) + a[e]; v[4 + e] = Tag::to_f32(h[4 + e]) + b[e]; }
+}
+// the pair of 8 fp32 values: hi (16-bit vector) and the two lo8 dwords
+template <class Tag>
+__device__ __forceinline__ u32x2 mve_pair_split8(const float (&v)[8], typename Tag::V8& hi) {
+#pragma clang fp contract(off)
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hi[e] = Tag::from_f32(v[e]); r[e] = v[e] - Tag::to_f32(hi[e]); }
+    return u32x2{mve_lo8_pack4(r[0], r[1], r[2], r[3]), mve_lo8_pack4(r[4], r[5], r[6], r[7])};
+}
+
 // dispatch a templated launcher on the runtime dtype code
 #define MVE_DISPATCH_16(dtype, FN, ...)                                \
     ((dtype) == MVE_F16 ? FN<F16Tag>(__VA_ARGS__)                      \

@@ -73,31 +73,35 @@ __global__ __launch_bounds__(NT) void k_axpy(const typename Tag::T* __restrict__
     reinterpret_cast<V8*>(y)[i] = o;
 }
 
-// (y, y_lo) = pair of (a + a_lo) + alpha * b: a stream tensor of the executor's residual_pair mode plus a 16-bit addend
+// (y, y_lo) = pair of (a + a_lo) + alpha * b: a stream tensor of the executor's residual_pair mode plus a 16-bit addend; the low halves are lo8
+// (one byte per element, common.h)
 template <class Tag>
-__global__ __launch_bounds__(NT) void k_axpy_pair(const typename Tag::T* __restrict__ a, const typename Tag::T* __restrict__ al,
+__global__ __launch_bounds__(NT) void k_axpy_pair(const typename Tag::T* __restrict__ a, const unsigned char* __restrict__ al,
                                                   const typename Tag::T* __restrict__ b, float alpha, typename Tag::T* __restrict__ y,
-                                                  typename Tag::T* __restrict__ yl, size_t n8) {
+                                                  unsigned char* __restrict__ yl, size_t n8) {
 #pragma clang fp contract(off)
     typedef typename Tag::V8 V8;
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= n8) return;
     const V8 va = reinterpret_cast<const V8*>(a)[i], vb = reinterpret_cast<const V8*>(b)[i];
-    V8 vl = {};
-    if (al) vl = reinterpret_cast<const V8*>(al)[i];
-    V8 o, ol;
+    u32x2 vl = {0u, 0u};
+    if (al) vl = reinterpret_cast<const u32x2*>(al)[i];
+    float s[8], v[8];
+    mve_pair_load8<Tag>(va, vl, s);
+    bool nothing = true;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float add = alpha * Tag::to_f32(vb[e]);
-        const float v = (Tag::to_f32(va[e]) + Tag::to_f32(vl[e])) + add;
-        o[e] = Tag::from_f32(v);
-        ol[e] = Tag::from_f32(v - Tag::to_f32(o[e]));
-        // adding nothing must change nothing, bit for bit (unet_dec without ControlNet feeds zero residuals through this kernel): re-splitting
-        // hi + lo can move hi by one step when |lo| rounded up to exactly half a step of an odd hi
-        if (add == 0.f) { o[e] = va[e]; ol[e] = vl[e]; }
+        nothing = nothing && add == 0.f;
+        v[e] = s[e] + add;
     }
+    V8 o;
+    u32x2 ol = mve_pair_split8<Tag>(v, o);
+    // adding nothing must change nothing, bit for bit (unet_dec without ControlNet feeds zero residuals through this kernel): re-splitting
+    // hi + lo can move hi by one step when |lo| was rounded up to exactly half a step of an odd hi
+    if (nothing) { o = va; ol = vl; }
     reinterpret_cast<V8*>(y)[i] = o;
-    reinterpret_cast<V8*>(yl)[i] = ol;
+    reinterpret_cast<u32x2*>(yl)[i] = ol;
 }
 
 // noise = g * text + (1 - g) * uncond   on f32 NCHW latents (adapter3d_mixin.py:130-134)
@@ -312,8 +316,8 @@ int mve_axpy_pair(int dtype, const void* a, const void* a_lo, const void* b, flo
     if (n == 0) return MVE_OK;
     MVE_CHECK(a && b && y && n % 8 == 0, MVE_ERR_ARG, "axpy_pair: n must be a multiple of 8");
     const unsigned grid = mve_cdiv(n / 8, NT);
-    if (dtype == MVE_F16) k_axpy_pair<F16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const f16*)a, (const f16*)a_lo, (const f16*)b, alpha, (f16*)y, (f16*)y_lo, n / 8);
-    else if (dtype == MVE_BF16) k_axpy_pair<BF16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const bf16*)a, (const bf16*)a_lo, (const bf16*)b, alpha, (bf16*)y, (bf16*)y_lo, n / 8);
+    if (dtype == MVE_F16) k_axpy_pair<F16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const f16*)a, (const unsigned char*)a_lo, (const f16*)b, alpha, (f16*)y, (unsigned char*)y_lo, n / 8);
+    else if (dtype == MVE_BF16) k_axpy_pair<BF16Tag><<<grid, NT, 0, (hipStream_t)stream>>>((const bf16*)a, (const unsigned char*)a_lo, (const bf16*)b, alpha, (bf16*)y, (unsigned char*)y_lo, n / 8);
     else { mve_set_error("axpy_pair: bad dtype"); return MVE_ERR_ARG; }
     MVE_LAUNCH_CHECK();
     return MVE_OK;

@@ -23,14 +23,14 @@ struct Builder {
     Builder(Unet& u_, Plan& p) : u(u_), pl(p), c(u_.cfg) {}
 
     Ref ws(size_t bytes) { Ref r; r.kind = Ref::WS; r.off = ar.alloc(bytes); return r; }
-    // residual_pair mode (AttnOpts::residual_pair): a tensor of the residual stream gets a companion of the same size for its low half.  The
+    // residual_pair mode (AttnOpts::residual_pair): a tensor of the residual stream gets a companion of half its size for its 8-bit low half.  The
     // companion is found through the high half's workspace offset, so the ops below pick it up by themselves: an output with a companion is
     // written as a pair, a residual / normalised input with a companion is read as one.  Everything else -- every MFMA operand read -- sees the
     // high half alone, exactly the tensor of the plain mode.
     std::map<size_t, Ref> lo_of;
     Ref ws_stream(size_t bytes) {
         Ref r = ws(bytes);
-        if (pl.ao.residual_pair) lo_of[r.off] = ws(bytes);
+        if (pl.ao.residual_pair) lo_of[r.off] = ws(bytes / 2);      // lo8: one byte per 16-bit element (common.h)
         return r;
     }
     Ref lo(const Ref& r) const {

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     if (res_in_acc) {
         typedef T T4 __attribute__((ext_vector_type(4)));
         const T* rh = reinterpret_cast<const T*>(p.residual);
-        const T* rl = reinterpret_cast<const T*>(p.residual_lo);
+        const unsigned char* rl = reinterpret_cast<const unsigned char*>(p.residual_lo);      // lo8: one byte per element (common.h)
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -235,9 +235,10 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
                 n = n + 4 <= p.N ? n : 0;                     // (a dead column group of the last tile: never stored)
                 const size_t ro = (size_t)m * p.ldr + n;
                 const T4 h = *reinterpret_cast<const T4*>(rh + ro);
-                const T4 l = rl ? *reinterpret_cast<const T4*>(rl + ro) : T4{};
+                float l[4] = {0.f, 0.f, 0.f, 0.f};
+                if (rl) mve_lo8_unpack4(*reinterpret_cast<const unsigned*>(rl + ro), l);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j][i][e] = Tag::to_f32(h[e]) + Tag::to_f32(l[e]);
+                for (int e = 0; e < 4; ++e) acc[j][i][e] = Tag::to_f32(h[e]) + l[e];
             }
         }
     }
@@ -818,7 +819,7 @@ int mve_upsample_conv_phases(int dtype, const void* x, int C, int B, int Hs, int
         p.W = (const char*)W4 + (size_t)ph * Cout * p.K * 2;
         const size_t o0 = ((size_t)py * 2 * Ws + px) * Cout * 2;       // bytes: pixel (py, px) of image 0
         p.out = (char*)out + o0;
-        p.out_lo = out_lo ? (char*)out_lo + o0 : nullptr;
+        p.out_lo = out_lo ? (char*)out_lo + o0 / 2 : nullptr;         // (lo8: one byte per element)
         p.bias = bias;
         p.ldc = 2 * Cout; p.ldw = p.K;
         p.orow_shift = lw; p.orow_extra = 2 * Ws * Cout;

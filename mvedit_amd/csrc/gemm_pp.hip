@@ -281,24 +281,27 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
             typedef typename Tag::T T;
             typedef T T4 __attribute__((ext_vector_type(4)));
             const T* rh = reinterpret_cast<const T*>(p.residual);
-            const T* rl = reinterpret_cast<const T*>(p.residual_lo);
+            const unsigned char* rl = reinterpret_cast<const unsigned char*>(p.residual_lo);      // lo8: one byte per element (common.h)
             const int col = n0 + wn * WTN + (lane >> 4) * 4;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {                   // one fragment row at a time (10 loads in flight): hoisted to the top, the 80 loads would spill
                 int m = m0 + wm * WTM + i * 16 + (lane & 15);
                 m = m < p.M ? m : p.M - 1;
                 const size_t ro = (size_t)m * p.ldr + col;
-                T4 h[NF], l[NF];
+                T4 h[NF];
+                unsigned l[NF];
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     h[j] = *reinterpret_cast<const T4*>(rh + ro + j * 16);
-                    l[j] = rl ? *reinterpret_cast<const T4*>(rl + ro + j * 16) : T4{};
+                    l[j] = rl ? *reinterpret_cast<const unsigned*>(rl + ro + j * 16) : 0u;       // (E5M2 zero is all-zero bits)
                 }
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {               // (whole-vector assignment: element writes through the captured reference keep `acc` in scratch)
                     f32x4 a;
+                    float lf[4];
+                    mve_lo8_unpack4(l[j], lf);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = Tag::to_f32(h[j][e]) + Tag::to_f32(l[j][e]);
+                    for (int e = 0; e < 4; ++e) a[e] = Tag::to_f32(h[j][e]) + lf[e];
                     acc[j][i] = a;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -712,6 +715,7 @@ void mve_gemm_pp_old_swizzle(int on) { g_pp_old_swizzle = on ? 1 : 0; }
 int mve_gemm_pp_launch(int dtype, int mode, const void* params, void* stream) {
     GemmParams p = *reinterpret_cast<const GemmParams*>(params);
     p.old_swizzle = g_pp_old_swizzle;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MVE_PP_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     hipStream_t s = (hipStream_t)stream;
     if (p.tile_n == 161) {               // the caller asks for the two-blocks-per-CU tile
         if (!pp2_eligible(mode, p)) return 1;

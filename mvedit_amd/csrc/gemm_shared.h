@@ -47,10 +47,11 @@ struct GemmParams {
     const float* bias;       // [N] or null
     const float* rowvec;     // [M/rows_per_vec][ldrv] f32 (time embedding), or null
     const void* residual;    // [M][ldr] 16-bit or null
-    // Residual stream as an unrounded pair (round 4, the executor's `residual_pair` mode): a stream tensor x is stored as hi = round16(x) -- what every
-    // MFMA operand read sees -- and lo = round16(x - hi), together ~22 mantissa bits.  Both null: the single 16-bit tensors of rounds 1-3.
-    const void* residual_lo; // [M][ldr] 16-bit: the low half of the residual, or null (residual is then the whole value)
-    void* out_lo;            // [M][ldc] 16-bit: receives round16(v - round16(v)) next to out = round16(v), or null
+    // Residual stream as an unrounded pair (round 4, the executor's `residual_pair` mode; the default since round 5): a stream tensor x is stored as
+    // hi = round16(x) -- what every MFMA operand read sees -- and an 8-bit low half lo8 = E5M2(2^8 (x - hi)) (common.h: mve_lo8_*; 16 bits in round 4).
+    // Both null: the single 16-bit tensors of rounds 1-3.
+    const void* residual_lo; // [M][ldr] BYTES: the low half of the residual, or null (residual is then the whole value)
+    void* out_lo;            // [M][ldc] BYTES: receives lo8(v - round16(v)) next to out = round16(v), or null
     int M, N, K;
     int lda, ldw, ldc, ldr, ldrv;   // row strides (elements) of A, W, out, residual, rowvec
     int rows_per_vec;
@@ -66,6 +67,7 @@ struct GemmParams {
     int tile_n;        // 256-row ping-pong tile only: 0 = widest width that divides N (320 / 256 / 128); 160 = the 160-wide tile (N % 160 == 0),
                        // which the dispatcher picks when the 320-wide tiling would leave CUs without a block (small batches)
     int old_swizzle;   // ping-pong tile only, A/B aid: 1 = round 2's ring swizzle (2-way bank conflicts on every fragment read)
+    int dbg;           // development switches of the residual-pair epilogue (MVE_PP_DBG; 0 in every shipped path)
     // Output rows in groups: row m of out (and out_lo) starts at element m * ldc + (m >> orow_shift) * orow_extra.  orow_extra = 0: plain rows.
     // The phase convs of mve_upsample_conv_phases write pixel (b, i, j) of a [B][H][W] launch to pixel (b, 2 i + py, 2 j + px) of the [B][2H][2W]
     // NHWC output: ldc = 2 C, orow_shift = log2 W, orow_extra = 2 W C, base shifted by (py 2 W + px) C.
@@ -116,9 +118,11 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
     typedef typename Tag::V8 V8;
     if (!RES_DONE && p.residual && !p.res_after_scale) {
         if (PAIR && p.residual_lo) {     // the pair is added as ONE value: hi + lo is exact in fp32 (|lo| <= ulp(hi) / 2)
-            const V8 rl = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual_lo) + (size_t)m * p.ldr + n);
+            const u32x2 rl = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.residual_lo) + (size_t)m * p.ldr + n);
+            float r8[8];
+            mve_pair_load8<Tag>(rr, rl, r8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]) + Tag::to_f32(rl[e]);
+            for (int e = 0; e < 8; ++e) v[e] += r8[e];
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += Tag::to_f32(rr[e]);
@@ -151,10 +155,11 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
         T* op = reinterpret_cast<T*>(p.out) + orow + n;
         if (ok) *reinterpret_cast<V8*>(op) = pk;
         if (PAIR && p.out_lo) {
-            V8 pl;
+            float r[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pl[e] = Tag::from_f32(v[e] - Tag::to_f32(pk[e]));
-            if (ok) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.out_lo) + orow + n) = pl;
+            for (int e = 0; e < 8; ++e) r[e] = v[e] - Tag::to_f32(pk[e]);
+            const u32x2 pl = {mve_lo8_pack4(r[0], r[1], r[2], r[3]), mve_lo8_pack4(r[4], r[5], r[6], r[7])};
+            if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.out_lo) + orow + n) = pl;
         }
     }
 }

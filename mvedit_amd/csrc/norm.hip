@@ -31,7 +31,7 @@ struct GNSrc {
     const void* x1; const void* x2;
     int C1, C2;       // channels of each source (C2 may be 0)
     int HW, B;
-    const void* x1_lo; const void* x2_lo;      // residual_pair mode: low halves of the sources (the value is hi + lo), or null
+    const void* x1_lo; const void* x2_lo;      // residual_pair mode: 8-bit low halves of the sources (lo8, common.h: the value is hi + lo), or null
 };
 
 // chunk index (over the concatenated channel axis) -> source pointer for row r of image b
@@ -52,12 +52,14 @@ __device__ __forceinline__ void gn_load8(const GNSrc& s, int b, int r, int chunk
     if constexpr (PAIR) {
         const int ch = chunk * 8;
         const T* base_h = reinterpret_cast<const T*>(ch < s.C1 ? s.x1 : s.x2);
-        const T* base_l = reinterpret_cast<const T*>(ch < s.C1 ? s.x1_lo : s.x2_lo);
-        if (base_l) {
-            float l[8];
-            load8<Tag>(base_l + (ph - base_h), l);
+        const unsigned char* base_l = reinterpret_cast<const unsigned char*>(ch < s.C1 ? s.x1_lo : s.x2_lo);
+        if (base_l) {                      // lo8: one byte per element at the element offset of the high half
+            const u32x2 l = *reinterpret_cast<const u32x2*>(base_l + (ph - base_h));
+            float a[4], b[4];
+            mve_lo8_unpack4(l[0], a);
+            mve_lo8_unpack4(l[1], b);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += l[e];
+            for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
         }
     }
 }
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, i
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= M) return;
     const int nchunk = C / 8;
-    V8 raw[R][MAXC8], rawl[R][MAXC8];
+    V8 raw[R][MAXC8];
+    u32x2 rawl[R][MAXC8];                 // residual_pair mode: the 8-bit low halves (lo8, common.h)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int row = row0 + r < M ? row0 + r : M - 1;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, i
             const int c = lane + i * 64;
             if (c < nchunk) {
                 raw[r][i] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(x) + (size_t)row * ldx + c * 8);
-                if (x_lo) rawl[r][i] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(x_lo) + (size_t)row * ldx + c * 8);   // residual_pair mode (uniform branch)
+                if (x_lo) rawl[r][i] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(x_lo) + (size_t)row * ldx + c * 8);   // residual_pair mode (uniform branch)
             }
         }
     }
@@ -386,8 +389,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, i
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = Tag::to_f32(raw[r][i][e]);
                 if (x_lo) {
+                    float a[4], b[4];
+                    mve_lo8_unpack4(rawl[r][i][0], a);
+                    mve_lo8_unpack4(rawl[r][i][1], b);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[i][e] += Tag::to_f32(rawl[r][i][e]);
+                    for (int e = 0; e < 4; ++e) { v[i][e] += a[e]; v[i][4 + e] += b[e]; }
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += v[i][e];

@@ -33,6 +33,23 @@ def _chk16(*ts):
 NO_SPLITK = 8
 
 
+def _chk_lo8(t):
+    assert t is None or (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()), 'a low half is a contiguous uint8 tensor (lo8)'
+
+
+def split_pair(x32, dtype):
+    """fp32 tensor -> (hi, lo8): hi = x rounded to `dtype`, lo8 = E5M2(2^8 (x - hi)) as uint8 -- the stream-pair format of the *_pair entry
+    points (include/mvedit_amd.h); torch.float8_e5m2 rounds to nearest even like v_cvt_pk_bf8_f32."""
+    hi = x32.to(dtype)
+    lo = ((x32.float() - hi.float()) * 256.0).to(torch.float8_e5m2).view(torch.uint8)
+    return hi, lo
+
+
+def lo8_to_float(lo8):
+    """uint8 low half of a stream pair -> its fp32 value."""
+    return lo8.view(torch.float8_e5m2).float() / 256.0
+
+
 def _splitk_ws(M, N, K, device, rows_per_image):
     nbytes = _lib.raw('mve_gemm_workspace_bytes')(M, N, K, int(rows_per_image)) if rows_per_image else 0
     return (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes) if nbytes else (None, 0)
@@ -41,14 +58,15 @@ def _splitk_ws(M, N, K, device, rows_per_image):
 def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, out=None, out_scale=1.0, rows_per_image=0, residual_lo=None,
          pair_out=False):
     """a [M,K], w [N,K] -> [M,N] (or [M,N/2] with GEGLU).  bias/rowvec fp32.
-    residual_lo / pair_out: the residual-pair entry point (mve_gemm_pair): the residual is residual + residual_lo, and with pair_out the
-    result comes back as (hi, lo) = (round16(v), round16(v - hi))."""
-    _chk16(a, w, residual, residual_lo)
+    residual_lo / pair_out: the residual-pair entry point (mve_gemm_pair): the residual is residual + lo8_to_float(residual_lo), and with
+    pair_out the result comes back as (hi, lo8): hi = round16(v) and the 8-bit low half of v - hi (uint8 tensor, see split_pair / lo8_to_float)."""
+    _chk16(a, w, residual)
+    _chk_lo8(residual_lo)
     if residual_lo is not None or pair_out:
         M, K = a.shape
         N = w.shape[0]
         out = torch.empty(M, N, dtype=a.dtype, device=a.device)
-        out_lo = torch.empty_like(out) if pair_out else None
+        out_lo = torch.empty(M, N, dtype=torch.uint8, device=a.device) if pair_out else None
         ws, ws_bytes = _splitk_ws(M, N, K, a.device, rows_per_image)
         with torch.cuda.device(a.device):
             _lib.call('mve_gemm_pair', dt(a), _lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(out), out.stride(0),
@@ -77,7 +95,8 @@ def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec
     """x1 [B*H*W, C1] (+ x2 [B*H*W, C2]) NHWC, w [Cout,3,3,C1+C2] -> ([B*Ho*Wo, Cout], Ho, Wo).
     With flags & W_CHUNK64 the weight is [Cout, (C1+C2)/64, 3, 3, 64] (see pack_conv_weight).
     residual_lo / pair_out: the residual-pair entry point (mve_conv3x3_pair) -> ((out, out_lo), Ho, Wo) with pair_out."""
-    _chk16(x1, x2, w, residual, residual_lo)
+    _chk16(x1, x2, w, residual)
+    _chk_lo8(residual_lo)
     C1 = x1.shape[1]
     C2 = x2.shape[1] if x2 is not None else 0
     Cout = w.shape[0]
@@ -87,7 +106,7 @@ def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec
     out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32 if flags & OUT_F32 else x1.dtype, device=x1.device)
     ws, ws_bytes = _splitk_ws(B * Ho * Wo, Cout, 9 * (C1 + C2), x1.device, Ho * Wo if splitk else 0)
     if residual_lo is not None or pair_out:
-        out_lo = torch.empty_like(out) if pair_out else None
+        out_lo = torch.empty(out.shape, dtype=torch.uint8, device=out.device) if pair_out else None
         with torch.cuda.device(x1.device):
             _lib.call('mve_conv3x3_pair', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x2), C2, B, H, W, stride, int(bool(upsample)),
                       _lib.ptr(w), Cout, _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(rowvec),
@@ -116,7 +135,7 @@ def conv3x3_shortcut(x1, w, B, H, W, x3, x4=None, bias=None, bias2=None, residua
     ws, ws_bytes = _splitk_ws(B * H * W, Cout, 9 * C1 + C3 + C4, x1.device, H * W if splitk else 0)
     if pair_out:
         assert residual is None
-        out_lo = torch.empty_like(out)
+        out_lo = torch.empty(out.shape, dtype=torch.uint8, device=out.device)
         with torch.cuda.device(x1.device):
             _lib.call('mve_conv3x3_shortcut_pair', dt(x1), _lib.ptr(x1), C1, _lib.ptr(x3), C3, _lib.ptr(x4), C4, B, H, W, _lib.ptr(w), Cout,
                       _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(bias2), 0, 1.0, _lib.ptr(ws), ws_bytes, _lib.ptr(out_lo), _s(x1))
@@ -150,7 +169,7 @@ def upsample_conv_phases(x, w4, B, H, W, bias=None, pair_out=False, splitk=True)
     C, Cout = x.shape[1], w4.shape[1]
     assert w4.numel() == 16 * Cout * C
     out = torch.empty(B * 4 * H * W, Cout, dtype=x.dtype, device=x.device)
-    out_lo = torch.empty_like(out) if pair_out else None
+    out_lo = torch.empty(out.shape, dtype=torch.uint8, device=out.device) if pair_out else None
     nb = _lib.raw('mve_upsample_conv_phases_workspace_bytes')(C, Cout, B, H, W) if splitk else 0
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
     with torch.cuda.device(x.device):
