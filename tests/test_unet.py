@@ -529,11 +529,16 @@ def test_engine_sd15_rows_of_the_timed_64_image_batch_vs_oracle(lib):
         e = ((out[r] - ref[k]).norm() / ref[k].norm()).item()
         print(f'row {r} of the 64-image batch vs the fp32 oracle: rel-L2 {e:.3e}')
         assert e <= 1.0e-3, (r, e)
-    # and the same rows alone (small-batch decisions) stay within two roundings of the batch's: the decisions differ in fp32 summation order only
+    # the same rows alone (small-batch decisions): the decisions differ in fp32 summation order only, which moves a fraction of a percent of the
+    # 16-bit outputs of a few launches by one step -- after which every rounding downstream decorrelates: the two results differ like two
+    # independent 16-bit evaluations (measured 9.4e-4; 1.3e-3 on the 16-bit stream), each inside the bar against fp32
     alone = eng(x[rows].cuda(), 499, ctx[rows].cuda())[0].float().cpu()
     d = ((alone - out[rows]).norm() / out[rows].norm()).item()
     print(f'rows alone vs rows of the batch: rel-L2 {d:.3e}')
-    assert d <= 5e-4, d
+    assert d <= 2e-3, d
+    for k in range(len(rows)):
+        e = ((alone[k] - ref[k]).norm() / ref[k].norm()).item()
+        assert e <= 1.0e-3, ('alone', rows[k], e)
 
 
 @pytest.mark.gpu
