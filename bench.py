@@ -174,17 +174,11 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    per_op = None
-    n_prof = 0
     t0 = time.perf_counter()
-    # per-op HIP events cost ~1 ms of host time per step: on every timed step at N = 1 (~65 ms steps), on the last timed step
-    # only at N > 1 where a rank's step is ~10 ms and the events would distort the scaling measurement
+    # The timed region: EXACTLY K steps, nothing but the workload (no per-op events: round 5 measured them at 2 ms of a 64 ms step -- 712 event records
+    # per step keep kernel tails from overlapping the next launch).
     for i in range(args.steps):
-        prof = (not args.no_op_timing) and (world == 1 or i == args.steps - 1)
-        _, mss = step(prof)
-        if mss is not None:
-            per_op = mss if per_op is None else [[a + b for a, b in zip(pa, pb)] for pa, pb in zip(per_op, mss)]
-            n_prof += 1
+        step(False)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -194,15 +188,24 @@ def main():
     if rank == 0 and wl == 'mvedit32' and last_raw[0] is not None:
         # rows of the LAST TIMED step's batch for the checker leg: view 0's unconditional and text rows (rows 0 and v_loc of [uncond | text])
         timed_rows = ([0, v_loc], last_raw[0][[0, v_loc]].float().cpu())
-    # the same K steps once more WITHOUT per-op HIP events (the events run inside the timed steps at N = 1)
-    ms_no_events = None
-    if world == 1 and not args.no_op_timing:
+    # The roofline's kernel durations: HIP events around every launch (mve_unet_forward's op_ms, recorded on the launch stream) over the SAME K steps
+    # repeated right after the timed ones -- same inputs, same plan, the chip in the same thermal / clock state (N > 1: one such step, a rank's step
+    # being ~10 ms).  `op_timing` in the line carries the wall time of these instrumented steps next to the timed ones.
+    per_op = None
+    n_prof = 0
+    ms_with_events = None
+    if not args.no_op_timing:
+        n_ev = args.steps if world == 1 else 1
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(False)
+        for i in range(n_ev):
+            _, mss = step(True)
+            per_op = mss if per_op is None else [[a + b for a, b in zip(pa, pb)] for pa, pb in zip(per_op, mss)]
+            n_prof += 1
         torch.cuda.synchronize()
-        ms_no_events = (time.perf_counter() - t1) / args.steps * 1e3
+        ms_with_events = (time.perf_counter() - t1) / n_ev * 1e3
+        if use_dist:
+            dist.barrier()
     # socket power / clock: sampled over EXTRA untimed steps right after the timed region (rocm-smi queries the SMU; nothing that is not the
     # workload runs next to the timed steps).  Every rank runs the extra steps (they contain the step's collective); rank 0 samples.
     sampler = PowerSampler() if rank == 0 else None
@@ -339,10 +342,10 @@ def main():
                 roof['clock'] = clk
             except Exception as e:      # informational only
                 roof['clock'] = {'error': repr(e)[:200]}
-        if ms_no_events is not None:
-            line['op_timing'] = dict(ms_per_step_with_per_op_events=round(ms_per_step, 3), ms_per_step_without=round(ms_no_events, 3),
-                                     note='the timed region carries one HIP event pair per op at N = 1 (the roofline figures come from them); the same K steps '
-                                          'again, right after, without them')
+        if ms_with_events is not None:
+            line['op_timing'] = dict(ms_per_step_timed_region=round(ms_per_step, 3), ms_per_step_with_per_op_events=round(ms_with_events, 3), steps_with_events=n_prof,
+                                     note='the timed K steps carry no events; the roofline / per-class durations are HIP events around every launch over the same '
+                                          'steps repeated right after the timed region (the events cost ~2 ms of host + queue time per 64-image step)')
         if world == 1 and not args.no_cpu_baseline:
             hw = (120, 80) if wl == 'zero123pp' else (LATENT, LATENT)
             if timed_rows is not None:
@@ -386,7 +389,7 @@ def main():
         if world == 1 and wl == 'mvedit32' and not args.no_extra:
             # what one rank of an N-GPU job runs (32 views x CFG / N images), on this box: the projection the first real SCALE file is to be read against
             try:
-                line['scaling_projection'] = scaling_projection(eng, dev, dtype, ms_no_events or ms_per_step)
+                line['scaling_projection'] = scaling_projection(eng, dev, dtype, ms_per_step)
             except Exception as e:
                 line['scaling_projection'] = {'error': repr(e)[:300]}
         if world == 1 and not args.no_extra and wl == 'mvedit32' and dtype == torch.float16 and pair_mode:

@@ -593,8 +593,8 @@ unsigned long long* g_pp_prof_host = nullptr;
 
 template <class Tag, int MODE, bool SEQ, int BN2>
 int launch_pp3(const GemmParams& p, hipStream_t s) {
-    if (p.residual_lo || p.out_lo) {          // residual_pair mode: the 320-wide tile without the slice fold has the instantiation for it
-        if constexpr (!SEQ && BN2 == 320) {
+    if (p.residual_lo || p.out_lo) {          // residual_pair mode: the 320-wide and (round 5: small batches) 160-wide tiles without the slice fold
+        if constexpr (!SEQ && (BN2 == 320 || BN2 == 160)) {
             static bool configured_pair[64] = {};
             int dev = 0;
             MVE_HIP(hipGetDevice(&dev));

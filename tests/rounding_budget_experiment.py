@@ -7,6 +7,8 @@ Sites:  norm   GroupNorm(+SiLU) / LayerNorm outputs            mm     conv / lin
         attn   SDPA output                                      act    GEGLU hidden
         res    the residual stream x + f(x) (hi + lo pair in the engine's `residual_fp32` mode = unrounded)
         bin    what a branch READS of the stream (the engine's norms read the 16-bit `hi` half only = rounded, unless MVE reads the pair)
+Options: --bf16 (also bf16), --phase (Upsample2D as four 2 x 2 phase convs with summed, once-rounded weights), --lo8 (the stream pair with the 8-bit
+low half the engine stores since round 5 against an exact low half).
 """
 import os
 import sys
@@ -25,6 +27,12 @@ class Sites:
     def __init__(self, q, **off):
         for k in ('norm', 'mm', 'attn', 'act', 'res', 'bin'):
             setattr(self, k, ident if off.get(k) else q)
+        self.where = ''          # the block being walked (site selectors of derived experiments look at it)
+        if off.get('lo8'):       # the stream as the engine stores it since round 5: hi = q(v) plus an 8-bit low half E5M2(2^8 (v - hi)); norms read hi + lo
+            def pair8(v):
+                hi = q(v)
+                return hi + ((v - hi) * 256.0).to(torch.float8_e5m2).float() / 256.0
+            self.res, self.bin = pair8, ident
 
 
 upsample_conv_phases = UO.upsample_conv_phases
@@ -161,6 +169,11 @@ if __name__ == '__main__':
                     a = rel(run(sd, cfg, x, t, ctx, q, True, **off))
                     b = rel(run(sd, cfg, x, t, ctx, q, True, phase_ups=True, **off))
                     print(f'  {label:40s} 3x3 on the upsampled input {a:.3e}   four 2x2 phase convs, summed weights rounded {b:.3e}', flush=True)
+                continue
+            if '--lo8' in sys.argv:
+                for label, off in [('engine + stream pair (fp32-exact low half), pair-reading norms, phase upsamplers', dict(res=1, bin=1)),
+                                   ('engine + stream pair with the 8-bit low half (lo8: what ships since round 5), phase upsamplers', dict(lo8=1))]:
+                    print(f'  {label:100s} {rel(run(sd, cfg, x, t, ctx, q, True, phase_ups=True, **off)):.3e}', flush=True)
                 continue
             for label, eng, off in [
                 ('PyTorch-half rounding points (re-walk)', False, {}),

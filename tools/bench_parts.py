@@ -62,7 +62,7 @@ class PowerSampler:
 def pmc_traffic(cls):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this kernel is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         rec = json.load(open(path)).get(cls)
         if not rec or rec.get('fetch_kib_mean') is None or rec.get('write_kib_mean') is None:
@@ -128,7 +128,7 @@ def secondary(dev):
     with its algorithmic HBM rate.  Synthetic scene: 128^3 occupancy sphere + 12-level hash grid; 81,920-face icosphere."""
     import math
     import numpy as np
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from scene import face_atlas, icosphere, sphere_density_grid
     from mvedit_amd import nerf, raymarching as rm
     from mvedit_amd.mesh_ops import Mesh, MeshRenderer, rasterize
@@ -385,7 +385,7 @@ def outer_step(dev, n_optim_timed=24):
     views); `optim` is the replicated 3D update every rank repeats."""
     import math
     import numpy as np
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from scene import icosphere, sphere_density_grid
     from mvedit_amd import nerf, raymarching as rm, synthetic as SY
     from mvedit_amd.controlnet import ControlNetEngine, MultiControlNetEngine
