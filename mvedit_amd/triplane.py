@@ -82,11 +82,14 @@ class TriPlaneDecoder:
 
     def _pack(self, tensors=None):
         """kernel-side copies of the parameters: weight matrices transposed to [in][out] (one input's fan-out = one contiguous scalar load).
-        Without `tensors` the copies are rebuilt only when a parameter changed (torch's version counter: optimiser steps, in-place edits and
-        load_state_dict all bump it or replace the tensor) -- not on every call of the NeRF sampling hot path."""
+        Without `tensors` the copies are rebuilt only when a parameter changed -- not on every call of the NeRF sampling hot path.  "Changed" is
+        read off (object identity, storage address, torch's version counter): optimiser steps, in-place ops and load_state_dict bump the counter or
+        replace the tensor.  Edits THROUGH `.data` (`p.data.copy_()`, `p.data.clamp_()`) and `set_` bump nothing: call `invalidate()` after them
+        (ADVICE round 4).  Every packed tensor is a COPY (`.clone()`), never an alias of the parameter, so a missed edit leaves all of them equally
+        stale instead of a mix of fresh aliases and stale transposes."""
         src = self.params if tensors is None else tensors
         if tensors is None:
-            sig = tuple((n, id(t), t._version) for n, t in src.items())
+            sig = tuple((n, id(t), t.data_ptr(), t._version) for n, t in src.items())
             if getattr(self, '_packed_sig', None) == sig:
                 return
             self._packed_sig = sig
@@ -96,9 +99,14 @@ class TriPlaneDecoder:
             if name in self._NAMES:
                 key, transpose = self._NAMES[name]
                 t = t.detach()
-                self.w[key] = (t.t() if transpose else t).contiguous()
+                self.w[key] = t.t().contiguous() if transpose else t.clone()
             elif name == 'encoder.params':
-                self.w['table'] = t.detach().reshape(-1, 2).contiguous()
+                self.w['table'] = t.detach().reshape(-1, 2).clone()
+
+    def invalidate(self):
+        """Forget the packed copies: the next call repacks from parameters().  Needed only after edits torch's version counter does not see
+        (`.data` writes, `set_`)."""
+        self._packed_sig = None
 
     def parameters(self):
         """reference name -> tensor (fp32, the reference module's layout); mark them requires_grad_(True) and optimise them with any torch optimiser"""

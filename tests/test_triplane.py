@@ -62,6 +62,33 @@ def _engine(tag):
     return eng.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
 
 
+def test_packed_parameter_copies_follow_edits():
+    """ADVICE round 4: the kernel-side copies (_pack) are rebuilt when torch's version counter, the tensor's identity or its storage address move;
+    `.data` edits move none of them -- `invalidate()` is the documented way -- and every packed tensor is a copy, so a missed edit leaves the set
+    consistent (all stale) instead of fresh aliases next to stale transposes.  No GPU needed: packing is host-side bookkeeping."""
+    pytest.importorskip('mvedit_amd._lib')
+    from mvedit_amd.triplane import TriPlaneDecoder
+    tag = next(t for t in CASES if not CASES[t]['ingp'])
+    c = CASES[tag]
+    eng = TriPlaneDecoder(plane_cfg=c['plane_cfg'], activation=c['activation'], flip_z=c['flip_z'], device='cpu')
+    sd = {'base_net.0.weight': G[f'{tag}_base_w'], 'base_net.0.bias': G[f'{tag}_base_b'], 'density_net.0.weight': G[f'{tag}_dens_w'],
+          'density_net.0.bias': G[f'{tag}_dens_b'], 'color_net.0.weight': G[f'{tag}_col1_w'], 'color_net.0.bias': G[f'{tag}_col1_b'],
+          'color_net.2.weight': G[f'{tag}_col2_w'], 'color_net.2.bias': G[f'{tag}_col2_b']}
+    eng.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    p_b, p_w = eng.params['base_net.0.bias'], eng.params['base_net.0.weight']
+    assert eng.w['base_b'].data_ptr() != p_b.data_ptr()                      # a copy, not an alias
+    p_b.add_(1.0)                                                            # in-place op: version counter moves
+    eng._pack()
+    assert torch.equal(eng.w['base_b'], p_b)
+    p_b.data.mul_(2.0)                                                       # through .data: nothing moves ...
+    p_w.data.mul_(2.0)
+    eng._pack()
+    assert not torch.equal(eng.w['base_b'], p_b) and not torch.equal(eng.w['base_wT'], p_w.t())      # ... both copies stale, consistently
+    eng.invalidate()
+    eng._pack()
+    assert torch.equal(eng.w['base_b'], p_b) and torch.equal(eng.w['base_wT'], p_w.t())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', list(CASES))
 def test_hip_vs_reference_output(lib, tag):

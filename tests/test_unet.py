@@ -6,6 +6,11 @@ not gpu : plan-time logic only (no device memory is touched): analytic FLOPs equ
           oracle vs committed golden.
 gpu     : end-to-end parity on seeded random weights.
 
+Round 5: the engine's DEFAULT mode carries the residual stream as an unrounded pair (16-bit value + 8-bit low half) and is held to north_star's
+1e-3 against fp32 arithmetic at every full-size configuration (benchmark shape, rows of the timed 64-image batch, L = 8192 pairing, Zero123++
+tiling: 8.4e-4 .. 9.6e-4 measured); the small synthetic configurations (random unit-gain networks of 2-3 levels) measure 8.6e-4 .. 1.1e-3 and keep
+the relative criterion below.
+
 Tolerance, stated once.  north_star: "within 1e-3 rel fp16" against the reference's PyTorch path.  The
 reference's fp16 path is PyTorch half: every op accumulates in fp32 and rounds its OUTPUT to fp16.  The oracle
 reproduces exactly that when run with q=quantizer(float16) (it rounds at every op boundary).  Two numbers are
@@ -434,7 +439,7 @@ def test_engine_residual_pair_meets_north_star_at_the_benchmark_shape(lib):
 def test_engine_sd15_cross_image_pairing_full_size_vs_oracle(lib, dtype):
     """CrossImageAttnProcWrapper at the size the 3D pipelines use it (joint_attn.py:11-37 with num_cross_attn_imgs = 2 on a [2, 4, 128, 64]
     latent, i.e. one 2 x 8192-token self-attention at level 0): full-size oracle comparison."""
-    _parity_hw(U.SD15, 2, 128, 64, dtype, n_img=2, t=torch.tensor([20.0, 20.0]))
+    _parity_hw(U.SD15, 2, 128, 64, dtype, n_img=2, t=torch.tensor([20.0, 20.0]), fp32_bar=1.0e-3 if dtype == torch.float16 else None)      # (measured 9.2e-4)
 
 
 @pytest.mark.gpu
@@ -462,6 +467,7 @@ def test_engine_sd21_zero123pp_true_tiling_vs_oracle(lib):
     out = eng(x.to(dtype).cuda(), 400, ctx.to(dtype).cuda(), cross_attention_kwargs=dict(mode='r', ref_dict=d, is_cfg_guidance=True))[0]
     assert out.shape == (B, 4, 120, 80)
     _check(out, ref16, ref32)
+    assert eng.residual_pair and _rel(out, ref32)[0] <= 1.0e-3, _rel(out, ref32)[0]          # north_star's bar in the default mode (measured 9.3e-4)
 
 
 def test_synthetic_weights_module_matches_oracle_inventory():
