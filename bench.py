@@ -339,6 +339,9 @@ def main():
             try:
                 clk = clock_probe(dev)
                 clk['frac_at_clock'] = round(roof['achieved'] / clk['peak_at_clock'], 4)
+                # which limiter holds the clock there: the SMU's package-power tracking -- gpu_metrics ppt_residency_acc advances only inside the
+                # conv loop, thermal / prochot residencies stay 0 (tools/limiter_probe.py, profiles/r05_limiter.log).  Diagnosis, not a score.
+                clk['limiter'] = 'PPT (package power tracking): profiles/r05_limiter.log'
                 roof['clock'] = clk
             except Exception as e:      # informational only
                 roof['clock'] = {'error': repr(e)[:200]}
