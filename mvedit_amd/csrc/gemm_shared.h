@@ -67,7 +67,7 @@ struct GemmParams {
     int tile_n;        // 256-row ping-pong tile only: 0 = widest width that divides N (320 / 256 / 128); 160 = the 160-wide tile (N % 160 == 0),
                        // which the dispatcher picks when the 320-wide tiling would leave CUs without a block (small batches)
     int old_swizzle;   // ping-pong tile only, A/B aid: 1 = round 2's ring swizzle (2-way bank conflicts on every fragment read)
-    int dbg;           // development switches of the residual-pair epilogue (MVE_PP_DBG; 0 in every shipped path)
+    int dbg;           // development switch (MVE_PP_DBG, 0 in every shipped path): bit 1 = pair launches of the 256-row tile take the generic epilogue path (A/B aid)
     // Output rows in groups: row m of out (and out_lo) starts at element m * ldc + (m >> orow_shift) * orow_extra.  orow_extra = 0: plain rows.
     // The phase convs of mve_upsample_conv_phases write pixel (b, i, j) of a [B][H][W] launch to pixel (b, 2 i + py, 2 j + px) of the [B][2H][2W]
     // NHWC output: ldc = 2 C, orow_shift = log2 W, orow_extra = 2 W C, base shifted by (py 2 W + px) C.

@@ -559,7 +559,7 @@ def outer_step(dev, n_optim_timed=24):
     out['mesh_optim_iter_ms'] = round(ms, 3)
 
     try:
-        out['texture_superres'] = texture_superres(dev, lp, tm)
+        out['texture_superres'] = texture_superres(dev, lp)
     except Exception as e:      # a composed figure must not take the others with it
         out['texture_superres'] = {'error': repr(e)[:300]}
 
@@ -573,7 +573,7 @@ def outer_step(dev, n_optim_timed=24):
     return out
 
 
-def texture_superres(dev, lp, tm):
+def texture_superres(dev, lp):
     """BASELINE config 4's second half composed end to end: the texture super-resolution loop of the 3D-to-3D pipelines
     (lib/pipelines/mvedit_texture_superres_pipeline.py:171-470 as lib/apis/adapter3d.py:578-620 calls it with the web UI defaults of
     lib/core/webui/shared_opts.py:245-275: 6 views + 2 regularisation views at 512^2, 24 steps at denoising strength 0.4 = 10 denoise steps,
@@ -736,9 +736,8 @@ if __name__ == '__main__':          # python tools/bench_parts.py texture_superr
     if what == 'texture_superres':
         from mvedit_amd import synthetic as SY_
         from mvedit_amd.lpips import LPIPSEngine as LP_
-        from mvedit_amd.tonemapping import Tonemapping as TM_
         lp_ = LP_.from_state_dict({k: v.to(torch.bfloat16).float() for k, v in SY_.make_lpips_state_dict().items()}, torch.bfloat16, device=dev_)
-        print(json.dumps(texture_superres(dev_, lp_, TM_(device=dev_))))
+        print(json.dumps(texture_superres(dev_, lp_)))
     elif what == 'outer_step':
         print(json.dumps(outer_step(dev_)))
     else:
