@@ -652,7 +652,7 @@ int launch_pp2(const GemmParams& p, hipStream_t s) {
         configured[dev] = true;
         if (getenv("MVE_DEBUG")) {
             int nb = -1;
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_gemm_pp<Tag, 0, false, 160, false, 3>), PNTH, pp_smem(160, 3));
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_gemm_pp<Tag, 0, false, 160, false, 3>), PNTH, pp_smem(160, 3));
             fprintf(stderr, "[mve] k_gemm_pp<160, 3 slots>: %d blocks per CU by the occupancy API (LDS %d B per block)\n", nb, pp_smem(160, 3));
         }
     }
