@@ -33,6 +33,8 @@ class Sites:
                 hi = q(v)
                 return hi + ((v - hi) * 256.0).to(torch.float8_e5m2).float() / 256.0
             self.res, self.bin = pair8, ident
+            if off.get('h1pair'):
+                self.h1 = pair8
 
 
 upsample_conv_phases = UO.upsample_conv_phases
@@ -58,7 +60,8 @@ def run(sd, cfg, x, t, ctx, q, engine=True, phase_ups=False, **off):
         h = S.norm(F.silu(F.group_norm(xin, g, c.w(p + '.norm1.weight'), c.w(p + '.norm1.bias'), eps)))
         tt = F.linear(q(F.silu(temb)), c.w(p + '.time_emb_proj.weight'), c.w(p + '.time_emb_proj.bias'))       # fp32 row vector in the engine
         if engine:
-            h = S.mm(F.conv2d(h, c.w(p + '.conv1.weight'), c.w(p + '.conv1.bias'), padding=1) + tt[:, :, None, None])
+            # conv1's output is read by GroupNorm only -- never as an MFMA operand: `h1` = the site on its own (a pair there costs one byte per element)
+            h = getattr(S, 'h1', S.mm)(F.conv2d(h, c.w(p + '.conv1.weight'), c.w(p + '.conv1.bias'), padding=1) + tt[:, :, None, None])
         else:
             h = S.mm(conv(h, p + '.conv1') + S.mm(tt)[:, :, None, None])
         h = S.norm(F.silu(F.group_norm(h, g, c.w(p + '.norm2.weight'), c.w(p + '.norm2.bias'), eps)))
