@@ -216,6 +216,22 @@ def test_residual_pair_is_a_plan_option(lib):
         lib.call('mve_unet_set_residual_mode', vae.decoder._h, 1)
 
 
+def test_residual_pair_environment_switch():
+    """MVE_RESIDUAL_PAIR=0 in the environment creates UNet handles on the 16-bit stream (read by mve_unet_create, i.e. in a fresh process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import torch; from mvedit_amd.unet import UNet2DConditionEngine, SD15_CONFIG; '
+            'print(UNet2DConditionEngine(SD15_CONFIG, torch.float16, device="cpu").residual_pair)')
+    for val, want in (('0', 'False'), ('1', 'True'), (None, 'True')):
+        env = dict(os.environ)
+        env.pop('MVE_RESIDUAL_PAIR', None)
+        if val is not None:
+            env['MVE_RESIDUAL_PAIR'] = val
+        out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == want, (val, out.stdout, out.stderr[-500:])
+
+
 def test_controlnet_shared_conditioning_is_a_plan_option(lib):
     """mve_controlnet_set_cond_repeat (plan-time only, no GPU): with R = 2 the conditioning embedding is planned for half the batch (its conv flops
     halve, conv_in runs once per half), everything else is unchanged; UNet handles refuse the option."""
