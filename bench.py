@@ -14,10 +14,15 @@ all-gather over xGMI gives every rank the full [V,4,64,64] noise prediction (wha
 consumes).  value = steps/s of the whole 32-view job = 1 / max-over-ranks(step time).
 
 The JSON line also carries
-  roofline     : the dominant kernel (3x3 implicit-GEMM conv, MFMA bound): algorithmic FLOPs of all its launches in
-                 one step / their summed HIP-event durations, measured in the timed region on the launch stream;
-  cpu_baseline : the torch-fp32 oracle of the same UNet timed on this box's host cores on a bounded sample
-                 (one forward of one image), scaled to 64 forwards/step.  Baseline only.
+  roofline     : the dominant kernel (k_gemm_pp: 3x3 implicit-GEMM conv + linear launches, MFMA bound): algorithmic FLOPs of all its
+                 launches in one step / their summed HIP-event durations, recorded on the launch stream over the K timed steps REPEATED right
+                 after the timed region (round 5: the events themselves cost ~2 ms of a 64 ms step, so the timed K steps carry none;
+                 `op_timing` has both wall times);
+  cpu_baseline : the torch-fp32 oracle of the same UNet timed on this box's host cores on a bounded sample (a forward of two images),
+                 scaled to 64 forwards/step.  Baseline only;
+  parity       : rows of the LAST TIMED step's 64-image output against fp32 oracle forwards of the same items (north_star: 1e-3).
+The engine runs in its default mode: residual stream as an unrounded pair (16-bit value + 8-bit low half), the mode inside north_star's 1e-3;
+`--plain-stream` times the reference's 16-bit stream (also reported as extra_workloads[0]).
 """
 import argparse
 import json
