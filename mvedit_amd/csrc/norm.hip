@@ -149,7 +149,9 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn_apply(GNSrc s, int nsplit, in
     const int C = s.C1 + s.C2;
     const int chunk = blockIdx.y * GN_TX + threadIdx.x;
     if (chunk * 8 >= C) return;
-    const int b = blockIdx.z, split = blockIdx.x;
+    // (round 5) the apply pass walks the tensor in the REVERSE order of the statistics pass: what that pass read last is read first here, while it
+    // is still in the Infinity Cache (3-7 % on the level-0 tensors, tools/gn_pair_bench.py; pure index remap: same bits)
+    const int b = (int)gridDim.z - 1 - (int)blockIdx.z, split = (int)gridDim.x - 1 - (int)blockIdx.x;
     const int rows_per = (s.HW + nsplit - 1) / nsplit;
     const int r0 = split * rows_per, r1 = min(s.HW, r0 + rows_per);
     const int cpg = C / G;
@@ -431,17 +433,28 @@ __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, i
     }
 }
 
-int gn_tx(int C) { return C <= 128 ? 16 : (C <= 256 ? 32 : 64); }
+// Lanes along the channel chunks of a row.  C <= 256 (the VAE's image-resolution tensors): 16 / 32.  Above that (round 5) a width that DIVIDES the
+// number of 8-channel chunks, so that no lane idles: 320 channels = 40 chunks ran on 64-wide blocks with 24 idle lanes, and the pair-reading kernels
+// (unpacking + SiLU on 62 % of the lanes) could not hide that behind the memory time -- 2.9 TB/s on the level-0 stream tensors against 4.5 for the plain
+// ones.  40-wide blocks (6 rows of 40 lanes; also 80 / 120 / 240 chunks): level-0 C = 320 plain 0.108 -> 0.092 ms, pair 0.229 -> 0.179; C = 640 pair
+// 0.439 -> 0.333 (tools/gn_pair_bench.py, 64 images).
+int gn_tx(int C) {
+    if (C <= 128) return 16;
+    if (C <= 256) return 32;
+    const int ch = C / 8;
+    // (8-wide blocks -- 128-byte row pieces -- lose more to the memory system than idle lanes cost: measured; 40 = the 320 / 960-channel tensors, 6 rows of 40 lanes per block)
+    return ch % 64 == 0 ? 64 : (ch % 32 == 0 ? 32 : (ch % 40 == 0 ? 40 : (ch % 16 == 0 ? 16 : 64)));
+}
 
 int gn_nsplit(int B, int HW, int C) {
-    if (gn_tx(C) < 64) {      // narrow tensors are the large-image ones: ~512 rows per block, independent of the batch
+    if (C <= 256) {           // narrow tensors are the large-image ones: ~512 rows per block, independent of the batch
         const int ns = HW / 512;
         return ns < 1 ? 1 : (ns > 512 ? 512 : ns);
     }
-    // a function of the rows per image only: the grouping of the fp32 partial sums -- and so the statistics' last bits -- must not
-    // depend on the batch (batch invariance); 64 rows per block, at most 64 splits: 4096 blocks at 64 images of 64 x 64
+    // a function of the rows per image and the channel count only: the grouping of the fp32 partial sums -- and so the statistics' last bits --
+    // must not depend on the batch (batch invariance).  16 rows per thread: 64 rows per block of 64-wide blocks, 96 / 128 / 256 for 40 / 32 / 16-wide
     (void)B;
-    const int ns = HW / 64;
+    const int ns = HW / (16 * (GN_THREADS / gn_tx(C)));
     return ns < 1 ? 1 : (ns > 64 ? 64 : ns);
 }
 
@@ -458,13 +471,15 @@ int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* be
         float* partial = ws;
         float* stats = ws + (size_t)s.B * ns * C * 2;
         dim3 grid(ns, ncg, s.B), block(tx, GN_THREADS / tx);
-        if (tx == 16) k_gn_partial<Tag, 16, true><<<grid, block, 0, st>>>(s, ns, partial);
+        if (tx == 40) k_gn_partial<Tag, 40, true><<<grid, block, 0, st>>>(s, ns, partial);
+        else if (tx == 16) k_gn_partial<Tag, 16, true><<<grid, block, 0, st>>>(s, ns, partial);
         else if (tx == 32) k_gn_partial<Tag, 32, true><<<grid, block, 0, st>>>(s, ns, partial);
         else k_gn_partial<Tag, 64, true><<<grid, block, 0, st>>>(s, ns, partial);
         MVE_LAUNCH_CHECK();
         k_gn_finalize<<<mve_cdiv(s.B * G, 4), 256, 0, st>>>(partial, s.B, ns, C, G, s.HW, eps, stats);
         MVE_LAUNCH_CHECK();
-        if (tx == 16) k_gn_apply<Tag, 16, true><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+        if (tx == 40) k_gn_apply<Tag, 40, true><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+        else if (tx == 16) k_gn_apply<Tag, 16, true><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
         else if (tx == 32) k_gn_apply<Tag, 32, true><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
         else k_gn_apply<Tag, 64, true><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
         MVE_LAUNCH_CHECK();
@@ -479,13 +494,15 @@ int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* be
     float* partial = ws;
     float* stats = ws + (size_t)s.B * ns * C * 2;
     dim3 grid(ns, ncg, s.B), block(tx, GN_THREADS / tx);
-    if (tx == 16) k_gn_partial<Tag, 16><<<grid, block, 0, st>>>(s, ns, partial);
+    if (tx == 40) k_gn_partial<Tag, 40><<<grid, block, 0, st>>>(s, ns, partial);
+    else if (tx == 16) k_gn_partial<Tag, 16><<<grid, block, 0, st>>>(s, ns, partial);
     else if (tx == 32) k_gn_partial<Tag, 32><<<grid, block, 0, st>>>(s, ns, partial);
     else k_gn_partial<Tag, 64><<<grid, block, 0, st>>>(s, ns, partial);
     MVE_LAUNCH_CHECK();
     k_gn_finalize<<<mve_cdiv(s.B * G, 4), 256, 0, st>>>(partial, s.B, ns, C, G, s.HW, eps, stats);
     MVE_LAUNCH_CHECK();
-    if (tx == 16) k_gn_apply<Tag, 16><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+    if (tx == 40) k_gn_apply<Tag, 40><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
+    else if (tx == 16) k_gn_apply<Tag, 16><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
     else if (tx == 32) k_gn_apply<Tag, 32><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
     else k_gn_apply<Tag, 64><<<grid, block, 0, st>>>(s, ns, G, stats, gamma, beta, silu, out);
     MVE_LAUNCH_CHECK();
