@@ -238,7 +238,7 @@ MVE_API int mve_conv3x3_shortcut(int dtype, const void* x1, int C1, const void* 
  *          order, ONE rounding to the storage type).  That rounding is the only arithmetic difference from the 3 x 3 form: the two agree to the
  *          storage precision of the weights, not bit for bit (tests/test_unet_ops.py pins both the exact identity on the rounded phase weights and
  *          the distance to the 3 x 3 form; end to end: tests/rounding_budget_experiment.py --phase).
- *   d_out: [B][2 Hs][2 Ws][Cout] NHWC, dense; d_out_lo (NULL or same shape): the low half in residual_pair mode.
+ *   d_out: [B][2 Hs][2 Ws][Cout] NHWC, dense; d_out_lo (NULL or the same shape in BYTES): the 8-bit low half (lo8, below) in residual_pair mode; needs Cout % 320 == 0.
  * Needs C % 64 == 0, Cout a multiple of 128, Ws a power of two, B Hs Ws >= 64 (mve_upsample_conv_phases_supported = 1); one launch of the
  * ping-pong kernel (2 x 2 window, grouped output rows) for the four phases where B Hs Ws is a multiple of 256, four launches otherwise; K slices by
  * the conv slice rule with 4 Hs Ws rows per image -- batch independent (workspace: *_workspace_bytes). */
