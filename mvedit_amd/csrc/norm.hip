@@ -509,104 +509,9 @@ int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* be
     return MVE_OK;
 }
 
-// LayerNorm for the UNet's widths (C = 320 / 640 / 1280: 40 / 80 / 160 vectors per row) with every lane loaded (round 5).  The row-per-wave kernel
-// above leaves 24 of 64 lanes idle at C = 320 (16 of 128 at 640, 32 of 192 at 1280) and, as the GroupNorm kernels showed (profiles/
-// r05_gn_lane_layout_ab.log), a memory instruction that carries 640 bytes instead of 1 KiB costs bandwidth, not just lanes.  Here a wave takes
-// R = 8 / 4 / 2 rows = 320 vectors as FIVE full-width loads (vector f = 64 k + lane of the wave's rows, row-major); the per-row sums go through a
-// wave-private LDS strip: every lane drops the sums of its five vectors, 64 / R lanes per row add five entries each and finish with xor shuffles.
-// Two passes (mean, centred variance) as above; a row's bits differ from the kernel above by summation order only.
-template <class Tag, int NCH>        // NCH = C / 8: 40, 80, 160
-__global__ __launch_bounds__(256) void k_layernorm_flat(const void* __restrict__ x, int ldx, void* __restrict__ y, int ldy, int M,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                        const void* __restrict__ x_lo) {
-    typedef typename Tag::T T;
-    typedef typename Tag::V8 V8;
-    constexpr int R = 320 / NCH, G = 64 / R, C = NCH * 8;           // rows per wave, lanes per row in the reduction
-    static_assert(R * NCH == 320 && G * R == 64 && NCH % G == 0 && NCH / G == 5, "five vectors per lane, five strip entries per reducing lane");
-    __shared__ float strip[4][320];
-    __shared__ float rowstat[4][8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * 4 + wave) * R;
-    float v[5][8];
-    int vr[5], vc[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int f = k * 64 + lane;
-        vr[k] = f / NCH;
-        vc[k] = f - vr[k] * NCH;
-        const int row = row0 + vr[k] < M ? row0 + vr[k] : M - 1;     // (rows past the end recompute the last row and store nothing)
-        const V8 h = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(x) + (size_t)row * ldx + vc[k] * 8);
-        if (x_lo) {                                                  // residual_pair mode (uniform branch): hi + lo8
-            const u32x2 l = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(x_lo) + (size_t)row * ldx + vc[k] * 8);
-            mve_pair_load8<Tag>(h, l, v[k]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[k][e] = Tag::to_f32(h[e]);
-        }
-    }
-    const int g = lane / G, sub = lane - g * G;
-    // sum over each of the wave's R rows of one value per vector -> the row's total in rowstat[wave][row]
-    auto row_sums = [&](const float (&part)[5]) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) strip[wave][k * 64 + lane] = part[k];
-        __syncthreads();
-        float a = 0.f;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) a += strip[wave][g * NCH + sub * 5 + j];
-#pragma unroll
-        for (int d = G / 2; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-        if (sub == 0) rowstat[wave][g] = a;
-        __syncthreads();
-    };
-    float part[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        float a = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a += v[k][e];
-        part[k] = a;
-    }
-    row_sums(part);
-    float mean[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) mean[k] = rowstat[wave][vr[k]] / (float)C;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean[k]; q += d * d; }
-        part[k] = q;
-    }
-    row_sums(part);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const float rstd = rsqrtf(rowstat[wave][vr[k]] / (float)C + eps);
-        const int row = row0 + vr[k];
-        V8 pk;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ch = vc[k] * 8 + e;
-            pk[e] = Tag::from_f32((v[k][e] - mean[k]) * rstd * gamma[ch] + beta[ch]);
-        }
-        if (row < M) *reinterpret_cast<V8*>(reinterpret_cast<T*>(y) + (size_t)row * ldy + vc[k] * 8) = pk;
-    }
-}
-
-int g_ln_flat = -1;          // MVE_LN_FLAT=0: the row-per-wave kernel for every width (A/B)
-
 template <class Tag>
 int ln_run(const void* x, int ldx, void* y, int ldy, int M, int C, const float* gamma, const float* beta, float eps,
            hipStream_t st, const void* x_lo) {
-    if (g_ln_flat < 0) { const char* e = getenv("MVE_LN_FLAT"); g_ln_flat = e ? atoi(e) : 1; }
-    if (g_ln_flat && (C == 320 || C == 640 || C == 1280)) {
-        const int R = 2560 / C;
-        const unsigned grid = mve_cdiv(M, 4 * R);
-        if (C == 320) k_layernorm_flat<Tag, 40><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, gamma, beta, eps, x_lo);
-        else if (C == 640) k_layernorm_flat<Tag, 80><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, gamma, beta, eps, x_lo);
-        else k_layernorm_flat<Tag, 160><<<grid, 256, 0, st>>>(x, ldx, y, ldy, M, gamma, beta, eps, x_lo);
-        MVE_LAUNCH_CHECK();
-        return MVE_OK;
-    }
     const int per_lane = (C / 8 + 63) / 64;
     if (per_lane <= 1) k_layernorm<Tag, 1, 4><<<mve_cdiv(M, 16), 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
     else if (per_lane == 2) k_layernorm<Tag, 2, 2><<<mve_cdiv(M, 8), 256, 0, st>>>(x, ldx, y, ldy, M, C, gamma, beta, eps, x_lo);
