@@ -7,6 +7,7 @@
 #include "../../mvedit_amd/csrc/common.h"
 
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <type_traits>
 #include <vector>
@@ -66,12 +67,35 @@ __global__ void k_ref(const AttnParams p, float* out) {
 // ---- kernel under development --------------------------------------------------------------------------------------------------------
 // VAR bits: 1 = software pipeline (S^T of tile t + 1 under the softmax of tile t) with early fragment reads; 2 = tree-shaped row maximum;
 //           4 = V^T fragments through the transpose-read builtin (compiler-counted lgkmcnt) instead of the asm block
+//           32 (round 5) = two 64-key tiles per LDS stage: one barrier per 128 keys (45 KB of LDS per block)
+//           8 / 16 / 24 (round 5) = the exponentials of one pair of columns in 4 / in 2 / of every pair through exp2_poly_pair instead of v_exp_f32
+// 2^x for a pair of columns without the transcendental unit: clamp, round-to-nearest split by the 1.5 * 2^23 constant (the integer part lands in the
+// low mantissa bits), degree-3 polynomial of the fraction on [-1/2, 1/2] (relative error 7.6e-5, under fp16's half ulp of 4.9e-4) on v_pk_fma_f32, the
+// integer part shifted into the exponent field.  10 VALU instructions per pair (2 v_max, 3 v_pk_add, 3 v_pk_fma, 2 v_lshl_add) against 2 v_exp_f32.
+__device__ __forceinline__ f32x2 exp2_poly_pair(float x0, float x1) {
+    const f32x2 magic = {12582912.f, 12582912.f};
+    const f32x2 x = {fmaxf(x0, -126.f), fmaxf(x1, -126.f)};
+    const f32x2 t = x + magic;
+    const f32x2 f = x - (t - magic);
+    const f32x2 c3 = {0.05520550534f, 0.05520550534f}, c2 = {0.24261397123f, 0.24261397123f}, c1 = {0.69325476885f, 0.69325476885f},
+                c0 = {0.99992769957f, 0.99992769957f};
+    f32x2 q = __builtin_elementwise_fma(c3, f, c2);
+    q = __builtin_elementwise_fma(q, f, c1);
+    q = __builtin_elementwise_fma(q, f, c0);
+    f32x2 r;
+    r[0] = __uint_as_float(__float_as_uint(q[0]) + (__float_as_uint(t[0]) << 23));
+    r[1] = __uint_as_float(__float_as_uint(q[1]) + (__float_as_uint(t[1]) << 23));
+    return r;
+}
+
 template <int NW, int NST, int WPS, int VAR>
 __global__ __launch_bounds__(64 * NW, WPS) void k_attn4(const AttnParams p) {
     constexpr int D = 40, KB = 64, QB = 32 * NW;
     constexpr int K_ROW = 80, V_ROW = 96;
-    constexpr int K_BYTES = KB * K_ROW, V_BYTES = KB * V_ROW, STAGE = K_BYTES + V_BYTES;
-    constexpr int N_DMA = STAGE / 1024, K_DMA = K_BYTES / 1024, DMA_PER_WAVE = (N_DMA + NW - 1) / NW;
+    constexpr int SUB = (VAR & 32) ? 2 : 1;             // key tiles per LDS stage = per barrier
+    constexpr int K_BYTES = KB * K_ROW, V_BYTES = KB * V_ROW, STAGE1 = K_BYTES + V_BYTES, STAGE = SUB * STAGE1;
+    constexpr int N_DMA1 = STAGE1 / 1024, N_DMA = SUB * N_DMA1, K_DMA = K_BYTES / 1024, DMA_PER_WAVE = (N_DMA + NW - 1) / NW;
+    static_assert(SUB == 1 || ((VAR & 1) == 0 && NW == 8), "two tiles per stage: plain loop, 8-wave blocks (3 LDS-DMAs per wave and stage)");
     constexpr bool PIPE = (VAR & 1) != 0, TREE = (VAR & 2) != 0, TRB = (VAR & 4) != 0;
     static_assert(!PIPE || NST >= 3, "the pipelined loop keeps the next tile's K resident");
 
@@ -109,22 +133,24 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attn4(const AttnParams p) {
     const int wv = __builtin_amdgcn_readfirstlane(wid);
     const unsigned smem_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const T* d_src[DMA_PER_WAVE];
-    int d_ld[DMA_PER_WAVE];
+    int d_ld[DMA_PER_WAVE], d_dst[DMA_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) {
         const int inst = wv + NW * i;
-        const int o = inst * 1024 + lane * 16;
-        if (inst < K_DMA) {
+        const int sb = inst / N_DMA1, j = inst - sb * N_DMA1;
+        const int o = j * 1024 + lane * 16;
+        d_dst[i] = sb * STAGE1 + j * 1024;
+        if (j < K_DMA) {
             const int c = o >> 4;
             const int key = c / 5, col = (c - key * 5) * 8;
             d_ld[i] = p.ldk;
-            d_src[i] = kb1 + (size_t)key * p.ldk + col;
+            d_src[i] = kb1 + (size_t)(key + sb * KB) * p.ldk + col;
         } else {
             const int c = (o - K_BYTES) >> 4;
             const int r = c / 6, col = c - r * 6;
             const int key = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
             d_ld[i] = col < 5 ? p.ldv : 0;
-            d_src[i] = col < 5 ? vb1 + (size_t)key * p.ldv + col * 8 : ones;
+            d_src[i] = col < 5 ? vb1 + (size_t)(key + sb * KB) * p.ldv + col * 8 : ones;
         }
     }
     auto dma = [&](int stage_off) {
@@ -132,12 +158,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attn4(const AttnParams p) {
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
             const int inst = wv + NW * i;
             if (inst < N_DMA) {
-                attn_dma16(d_src[i], smem_base + stage_off + inst * 1024);
-                d_src[i] += (size_t)KB * d_ld[i];
+                attn_dma16(d_src[i], smem_base + stage_off + d_dst[i]);
+                d_src[i] += (size_t)(KB * SUB) * d_ld[i];
             }
         }
     };
-    const int n_tiles = p.Lk / KB;                 // lab: Lk % 64 == 0
+    const int n_tiles = p.Lk / (KB * SUB);         // stages; lab: Lk % 128 == 0
     const int n_mine = (N_DMA - wv + NW - 1) / NW;
 
     const int k_off01 = l32 * K_ROW + hi * 16;
@@ -245,9 +271,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attn4(const AttnParams p) {
             unsigned pk[8];
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
-                const float e0 = __builtin_amdgcn_exp2f(sk[2 * r2]);
-                const float e1 = __builtin_amdgcn_exp2f(sk[2 * r2 + 1]);
-                pk[r2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e0, e1}, T2));
+                constexpr int POLY = (VAR >> 3) & 3;                // 0: none, 1: one pair in 4, 2: one pair in 2, 3: every pair
+                const bool poly = POLY == 3 || (POLY == 2 && (r2 & 1)) || (POLY == 1 && (r2 & 3) == 3);
+                f32x2 e;
+                if (poly) e = exp2_poly_pair(sk[2 * r2], sk[2 * r2 + 1]);
+                else e = f32x2{__builtin_amdgcn_exp2f(sk[2 * r2]), __builtin_amdgcn_exp2f(sk[2 * r2 + 1])};
+                pk[r2] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, T2));
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -293,12 +322,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_attn4(const AttnParams p) {
         if (nxt == NST * STAGE) nxt = 0;
         for (int t = 0; t < n_tiles; ++t) {
             if (t + PD < n_tiles) dma(nxt);
-            const KF kf = load_k(smem + cur);
-            S2 s = qk_mfma(kf);
-            softmax_max(s, t == 0);
-            const PB pb = softmax_exp(s);
-            const VF vf = load_v(smem + cur);
-            pv_mfma(vf, pb);
+#pragma nounroll
+            for (int sb = 0; sb < SUB; ++sb) {                      // not unrolled: the two tiles' fragments interleaved cost 30 spilled registers
+                const unsigned char* St = smem + cur + sb * STAGE1;
+                const KF kf = load_k(St);
+                S2 s = qk_mfma(kf);
+                softmax_max(s, t == 0 && sb == 0);
+                const PB pb = softmax_exp(s);
+                const VF vf = load_v(St);
+                pv_mfma(vf, pb);
+            }
             const int last_issued = t + PD < n_tiles ? t + PD : n_tiles - 1;
             wait_sync(last_issued > t + 1 ? n_mine * (last_issued - (t + 1)) : 0);
             nxt = cur;
@@ -1003,6 +1036,18 @@ int main(int argc, char** argv) {
     unsigned long long* d_prof; CK(hipMalloc(&d_prof, 32)); CK(hipMemset(d_prof, 0, 32));
     for (int r = 0; r < rounds; ++r) {
 #define RUN(KID, NW, NST, WPS, VAR) run_variant<KID, NW, NST, WPS, VAR>("k" #KID " NW" #NW " NST" #NST " WPS" #WPS " VAR" #VAR, small, ref.data(), big, d_prof)
+        if (argc > 2 && !strcmp(argv[2], "poly")) {   // round 5: v_exp_f32 against the packed-fp32 polynomial for 0 / 1/4 / 1/2 / all of the columns
+            RUN(4, 8, 2, 4, 4);
+            RUN(4, 8, 2, 4, 12);
+            RUN(4, 8, 2, 4, 20);
+            RUN(4, 8, 2, 4, 28);
+            continue;
+        }
+        if (argc > 2 && !strcmp(argv[2], "sub")) {    // round 5: one barrier per 64 keys against one per 128
+            RUN(4, 8, 2, 4, 4);
+            RUN(4, 8, 2, 4, 36);                  // (4-wave blocks would issue 6 LDS-DMAs per wave and stage: outside wait_sync's counted range)
+            continue;
+        }
         RUN(4, 8, 2, 4, 4);
         RUN(6, 4, 2, 2, 4);
         RUN(6, 4, 3, 2, 4);
