@@ -389,7 +389,7 @@ def main():
                                           note='one forward at the benchmark latent size; the oracle runs fp32 arithmetic over the same 16-bit weights')
             except Exception as e:
                 line['parity'] = {'error': repr(e)[:300]}
-        line['config']['residual_stream'] = ('unrounded (hi, lo) pair of 16-bit tensors (the engine\'s default mode; end-to-end error inside north_star\'s 1e-3)'
+        line['config']['residual_stream'] = ('(hi, lo8) pair: the 16-bit matrix-core operand + an 8-bit E5M2 remainder (the engine\'s default mode; end-to-end error inside north_star\'s 1e-3)'
                                              if pair_mode else '16-bit, rounded after every block (the reference\'s half modules)')
         phases = os.environ.get('MVE_UPSAMPLE_PHASES', '1') != '0'
         line['config']['upsample2d'] = ('four 2x2 phase convs over the source (summed 3x3 taps rounded once to the storage type; 4/9 of the multiply-adds)'
