@@ -190,6 +190,12 @@ MVE_API int mve_gemm(int dtype, const void* d_A, int lda, const void* d_W, int l
  * (threshold and option bits), so `old = tune(x); ...; tune(old)` restores every switch.  The defaults come from the environment
  * variables MVE_GEMM_BIG, MVE_GEMM_PP, MVE_GEMM_PP2 (0 never / 1 wherever eligible / 2 narrow launches only) and MVE_GEMM_STRICT_SPLITK. */
 MVE_API int mve_gemm_tune(int big_min_blocks);
+/* In-kernel K-slice reduction (round 6): a K-sliced GEMM / conv launch that the 256-row ping-pong tile takes folds its slices inside the launch
+ * (the blocks of an output tile write their fp32 partial tiles, meet at a per-tile counter, and each folds its share of the tile's rows over the
+ * slices in slice order and runs the fused epilogue) instead of leaving them to a second `k_splitk_reduce` launch; small launches (few images per
+ * rank) thereby run on the ping-pong loop instead of the 128-row two-stage kernel.  Same slices, same fold order, same epilogue: bit-identical to
+ * partials + reducer.  1 (default, MVE_GEMM_RED) on, 0 off, negative only queries.  Returns the previous value. */
+MVE_API int mve_gemm_red_tune(int on);
 /* Diagnostics: the number of K slices a GEMM / conv launch of this shape runs with under the current switches -- the slice rule's count (a function
  * of rows per image, N, K only), 1 where the un-split launch fills the chip (or the rule's count again in the strict mode, which emulates the slices
  * inside one block), or the smallest count that fills the chip where the rule would over-fill it.  Host logic only. */

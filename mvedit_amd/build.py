@@ -78,8 +78,34 @@ def _headers_digest():
     return h.hexdigest()
 
 
+_INC_RE = None
+
+
+def _deps_digest(path, seen=None):
+    """sha256 over the quoted #include closure of `path` (csrc/ and include/): a header edit rebuilds only the translation units that see it."""
+    global _INC_RE
+    import re
+    if _INC_RE is None:
+        _INC_RE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+    seen = seen if seen is not None else {}
+    if path in seen:
+        return ''
+    seen[path] = True
+    with open(path, 'rb') as fh:
+        data = fh.read()
+    h = hashlib.sha256(data)
+    for inc in _INC_RE.findall(data.decode('utf-8', 'replace')):
+        for d in (os.path.dirname(path), CSRC, os.path.join(REPO, 'include')):
+            cand = os.path.join(d, inc)
+            if os.path.exists(cand):
+                h.update(_deps_digest(cand, seen).encode())
+                break
+    return h.hexdigest()
+
+
 def _compile_one(hipcc, src, hdr_digest, verbose):
     path = os.path.join(CSRC, src)
+    hdr_digest = _deps_digest(path)
     obj = os.path.join(OBJDIR, src + '.o')
     stamp = obj + '.stamp'
     flags = COMMON_FLAGS + EXTRA_FLAGS.get(src, [])

@@ -33,6 +33,10 @@
 
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "gemm_shared.h"
 
 namespace {
@@ -428,6 +432,52 @@ int gemm_pp2_mode() {
     }
     return g_gemm_pp2;
 }
+// In-kernel slice reduction (round 6; gemm_pp.hip: pp_reduce_slices).  A K-sliced launch that the ping-pong tile can take (320-wide where that fills
+// the chip, 160-wide otherwise) folds its slices inside the launch: no k_splitk_reduce launch behind it, and -- for the small launches of a rank
+// that holds few images, which used to run on the 128-row two-stage kernel -- the deep LDS-DMA ring of the ping-pong loop.  Bit-identical to
+// partials + reducer (same slices, same fold order, same epilogue function).  MVE_GEMM_RED=0 / mve_gemm_red_tune(0) restore the reducer launches.
+int g_gemm_red = -1;
+bool gemm_red_on() {
+    if (g_gemm_red < 0) {
+        const char* e = getenv("MVE_GEMM_RED");
+        g_gemm_red = e ? atoi(e) : 1;
+    }
+    return g_gemm_red != 0;
+}
+constexpr int SK_SYNC_TILES = 8192;
+// one zeroed counter array per (device, stream): launches of a stream are ordered, and every launch leaves its counters at zero
+int* gemm_sk_sync(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int*> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = bufs.find({dev, s});
+    if (it != bufs.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    int* b = nullptr;
+    if (hipMalloc(&b, SK_SYNC_TILES * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemsetAsync(b, 0, SK_SYNC_TILES * sizeof(int), s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(b); return nullptr; }
+    bufs[{dev, s}] = b;
+    return b;
+}
+// -> MVE_OK: launched, result complete;  1: not taken (the caller runs its ordinary path);  < 0: error
+int launch_red(int dtype, int mode, const GemmParams& p, hipStream_t s) {
+    if (!gemm_red_on() || !gemm_pp_on() || p.splitk <= 1 || p.splitk > 64 || p.M < 64) return 1;
+    GemmParams q = p;
+    const long long tm = mve_cdiv(p.M, 256);
+    if (p.N % 320 == 0 && tm * (p.N / 320) * p.splitk >= 256) q.tile_n = 0;
+    else if (p.N % 160 == 0) q.tile_n = 160;
+    else return 1;
+    const long long tiles = tm * (p.N / (q.tile_n == 160 ? 160 : 320));
+    if (tiles > SK_SYNC_TILES || tiles * p.splitk > 1024) return 1;      // at most four blocks per CU-slot wait on siblings (see pp_reduce_slices)
+    if ((unsigned long long)p.splitk * p.M * p.N * 4ull >= 0xF0000000ull) return 1;      // the partial tiles are addressed through 32-bit buffer offsets
+    q.sk_sync = gemm_sk_sync(s);
+    if (!q.sk_sync) return 1;
+    return mve_gemm_pp_launch(dtype, mode, &q, s);
+}
+
 // MVE_OK after a launch, 1 when neither loop takes the problem (the caller falls back to the 128-row kernel), < 0 on error
 int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
     const int pp2 = gemm_pp2_mode();
@@ -498,6 +548,10 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 
 template <class Tag, int MODE>
 int launch_gemm_split(const GemmParams& p, hipStream_t s) {
+    if (p.splitk > 1) {
+        const int rc = launch_red(Tag::dtype, MODE, p, s);
+        if (rc != 1) return rc;
+    }
     // small batches: 256 x 320 tiles would leave CUs without a block, 256 x 160 tiles (ping-pong loop only) still cover them
     const bool narrow = gemm_big_min_blocks() > 0 && gemm_pp_on() && p.splitk <= 1 && p.N % 320 == 0 && p.M >= 64 &&
                         tile256_blocks(p.M, p.N, 1) < gemm_big_min_blocks() && 2 * tile256_blocks(p.M, p.N, 1) >= gemm_big_min_blocks();
@@ -547,6 +601,10 @@ int launch_phase(GemmParams q, hipStream_t s) {
             const int few = (int)((minb + t1 - 1) / t1);
             q.splitk = few < 2 ? 2 : (few < q.splitk ? few : q.splitk);
         }
+    }
+    if (q.splitk > 1) {
+        const int rr = launch_red(Tag::dtype, 1, q, s);
+        if (rr != 1) return rr;
     }
     const int rc = mve_gemm_pp_launch(Tag::dtype, 1, &q, s);
     if (rc == 1) {
@@ -600,6 +658,12 @@ int mve_gemm_tune(int big_min_blocks) {
         mve_gemm_pp_old_swizzle(g_old_swizzle);
         g_big_min_blocks = big_min_blocks & ~((7 << 28) | (1 << 27) | (1 << 26) | (1 << 25));       // (7 << 28): bits 28, 29 and 30
     }
+    return old;
+}
+
+int mve_gemm_red_tune(int on) {
+    const int old = gemm_red_on() ? 1 : 0;
+    if (on >= 0) g_gemm_red = on ? 1 : 0;
     return old;
 }
 

@@ -207,6 +207,7 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
         }
         return;
     }
+    const __amdgpu_buffer_rsrc_t part_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (int)0xFFFFFFF0u, 0x00020000);      // (sk_sync launches only)
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         if (wm == pass / PPW) {
@@ -242,6 +243,17 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
             if (partial) {
+                if (p.sk_sync) {
+                    // slices folded inside the launch (pp_reduce_slices): the partial tile leaves WRITE-THROUGH (sc1, 16-byte buffer stores) -- visible to
+                    // the sibling blocks on any XCD once this wave's vmcnt has drained, with no L2 write-back fence (a release fence per block
+                    // writes back the XCD's whole L2: measured +100 us on a 256-block launch, profiles/r06_ab_red_v1_fences.log)
+                    const unsigned off = (unsigned)((((size_t)kslice * p.M + mc) * p.N + nc) * 4);
+                    if (ok) {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, part_rsrc, off, 0, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, part_rsrc, off + 16, 0, 16);
+                    }
+                    continue;
+                }
                 float* pp = p.partial + ((size_t)kslice * p.M + mc) * p.N + nc;
                 if (ok) {
                     *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};

@@ -72,6 +72,11 @@ struct GemmParams {
     // The phase convs of mve_upsample_conv_phases write pixel (b, i, j) of a [B][H][W] launch to pixel (b, 2 i + py, 2 j + px) of the [B][2H][2W]
     // NHWC output: ldc = 2 C, orow_shift = log2 W, orow_extra = 2 W C, base shifted by (py 2 W + px) C.
     int orow_shift, orow_extra;
+    // In-kernel slice reduction (round 6, ping-pong tile, splitk > 1): one zero-initialised counter per output tile.  Non-null: the S blocks of a tile
+    // write their fp32 partials, count themselves in, wait until all S have arrived, and each folds ITS share of the tile's rows over the slices
+    // in slice order 0 .. S - 1 and runs the fused epilogue on it -- the arithmetic of k_splitk_reduce, bit for bit, without the second launch.
+    // The last block to finish puts the counter back to zero.
+    int* sk_sync;
     ConvGeom g;
 };
 
