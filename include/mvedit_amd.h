@@ -196,6 +196,11 @@ MVE_API int mve_gemm_tune(int big_min_blocks);
  * rank) thereby run on the ping-pong loop instead of the 128-row two-stage kernel.  Same slices, same fold order, same epilogue: bit-identical to
  * partials + reducer.  1 (default, MVE_GEMM_RED) on, 0 off, negative only queries.  Returns the previous value. */
 MVE_API int mve_gemm_red_tune(int on);
+/* The 128-row GEMM / conv kernel with a four-stage LDS ring (k_gemm_deep, csrc/gemm.hip; round 6): launches of at most `max_blocks` blocks -- the
+ * K-sliced GEMMs / convs of the deep UNet levels when a rank holds few images, where a block's K loop is a chain of memory round trips -- keep three K
+ * tiles in flight instead of one.  Same tile, MFMA order and epilogue as the two-stage loop: bit-identical.  Default 512 (MVE_GEMM_DEEP); 0 turns it
+ * off; negative only queries.  Returns the previous value. */
+MVE_API int mve_gemm_deep_tune(int max_blocks);
 /* Diagnostics: the number of K slices a GEMM / conv launch of this shape runs with under the current switches -- the slice rule's count (a function
  * of rows per image, N, K only), 1 where the un-split launch fills the chip (or the rule's count again in the strict mode, which emulates the slices
  * inside one block), or the smallest count that fills the chip where the rule would over-fill it.  Host logic only. */

@@ -51,8 +51,14 @@ int mve_gemm_pp_launch(int dtype, int mode, const void* params, void* stream);  
 void mve_gemm_pp_old_swizzle(int on);
 namespace {
 
-template <class Tag, int BN, int MODE>   // MODE 0: dense A, 1: conv3x3 gather
-__global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
+// NST: stages of the LDS ring.  2: the two-stage loop of rounds 1-5 (72 KiB at BN = 160: two blocks per CU; tile k + 1 in flight under the MFMAs of
+// tile k, drained at every barrier).  4 (round 6, k_gemm_deep; 144 KiB: one block per CU): launches of at most a block or two per CU -- the K-sliced
+// GEMMs / convs of the deep UNet levels when a rank holds few images -- are a chain of K-tile round trips (measured 1.0-1.5 us per 64-wide K tile against
+// ~0.3 us of MFMA work: time_embedding.linear_2, 20 tiles, 26.6 us; the 8 x 8 conv at 8 images, 22 tiles per slice, 40 us).  The ring keeps THREE tiles in
+// flight and never drains: LDS-DMA pieces issued from inline asm (M0 owned by the loop), one `s_waitcnt vmcnt(2 x pieces)` + `s_barrier` per tile.
+// Same tile, MFMA order and epilogue: bit-identical results.
+template <class Tag, int BN, int MODE, int NST>   // MODE 0: dense A, 1: conv3x3 gather
+__device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned char* smem) {
     constexpr int WN = BN / 2;          // wave sub-tile width
     constexpr int NF = WN / 16;         // W fragments per wave (4 / 5 / 2)
     constexpr int MF = 4;               // activation fragments per wave (64 rows)
@@ -63,12 +69,8 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     constexpr int B_STAGE = BN * ROW_BYTES;
     constexpr int STAGE = A_STAGE + B_STAGE;
     constexpr int CS_LD = BN + 4;                       // fp32 epilogue staging row stride (floats)
-    constexpr int SMEM0 = (2 * STAGE > 64 * CS_LD * 4) ? 2 * STAGE : 64 * CS_LD * 4;
-    constexpr int SMEM = SMEM0;
     typedef typename Tag::V8 V8;
     typedef typename Tag::T T;
-
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -78,9 +80,17 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     // split-K: the K slices of one output tile are adjacent logical blocks (same XCD, concurrently resident)
     const int S = p.splitk > 1 ? p.splitk : 1;
     const unsigned lin = mve_xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n * S));
-    const int kslice = lin % S;
-    const unsigned tile = lin / S;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    int kslice, tm, tn;
+    if (p.w_major) {          // weight strip major (GemmParams::w_major): the row panels of one (column tile, K slice) strip are consecutive blocks
+        tm = (int)(lin % (unsigned)tiles_m);
+        const unsigned rest = lin / (unsigned)tiles_m;
+        kslice = (int)(rest % (unsigned)S);
+        tn = (int)(rest / (unsigned)S);
+    } else {
+        kslice = lin % S;
+        const unsigned tile = lin / S;
+        tm = tile / tiles_n; tn = tile % tiles_n;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-thread load coordinates ------------------------------------------------------
@@ -157,6 +167,10 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     // fast conv addressing for the slab-major K order without upsample (see gemm_big.hip): uniform tap / slab arithmetic,
     // one multiply-add per row, the halo test is a bit of a per-row mask computed once
     const bool fast = MODE == 1 && p.g.chunk64;
+    const int gC1 = p.g.C1, gC3 = p.g.C3, g_nkm = p.g.nk_main;
+    const int dC21 = p.g.C2 - p.g.C1, dC43 = p.g.C4 - p.g.C3;
+    const long long gA1 = (long long)p.A, gA3 = (long long)p.A3;
+    const long long dA21 = (long long)p.A2 - (long long)p.A, dA43 = (long long)p.A4 - (long long)p.A3;
     int pix[A_PASSES];
     unsigned vmask[A_PASSES];
     if constexpr (MODE == 1) {
@@ -173,24 +187,41 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
             vmask[j] = mk;
         }
     }
+    // one LDS-DMA piece: 64 lanes x 16 B, lane-linear from a wave-uniform LDS address.  Ring of more than two stages: issued from inline asm, so that
+    // the compiler neither counts it nor drains it (the waits are the loop's own, below)
+    const unsigned smem_lds = (unsigned)(size_t)smem;
+    auto piece = [&](const T* src, unsigned char* dst) {
+        if constexpr (NST > 2) {
+            const unsigned d = (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_lds + (unsigned)(dst - smem)));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(d) : "memory");
+        } else {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
     auto dma_tile = [&](int kt, int stage) {   // global -> LDS directly, 1 KiB per wave instruction
+#ifdef MVE_GEMM_LAB
+        if ((p.dbg & 32) && kt > kt_begin + 2) return;        // timing-only ablation (tools/ab_gemm_lab.py): no LDS-DMA after the first tiles
+#endif
         const bool kin = kt * BK + lc * 8 < p.K;
         unsigned char* As = smem + stage * STAGE;
         unsigned char* Bs = As + A_STAGE;
         if (MODE == 1 && fast) {
+            // (sources as arithmetic on opaque scalars, as in gemm_pp.hip: left to select between kernarg FIELDS -- `second ? p.A2 : p.A` -- hipcc copies
+            // the parameter block to scratch and indexes it, and every scratch load in the K loop waits vmcnt(0): the whole LDS-DMA queue)
             int t_ = kt % 9, c0 = (kt / 9) * 64;                       // uniform
-            bool second = c0 >= p.g.C1;
-            const T* src = reinterpret_cast<const T*>(second ? p.A2 : p.A);
-            int cs = second ? p.g.C2 : p.g.C1;
-            int ch = (second ? c0 - p.g.C1 : c0) + lc * 8;
-            if (p.g.nk_main > 0 && kt >= p.g.nk_main) {                // 1x1 shortcut part: centre tap of the shortcut sources
+            bool second = c0 >= gC1;
+            long long srcb = gA1 + (second ? dA21 : 0ll);
+            int cs = gC1 + (second ? dC21 : 0);
+            int ch = (second ? c0 - gC1 : c0) + lc * 8;
+            if (g_nkm > 0 && kt >= g_nkm) {                            // 1x1 shortcut part: centre tap of the shortcut sources
                 t_ = 4;
-                c0 = (kt - p.g.nk_main) * 64;
-                second = c0 >= p.g.C3;
-                src = reinterpret_cast<const T*>(second ? p.A4 : p.A3);
-                cs = second ? p.g.C4 : p.g.C3;
-                ch = (second ? c0 - p.g.C3 : c0) + lc * 8;
+                c0 = (kt - g_nkm) * 64;
+                second = c0 >= gC3;
+                srcb = gA3 + (second ? dA43 : 0ll);
+                cs = gC3 + (second ? dC43 : 0);
+                ch = (second ? c0 - gC3 : c0) + lc * 8;
             }
+            const T* src = reinterpret_cast<const T*>(srcb);
             const int dy = t_ / 3, dx = t_ - dy * 3;
             const int toff = dy * p.g.Ws + dx;
 #pragma unroll
@@ -198,20 +229,20 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
                 int to = toff;
                 if (p.g.ups) to = (int)((((vmask[j] >> 9) & 1u) + dy) >> 1) * p.g.Ws + (int)((((vmask[j] >> 10) & 1u) + dx) >> 1);
                 const unsigned off = (unsigned)((pix[j] + to) * cs + ch);
-                const T* s = ((vmask[j] >> t_) & 1u) ? src + off : zero;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES), 16, 0, 0);
+                const T* s = (kin && ((vmask[j] >> t_) & 1u)) ? src + off : zero;      // (kin: the ring issues tiles past the end of K, never read)
+                piece(s, As + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES);
             }
         } else
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
             const T* s = a_src(kt, j, kin);
             s = s ? s : zero;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(As + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES), 16, 0, 0);
+            piece(s, As + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES);
         }
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) {
             const T* s = kin ? w_row[j] + kt * BK + lc * 8 : zero;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)s, (lds_ptr_t)(Bs + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES), 16, 0, 0);
+            piece(s, Bs + (j * ROWS_PER_PASS + wid * 8) * ROW_BYTES);
         }
         advance();
     };
@@ -247,16 +278,12 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
         }
     }
 
-    dma_tile(kt_begin, 0);
-    __syncthreads();
-
     const int frow = lane & 15, fchunk = lane >> 4;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) {
-            dma_tile(kt + 1, cur ^ 1);
-        }
-        const unsigned char* As = smem + cur * STAGE;
+    auto mma_tile = [&](int stage) {
+#ifdef MVE_GEMM_LAB
+        if (p.dbg & 16) return;                               // timing-only ablation: no fragment reads, no MFMAs
+#endif
+        const unsigned char* As = smem + stage * STAGE;
         const unsigned char* Bs = As + A_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -272,10 +299,53 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < MF; ++i) acc[j][i] = Tag::mfma16(wf[j], xf[i], acc[j][i]);
         }
+    };
+    if constexpr (NST > 2) {
+        // Ring of NST stages, prefetch distance D = NST - 1 tiles, never drained.  Iteration i (tile kt = kt_begin + i, stage i % NST):
+        //   wait until this wave's pieces of tile kt have landed -- D tiles are in flight, D - 1 may stay: vmcnt((D - 1) x pieces) -- and meet the
+        //   other waves (RAW: their pieces of tile kt too;  WAR: every wave is done with the MFMAs of tile kt - 1, whose stage (i - 1) % NST =
+        //   (i + D) % NST is the one refilled next);  issue tile kt + D;  MFMAs of tile kt.
+        // Tiles past kt_end are issued all the same (their K columns lie past the slice, or past K: zero page) and never read: the count of pieces in
+        // flight stays uniform, no tail code.  The compiler's own loads (res_in_acc above) are drained first so that they cannot sit in the queue.
+        constexpr int D = NST - 1, PIECES = A_PASSES + B_PASSES;
+        static_assert((D - 1) * PIECES <= 63, "vmcnt range");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned m0_keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(m0_keep));
+#pragma unroll 1
+        for (int t = 0; t < D; ++t) dma_tile(kt_begin + t, t);
+        int st = 0;
+#pragma unroll 1
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((D - 1) * PIECES) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const int st_new = st == 0 ? NST - 1 : st - 1;      // (i + D) % NST
+            dma_tile(kt + D, st_new);
+            mma_tile(st);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // the pieces past the end have landed before the epilogue reuses the ring
+        asm volatile("s_mov_b32 m0, %0" ::"s"(m0_keep));
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+    dma_tile(kt_begin, 0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) {
+            dma_tile(kt + 1, cur ^ 1);
+        }
+        mma_tile(cur);
         __syncthreads();   // the compiler drains the in-flight LDS-DMA (vmcnt(0)) ahead of this barrier
+    }
     }
 
     {
+#ifdef MVE_GEMM_LAB
+        if (p.dbg & 64) return;                               // timing-only ablation: no epilogue
+#endif
         // ---- epilogue: two 64-row passes through an fp32 LDS tile, 16-byte row-segment stores ----------------
         // (measured: storing 8 bytes per lane straight from the accumulators was 10-20 % slower on the K = 320 GEMMs)
         float* Cs = reinterpret_cast<float*>(smem);
@@ -303,6 +373,13 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + ch * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                if (p.splitk > 1 && p.sk_sync) {      // slices folded inside the launch (gemm_reduce_slices below): the partial tile leaves write-through
+                    const unsigned off = (unsigned)((((size_t)kslice * p.M + m) * p.N + n) * 4);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (int)0xFFFFFFF0u, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rs, off, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rs, off + 16, 0, 16);
+                    continue;
+                }
                 if (p.splitk > 1) {      // raw fp32 partial tile of this K slice; the reducer applies the epilogue
                     float* pp = p.partial + ((size_t)kslice * p.M + m) * p.N + n;
                     *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
@@ -314,6 +391,25 @@ __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
             __syncthreads();
         }
     }
+    if (p.splitk > 1 && p.sk_sync) gemm_reduce_slices<Tag, BN, BM, NT>(p, (unsigned)(tm * tiles_n + tn), kslice, S, m0, n0, tid);      // (uniform branch)
+}
+
+template <int BN, int NST>
+constexpr int gemm_smem_bytes() {
+    return (NST * (BM + BN) * ROW_BYTES > 64 * (BN + 4) * 4) ? NST * (BM + BN) * ROW_BYTES : 64 * (BN + 4) * 4;
+}
+
+template <class Tag, int BN, int MODE>
+__global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_smem_bytes<BN, 2>()];
+    gemm_body<Tag, BN, MODE, 2>(p, smem);
+}
+
+constexpr int DEEP_NST = 4;
+template <class Tag, int BN, int MODE>
+__global__ __launch_bounds__(NT, 1) void k_gemm_deep(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    gemm_body<Tag, BN, MODE, DEEP_NST>(p, dyn_smem);
 }
 
 // split-K reducer: out = epilogue( sum_s partial[s] ), 8 columns per thread
@@ -341,6 +437,15 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmParams p) {
 // 256 images).  A view therefore gets bit-identical results alone, in a chunk or on another rank AS LONG AS those launches take the same decision
 // (all small batches do); MVE_GEMM_STRICT_SPLITK=1 / mve_gemm_tune bit 30 / mvedit_amd.parallel.set_partition_invariant() make every launch
 // round as the rule's slices, at any batch (tests/test_abi.py::test_effective_splitk_by_batch).
+template <class Tag>
+int splitk_reduce_launch(const GemmParams& p, hipStream_t s) {
+    if (p.splitk > 1 && !p.sk_sync) {
+        k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
+        MVE_LAUNCH_CHECK();
+    }
+    return MVE_OK;
+}
+
 int g_splitk_policy = -1;      // MVE_GEMM_SPLITK: 1 (default) = the rule below; 0 = never split (A/B: what the slices cost at a given batch)
 int choose_splitk(int rows_per_image, int N, int K) {
     if (g_splitk_policy < 0) {
@@ -357,6 +462,48 @@ int choose_splitk(int rows_per_image, int N, int K) {
     return s < 2 ? 1 : (int)s;
 }
 
+int gemm_red_mode();
+int* gemm_sk_sync(hipStream_t s);
+constexpr int SK_SYNC_TILES = 8192;
+
+// Weight-strip-major block order for launches whose activations are the smaller operand (GemmParams::w_major).  MVE_GEMM_WMAJOR=0 / mve_gemm_deep_tune bit 30 off.
+int g_w_major = -1;
+bool gemm_w_major_on() {
+    if (g_w_major < 0) {
+        const char* e = getenv("MVE_GEMM_WMAJOR");
+        g_w_major = e ? atoi(e) : 1;
+    }
+    return g_w_major != 0;
+}
+
+// The four-stage ring of the 128-row kernel (k_gemm_deep) for launches of at most this many blocks; 0 turns it off.  MVE_GEMM_DEEP / mve_gemm_deep_tune.
+int g_gemm_deep = -1;
+int gemm_deep_max_blocks() {
+    if (g_gemm_deep < 0) {
+        const char* e = getenv("MVE_GEMM_DEEP");
+        g_gemm_deep = e ? atoi(e) : 0;
+    }
+    return g_gemm_deep;
+}
+
+template <class Tag>
+int splitk_reduce_launch(const GemmParams& p, hipStream_t s);
+
+template <class Tag, int BN, int MODE>
+int launch_deep(const GemmParams& p, unsigned grid, hipStream_t s) {
+    constexpr int SM = gemm_smem_bytes<BN, DEEP_NST>();
+    static bool configured[64] = {};
+    int dev = 0;
+    MVE_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !configured[dev]) {
+        MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_deep<Tag, BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, SM));
+        configured[dev] = true;
+    }
+    k_gemm_deep<Tag, BN, MODE><<<grid, NT, SM, s>>>(p);
+    MVE_LAUNCH_CHECK();
+    return splitk_reduce_launch<Tag>(p, s);
+}
+
 template <class Tag, int MODE>
 int launch_v(const GemmParams& p, hipStream_t s) {
     MVE_CHECK(p.g.kw != 2, MVE_ERR_STATE, "gemm: 2 x 2 conv windows run on the ping-pong kernel only");
@@ -367,15 +514,31 @@ int launch_v(const GemmParams& p, hipStream_t s) {
     else if (p.N <= 64) bn = 64;
     const unsigned tiles_m = mve_cdiv(p.M, BM), tiles_n = mve_cdiv(p.N, bn);
     const unsigned grid = tiles_m * tiles_n * (p.splitk > 1 ? p.splitk : 1);
+#ifdef MVE_GEMM_LAB
+    { const char* e = getenv("MVE_GEMM_LAB_BITS"); const_cast<GemmParams&>(p).dbg = e ? atoi(e) : 0; }
+#endif
+    // K slices folded inside the launch (gemm_reduce_slices) where every block of the grid is resident at once -- two 72 KiB blocks per CU -- so that a
+    // block waiting for its siblings never holds the slot one of them needs: no k_splitk_reduce launch behind such a launch
+    GemmParams pf;
+    if (p.splitk > 1 && !p.sk_sync && (gemm_red_mode() & 1) && grid <= 512 && tiles_m * tiles_n <= (unsigned)SK_SYNC_TILES &&
+        (unsigned long long)p.splitk * p.M * p.N * 4ull < 0xF0000000ull) {
+        if (int* sync = gemm_sk_sync(s)) {
+            pf = p;
+            pf.sk_sync = sync;
+            return launch_v<Tag, MODE>(pf, s);
+        }
+    }
+    // launches of at most gemm_deep_max_blocks() blocks (a block or two per CU) and more than two K tiles per block: the four-stage ring (k_gemm_deep)
+    const int nk_slice = ((p.K + BK - 1) / BK) / (p.splitk > 1 ? p.splitk : 1);
+    if ((int)grid <= gemm_deep_max_blocks() && nk_slice > 2 && bn >= 128) {
+        if (bn == 160) return launch_deep<Tag, 160, MODE>(p, grid, s);
+        return launch_deep<Tag, 128, MODE>(p, grid, s);
+    }
     if (bn == 160) k_gemm<Tag, 160, MODE><<<grid, NT, 0, s>>>(p);
     else if (bn == 128) k_gemm<Tag, 128, MODE><<<grid, NT, 0, s>>>(p);
     else k_gemm<Tag, 64, MODE><<<grid, NT, 0, s>>>(p);
     MVE_LAUNCH_CHECK();
-    if (p.splitk > 1) {
-        k_splitk_reduce<Tag><<<mve_cdiv((size_t)p.M * (p.N / 8), 256), 256, 0, s>>>(p);
-        MVE_LAUNCH_CHECK();
-    }
-    return MVE_OK;
+    return splitk_reduce_launch<Tag>(p, s);
 }
 
 // What a launch does when the slice rule (choose_splitk) asks for S > 1 slices but the un-split launch already fills the chip (>= one 256 x 320
@@ -436,15 +599,14 @@ int gemm_pp2_mode() {
 // the chip, 160-wide otherwise) folds its slices inside the launch: no k_splitk_reduce launch behind it, and -- for the small launches of a rank
 // that holds few images, which used to run on the 128-row two-stage kernel -- the deep LDS-DMA ring of the ping-pong loop.  Bit-identical to
 // partials + reducer (same slices, same fold order, same epilogue function).  MVE_GEMM_RED=0 / mve_gemm_red_tune(0) restore the reducer launches.
-int g_gemm_red = -1;
-bool gemm_red_on() {
+int g_gemm_red = -1;      // bit 0: the 128-row kernel folds its slices (launch_v);  bit 1: small K-sliced launches go to the ping-pong tile and fold there (launch_red)
+int gemm_red_mode() {
     if (g_gemm_red < 0) {
         const char* e = getenv("MVE_GEMM_RED");
-        g_gemm_red = e ? atoi(e) : 1;
+        g_gemm_red = e ? atoi(e) : 0;      // off: measured slower than partials + reducer on every K-sliced launch of an 8-image forward but the longest (profiles/r06_fold_modes_8images.log)
     }
-    return g_gemm_red != 0;
+    return g_gemm_red;
 }
-constexpr int SK_SYNC_TILES = 8192;
 // one zeroed counter array per (device, stream): launches of a stream are ordered, and every launch leaves its counters at zero
 int* gemm_sk_sync(hipStream_t s) {
     static std::mutex mu;
@@ -464,14 +626,14 @@ int* gemm_sk_sync(hipStream_t s) {
 }
 // -> MVE_OK: launched, result complete;  1: not taken (the caller runs its ordinary path);  < 0: error
 int launch_red(int dtype, int mode, const GemmParams& p, hipStream_t s) {
-    if (!gemm_red_on() || !gemm_pp_on() || p.splitk <= 1 || p.splitk > 64 || p.M < 64) return 1;
+    if (!(gemm_red_mode() & 2) || !gemm_pp_on() || p.splitk <= 1 || p.splitk > 64 || p.M < 64) return 1;
     GemmParams q = p;
     const long long tm = mve_cdiv(p.M, 256);
     if (p.N % 320 == 0 && tm * (p.N / 320) * p.splitk >= 256) q.tile_n = 0;
     else if (p.N % 160 == 0) q.tile_n = 160;
     else return 1;
     const long long tiles = tm * (p.N / (q.tile_n == 160 ? 160 : 320));
-    if (tiles > SK_SYNC_TILES || tiles * p.splitk > 1024) return 1;      // at most four blocks per CU-slot wait on siblings (see pp_reduce_slices)
+    if (tiles > SK_SYNC_TILES || tiles * p.splitk > 256) return 1;      // every block of the grid resident at once (one 104-144 KiB block per CU): a block waiting for its siblings never holds the slot one of them needs
     if ((unsigned long long)p.splitk * p.M * p.N * 4ull >= 0xF0000000ull) return 1;      // the partial tiles are addressed through 32-bit buffer offsets
     q.sk_sync = gemm_sk_sync(s);
     if (!q.sk_sync) return 1;
@@ -661,9 +823,15 @@ int mve_gemm_tune(int big_min_blocks) {
     return old;
 }
 
+int mve_gemm_deep_tune(int max_blocks) {
+    const int old = gemm_deep_max_blocks() | (gemm_w_major_on() ? 0 : (1 << 30));
+    if (max_blocks >= 0) { g_gemm_deep = max_blocks & ~(1 << 30); g_w_major = (max_blocks & (1 << 30)) ? 0 : 1; }
+    return old;
+}
+
 int mve_gemm_red_tune(int on) {
-    const int old = gemm_red_on() ? 1 : 0;
-    if (on >= 0) g_gemm_red = on ? 1 : 0;
+    const int old = gemm_red_mode();
+    if (on >= 0) g_gemm_red = on & 3;
     return old;
 }
 
@@ -716,6 +884,7 @@ int mve_gemm_pair(int dtype, const void* A, int lda, const void* W, int ldw, voi
     int rc = check_common(p, "gemm");
     if (rc) return rc;
     MVE_CHECK(A && lda % 8 == 0 && lda >= K, MVE_ERR_ARG, "gemm: bad A/lda (%d)", lda);
+    p.w_major = gemm_w_major_on() && M < N;       // fewer activation rows than weight rows: walk the row panels inside a weight strip (GemmParams::w_major)
     p.splitk = 1;
     if (workspace && !(flags & MVE_GEMM_NO_SPLITK)) {
         const int sk = choose_splitk(rows_per_image, N, K);
@@ -771,6 +940,7 @@ static int conv3x3_impl(int dtype, const void* x1, int C1, const void* x2, int C
     p.res_after_scale = (flags & MVE_GEMM_RES_AFTER_SCALE) ? 1 : 0;
     int rc = check_common(p, "conv3x3");
     if (rc) return rc;
+    p.w_major = gemm_w_major_on() && (long long)p.M * (C1 + C2) < (long long)p.N * p.K;      // activation tensor smaller than the weights (GemmParams::w_major)
     p.splitk = 1;
     if (workspace && !(flags & MVE_GEMM_NO_SPLITK)) {
         const int sk = choose_splitk(p.g.Ho * p.g.Wo, p.N, p.K);

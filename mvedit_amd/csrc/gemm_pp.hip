@@ -211,64 +211,6 @@ __device__ __forceinline__ void pp2_epilogue(const GemmParams& p, f32x4 (&acc)[5
     if (has_res) run(std::true_type()); else run(std::false_type());
 }
 
-// In-kernel slice reduction (GemmParams::sk_sync; RED instantiations).  Called by all 512 threads after the block's fp32 partial tile has been
-// written (big_tile_epilogue, `partial` path: write-through sc1 stores).  Arrival: every wave drains its vmcnt, then one lane counts the block in
-// (relaxed agent-scope atomic) and polls, relaxed, until the tile's S slices are all there; the partial tiles are read with sc1 loads -- correct
-// for any placement of the slices on XCDs / CUs, without a release or acquire fence (MI355X_MICROARCH.md, inter-workgroup visibility).  Every block then folds rows [256 s / S, 256 (s + 1) / S) of the tile over the slices in slice order 0 .. S - 1 starting from 0.0f and hands the
-// sums to gemm_epilogue_store: exactly k_splitk_reduce's arithmetic, so the result is bit-identical to partials + reducer launch on any tile
-// width and for any arrival order.  Waiting on siblings cannot deadlock: the slices of a tile are adjacent logical blocks (adjacent dispatch
-// slots of one XCD, mve_xcd_remap), the hardware dispatches blocks in index order, and a block only waits AFTER its own K loop -- the few tiles
-// that straddle the chunk boundary of two XCDs wait for blocks that are dispatched as soon as any other block retires.  The launcher keeps such
-// launches to at most four blocks per CU-slot anyway (gemm.hip).  Departure: the block that leaves last zeroes the counter for the next launch.
-template <class Tag, int BN2>
-__device__ __forceinline__ void pp_reduce_slices(const GemmParams& p, unsigned tile, int kslice, int S, int m0, int n0, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its write-through partial stores have reached memory
-    __syncthreads();
-    int* cnt = p.sk_sync + tile;
-    if (tid == 0) {
-        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (relaxed polling: an acquire load invalidates the CU's L1 on every poll; nothing below needs an acquire -- the partial tiles are read sc1)
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(4);
-    }
-    __syncthreads();
-    constexpr int CH = BN2 / 8;
-    const int r_lo = PBM * kslice / S, r_hi = PBM * (kslice + 1) / S;
-    const unsigned slice = (unsigned)((size_t)p.M * p.N * 4);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (int)0xFFFFFFF0u, 0x00020000);
-    auto ld = [&](unsigned off) {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);      // aux 16 = sc1: served past the L1, which may hold an older launch's lines
-        return f32x4{__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
-    };
-    for (int task = tid; task < (r_hi - r_lo) * CH; task += PNTH) {
-        const int r = task / CH, ch = task - r * CH;
-        const int m = m0 + r_lo + r, n = n0 + ch * 8;
-        if (m >= p.M || n >= p.N) continue;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const unsigned base = (unsigned)(((size_t)m * p.N + n) * 4);
-        int s = 0;
-        for (; s + 4 <= S; s += 4) {       // four slices requested before the first one is added; the additions stay in slice order
-            f32x4 a[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = ld(base + (unsigned)(s + u) * slice); b[u] = ld(base + (unsigned)(s + u) * slice + 16); }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += a[u][e]; v[4 + e] += b[u][e]; }
-        }
-        for (; s < S; ++s) {
-            const f32x4 a = ld(base + (unsigned)s * slice), b = ld(base + (unsigned)s * slice + 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
-        }
-        gemm_epilogue_store<Tag>(p, m, n, v);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 2 * S - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // Section timing (development aid, mve_gemm_pp_profile): per wave, shader-clock sums of the four parts of a step.
 __device__ unsigned long long* g_pp_prof = nullptr;
 
@@ -305,9 +247,18 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
     const int tiles_m = (p.M + PBM - 1) / PBM;
     const int S = p.splitk > 1 ? p.splitk : 1;
     const unsigned lin = mve_xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n * S));
-    const int kslice = lin % S;
-    const unsigned tile = lin / S;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    int kslice, tm, tn;
+    if (p.w_major) {          // weight strip major (GemmParams::w_major): the row panels of one (column tile, K slice) strip are consecutive blocks
+        tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)tiles_m));
+        const unsigned rest = lin / (unsigned)tiles_m;
+        kslice = __builtin_amdgcn_readfirstlane((int)(rest % (unsigned)S));
+        tn = __builtin_amdgcn_readfirstlane((int)(rest / (unsigned)S));
+    } else {
+        kslice = lin % S;
+        const unsigned t_ = lin / S;
+        tm = t_ / tiles_n; tn = t_ % tiles_n;
+    }
+    const unsigned tile = (unsigned)(tm * tiles_n + tn);
     const int m0 = tm * PBM, n0 = tn * BN2;
 
     const int nk_all = p.K / BK;
@@ -630,7 +581,7 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
     pp_mfma_settle();
     if constexpr (NSL == 3) pp2_epilogue<Tag>(p, acc, smem, m0, n0, wid, lane, wm, wn);
     else big_tile_epilogue<Tag, BN2, WAVES_N, PAIR>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
-    if constexpr (RED) pp_reduce_slices<Tag, BN2>(p, tile, kslice, S, m0, n0, tid);
+    if constexpr (RED) gemm_reduce_slices<Tag, BN2, PBM, PNTH>(p, tile, kslice, S, m0, n0, tid);
     if constexpr (PROF) {
         if (g_pp_prof && lane == 0) {
             __builtin_amdgcn_s_waitcnt(0);     // the epilogue's stores have left the wave (vmcnt / lgkmcnt / expcnt all zero)

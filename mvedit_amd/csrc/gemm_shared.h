@@ -77,6 +77,12 @@ struct GemmParams {
     // in slice order 0 .. S - 1 and runs the fused epilogue on it -- the arithmetic of k_splitk_reduce, bit for bit, without the second launch.
     // The last block to finish puts the counter back to zero.
     int* sk_sync;
+    // Block -> tile order (round 6).  0: row panel major -- consecutive logical blocks (one XCD, one L2) share an activation row panel and walk the
+    // weight strips: every XCD reads 1/8 of the activations and ALL of W.  1: weight strip major -- consecutive blocks share a (column tile, K slice)
+    // strip of W and walk the row panels: every XCD reads 1/8 of W and all of the activations.  The dispatcher sets it where the activations are
+    // the smaller operand (few rows: the deep UNet levels, small batches), where re-fetching all of W into eight L2s over the fabric is what
+    // bounds the launch (profiles/r06_ab_deep_ring_null.log: 118-236 MB of weight re-reads per 8-image conv).  Pure index remap: identical bits.
+    int w_major;
     ConvGeom g;
 };
 
@@ -202,5 +208,63 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, 
     if (p.residual) rr = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
     gemm_epilogue_tail<Tag>(p, m, n, v, rr);
 }
+
+// In-kernel slice reduction (GemmParams::sk_sync).  Called by all threads of a block (PNTH threads, PBM x BN2 tile) after its fp32 partial tile has been
+// written with write-through (sc1) stores (big_tile_epilogue's `partial` path; the 128-row kernel's epilogue).  Arrival: every wave drains its vmcnt, then one lane counts the block in
+// (relaxed agent-scope atomic) and polls, relaxed, until the tile's S slices are all there; the partial tiles are read with sc1 loads -- correct
+// for any placement of the slices on XCDs / CUs, without a release or acquire fence (MI355X_MICROARCH.md, inter-workgroup visibility).  Every block then folds rows [PBM s / S, PBM (s + 1) / S) of the tile over the slices in slice order 0 .. S - 1 starting from 0.0f and hands the
+// sums to gemm_epilogue_store: exactly k_splitk_reduce's arithmetic, so the result is bit-identical to partials + reducer launch on any tile
+// width and for any arrival order.  Waiting on siblings cannot deadlock: the launchers (gemm.hip: launch_red, launch_v) fold inside the launch only
+// where the whole grid is resident at once (at most one ping-pong block, or two 128-row blocks, per CU), so a waiting block never holds the slot
+// a sibling needs; a block only waits AFTER its own K loop.  Departure: the block that leaves last zeroes the counter for the next launch.
+template <class Tag, int BN2, int PBM, int PNTH>
+__device__ __forceinline__ void gemm_reduce_slices(const GemmParams& p, unsigned tile, int kslice, int S, int m0, int n0, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its write-through partial stores have reached memory
+    __syncthreads();
+    int* cnt = p.sk_sync + tile;
+    if (tid == 0) {
+        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (relaxed polling: an acquire load invalidates the CU's L1 on every poll; nothing below needs an acquire -- the partial tiles are read sc1)
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    constexpr int CH = BN2 / 8;
+    const int r_lo = PBM * kslice / S, r_hi = PBM * (kslice + 1) / S;
+    const unsigned slice = (unsigned)((size_t)p.M * p.N * 4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (int)0xFFFFFFF0u, 0x00020000);
+    auto ld = [&](unsigned off) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);      // aux 16 = sc1: served past the L1, which may hold an older launch's lines
+        return f32x4{__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+    };
+    for (int task = tid; task < (r_hi - r_lo) * CH; task += PNTH) {
+        const int r = task / CH, ch = task - r * CH;
+        const int m = m0 + r_lo + r, n = n0 + ch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned base = (unsigned)(((size_t)m * p.N + n) * 4);
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {       // four slices requested before the first one is added; the additions stay in slice order
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = ld(base + (unsigned)(s + u) * slice); b[u] = ld(base + (unsigned)(s + u) * slice + 16); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += a[u][e]; v[4 + e] += b[u][e]; }
+        }
+        for (; s < S; ++s) {
+            const f32x4 a = ld(base + (unsigned)s * slice), b = ld(base + (unsigned)s * slice + 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+        }
+        gemm_epilogue_store<Tag>(p, m, n, v);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 2 * S - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 
 }  // namespace

@@ -221,7 +221,11 @@ __device__ __forceinline__ void gnf_block_sum(float (&v)[GNF_MAX_GROUPS], float*
     }
 }
 
-template <class Tag, int NT, int MAXI>
+// PAIR (round 5): the sources are stream pairs (hi + lo8, common.h).  The 16-bit halves stay packed in registers as before; the 8-bit low halves
+// are re-read from memory in each of the three passes (8 bytes per vector, L2-resident: the slice was fetched a moment ago) instead of costing
+// another 2 registers per vector next to MAXI = 20 of them.  Until round 5 a pair took the three-launch path at every size: 28 of the 61 GroupNorms
+// of an SD-1.5 forward, ~20 us each at 8 images per rank.
+template <class Tag, int NT, int MAXI, bool PAIR = false>
 __global__ __launch_bounds__(NT) void k_gn_fused(GNSrc s, int G, int W8, int nchunk, int xcd_map, float eps, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, int silu, void* __restrict__ out) {
     typedef typename Tag::T T;
@@ -240,6 +244,24 @@ __global__ __launch_bounds__(NT) void k_gn_fused(GNSrc s, int G, int W8, int nch
     }
     const int total = s.HW * W8;
     V8 raw[MAXI];
+    // the 8 values of vector `it` (row, c8): the packed 16-bit half, plus its low half when the source is a pair
+    auto vals = [&](int it, int row, int c8, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Tag::to_f32(raw[it][e]);
+        if constexpr (PAIR) {
+            const int ch = (chunk * W8 + c8) * 8;
+            const bool first = ch < s.C1;
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(first ? s.x1_lo : s.x2_lo);
+            if (base) {
+                const u32x2 l = *reinterpret_cast<const u32x2*>(base + ((size_t)b * s.HW + row) * (first ? s.C1 : s.C2) + (first ? ch : ch - s.C1));
+                float a4[4], b4[4];
+                mve_lo8_unpack4(l[0], a4);
+                mve_lo8_unpack4(l[1], b4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += a4[e]; v[4 + e] += b4[e]; }
+            }
+        }
+    };
     float acc[GNF_MAX_GROUPS] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
@@ -249,8 +271,10 @@ __global__ __launch_bounds__(NT) void k_gn_fused(GNSrc s, int G, int W8, int nch
             raw[it] = *reinterpret_cast<const V8*>(gn_chunk_ptr<Tag>(s, b, row, chunk * W8 + c8));
             const int g0 = (c8 * 8) / cpg, eb = (g0 + 1) * cpg - c8 * 8;
             float lo = 0.f, hi = 0.f;
+            float x8[8];
+            vals(it, row, c8, x8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float v = Tag::to_f32(raw[it][e]); if (e < eb) lo += v; else hi += v; }
+            for (int e = 0; e < 8; ++e) { const float v = x8[e]; if (e < eb) lo += v; else hi += v; }
 #pragma unroll
             for (int g = 0; g < GNF_MAX_GROUPS; ++g) acc[g] += (g == g0 ? lo : 0.f) + (g == g0 + 1 ? hi : 0.f);
         }
@@ -270,9 +294,11 @@ __global__ __launch_bounds__(NT) void k_gn_fused(GNSrc s, int G, int W8, int nch
 #pragma unroll
             for (int g = 0; g < GNF_MAX_GROUPS; ++g) { m0 = g == g0 ? mean[g] : m0; m1 = g == g0 + 1 ? mean[g] : m1; }
             float lo = 0.f, hi = 0.f;
+            float x8[8];
+            vals(it, row, c8, x8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = Tag::to_f32(raw[it][e]);
+                const float v = x8[e];
                 if (e < eb) { const float d = v - m0; lo = __builtin_fmaf(d, d, lo); } else { const float d = v - m1; hi = __builtin_fmaf(d, d, hi); }
             }
 #pragma unroll
@@ -298,9 +324,11 @@ __global__ __launch_bounds__(NT) void k_gn_fused(GNSrc s, int G, int W8, int nch
         if (i < total) {
             const int row = i / W8, c8 = i - row * W8;
             V8 pk;
+            float x8[8];
+            vals(it, row, c8, x8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float y = __builtin_fmaf(Tag::to_f32(raw[it][e]), tab[0][c8 * 8 + e], tab[1][c8 * 8 + e]);
+                float y = __builtin_fmaf(x8[e], tab[0][c8 * 8 + e], tab[1][c8 * 8 + e]);
                 if (silu) y = y / (1.0f + __expf(-y));
                 pk[e] = Tag::from_f32(y);
             }
@@ -310,6 +338,14 @@ __global__ __launch_bounds__(NT) void k_gn_fused(GNSrc s, int G, int W8, int nch
 }
 
 int g_gn_fused_max_hw = -1;          // -1: read MVE_GN_FUSED_MAX_HW (default 1024); 0 disables the one-launch path
+int g_gn_fused_pair_max_hw = -1;     // -1: read MVE_GN_FUSED_PAIR_MAX_HW (default 256): stream PAIRS take the one-launch path up to this many pixels per image
+int gn_fused_pair_max_hw() {
+    if (g_gn_fused_pair_max_hw < 0) {
+        const char* e = getenv("MVE_GN_FUSED_PAIR_MAX_HW");
+        g_gn_fused_pair_max_hw = e ? atoi(e) : 256;
+    }
+    return g_gn_fused_pair_max_hw;
+}
 
 // -> vectors per row of a chunk (0: the tensor does not take the one-launch path), threads and vectors per thread
 int gnf_plan(int HW, int C, int G, int* nt, int* maxi) {
@@ -332,17 +368,17 @@ int gnf_plan(int HW, int C, int G, int* nt, int* maxi) {
     return W8;
 }
 
-template <class Tag, int NT>
+template <class Tag, int NT, bool PAIR = false>
 int gnf_launch(const GNSrc& s, int G, int W8, int maxi, float eps, const float* gamma, const float* beta, int silu, void* out, hipStream_t st) {
     const int nchunk = (s.C1 + s.C2) / (W8 * 8);
     const int xcd = (s.B % 8 == 0) ? 1 : 0;
     const unsigned grid = (unsigned)(s.B * nchunk);
     switch (maxi) {
-        case 4: k_gn_fused<Tag, NT, 4><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
-        case 8: k_gn_fused<Tag, NT, 8><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
-        case 12: k_gn_fused<Tag, NT, 12><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
-        case 16: k_gn_fused<Tag, NT, 16><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
-        default: k_gn_fused<Tag, NT, 20><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        case 4: k_gn_fused<Tag, NT, 4, PAIR><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        case 8: k_gn_fused<Tag, NT, 8, PAIR><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        case 12: k_gn_fused<Tag, NT, 12, PAIR><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        case 16: k_gn_fused<Tag, NT, 16, PAIR><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
+        default: k_gn_fused<Tag, NT, 20, PAIR><<<grid, NT, 0, st>>>(s, G, W8, nchunk, xcd, eps, gamma, beta, silu, out); break;
     }
     MVE_LAUNCH_CHECK();
     return MVE_OK;
@@ -463,8 +499,19 @@ int gn_run(const GNSrc& s, int G, float eps, const float* gamma, const float* be
            hipStream_t st) {
     const int C = s.C1 + s.C2;
     int nt = 0, maxi = 0;
-    const bool pair = s.x1_lo || s.x2_lo;        // (the one-launch kernel keeps its slice packed in registers: the pair takes the three-launch path)
+    const bool pair = s.x1_lo || s.x2_lo;
     if (pair) {
+        // (round 5) small tensors take the one-launch kernel as pairs too -- the choice depends on (HW, C, G) only, as for plain tensors
+        // (1024-thread blocks with > 8 vectors per thread -- the 960 / 1920-channel concatenations at 32 x 32 -- would spill next to the unpacking: those
+        // stay on the three launches)
+        // (round 6) ... up to gn_fused_pair_max_hw() = 256 pixels per image (the 16 x 16 and 8 x 8 levels): round 5 measured the pair-reading one-launch
+        // kernel at every size <= 1024 and reverted it -- +0.4 ms per 64-image step, all of it on the 32 x 32 tensors (20 packed vectors per thread
+        // next to the unpacking), against -0.2 ms at 8 images per rank (profiles/r05_gn_fused_pair_reverted.log).  Below 32 x 32 the slices are 4-8
+        // vectors per thread and the three launches are ~5 us of work under ~20 us of launch chain at any batch.
+        const int W8 = s.HW <= gn_fused_pair_max_hw() ? gnf_plan(s.HW, C, G, &nt, &maxi) : 0;
+        if (W8 && !(nt == 1024 && maxi > 8))
+            return nt == 256 ? gnf_launch<Tag, 256, true>(s, G, W8, maxi, eps, gamma, beta, silu, out, st)
+                             : gnf_launch<Tag, 1024, true>(s, G, W8, maxi, eps, gamma, beta, silu, out, st);
         const int tx = gn_tx(C);
         const int ncg = (C / 8 + tx - 1) / tx;
         const int ns = gn_nsplit(s.B, s.HW, C);

@@ -39,9 +39,13 @@ def test_linear_slices_folded_in_the_launch(lib, red, dtype, M, N, K, rpi):
     assert _lib.raw('mve_gemm_workspace_bytes')(M, N, K, rpi) > 0, 'the slice rule must cut this shape'
     a, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
     bias, res = rnd((N,), torch.float32, 3).cuda(), rnd((M, N), dtype, 4).cuda()
-    red(1)
+    red(2)                                           # ping-pong tile, slices folded in the launch
     o1 = ops.gemm(a, w, bias=bias, residual=res, rows_per_image=rpi)
     o1b = ops.gemm(a, w, bias=bias, residual=res, rows_per_image=rpi)
+    red(1)                                           # 128-row kernel, slices folded in the launch
+    o2 = ops.gemm(a, w, bias=bias, residual=res, rows_per_image=rpi)
+    o2b = ops.gemm(a, w, bias=bias, residual=res, rows_per_image=rpi)
+    assert torch.equal(o1, o2) and torch.equal(o2, o2b), '128-row fold != ping-pong fold'
     red(0)
     o0 = ops.gemm(a, w, bias=bias, residual=res, rows_per_image=rpi)
     old = tune(-1)
@@ -54,7 +58,7 @@ def test_linear_slices_folded_in_the_launch(lib, red, dtype, M, N, K, rpi):
     assert torch.equal(o1, o128), 'in-kernel fold != 128-row kernel + reducer'
     assert torch.equal(o1, o1b), 'second launch differs: counters not back at zero?'
     check('linear', o1, a.float().cpu() @ w.float().cpu().t() + bias.cpu() + res.float().cpu(), dtype, f'M={M} N={N} K={K}')
-    red(1)
+    red(3)
     rows = min(M, rpi)
     alone = ops.gemm(a[:rows], w, bias=bias, residual=res[:rows], rows_per_image=rpi)
     assert torch.equal(alone, o1[:rows]), 'batch invariance'
@@ -70,16 +74,16 @@ def test_linear_slices_pair_geglu_and_streams(lib, red, dtype):
     r32 = torch.randn(M, N, generator=torch.Generator().manual_seed(9)) * 3
     rh, rl = _split_pair(r32, dtype)
     outs = []
-    for on in (1, 0):
+    for on in (2, 1, 0):
         red(on)
         hi, lo = ops.gemm(a, w, bias=bias, residual=rh.cuda(), residual_lo=rl.cuda(), rows_per_image=rpi, pair_out=True)
         g = ops.gemm(a, w, flags=ops.GEGLU, rows_per_image=rpi)
         outs.append((hi, lo, g))
-    assert all(torch.equal(x, y) for x, y in zip(*outs))
+    assert all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(*outs))
     hi, lo, _ = outs[0]
     ref = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu() + (rh.double() + _lo(rl))
     assert float(((hi.double().cpu() + _lo(lo)) - ref).abs().max() / ref.abs().max()) < _pair_tol(dtype)
-    red(1)
+    red(3)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     got = []
@@ -109,9 +113,12 @@ def test_conv_slices_folded_in_the_launch(lib, red, dtype, B, H, C1, C2, Cout):
     w_k, wflag = ops.pack_conv_weight(wt, True)
     a1, a2 = to_nhwc(x1).cuda(), (to_nhwc(x2).cuda() if C2 else None)
     kw = dict(x2=a2, bias=bias.cuda(), rowvec=temb, flags=wflag)
-    red(1)
+    red(2)
     o1 = ops.conv3x3(a1, w_k.cuda(), B, H, H, **kw)[0]
     o1b = ops.conv3x3(a1, w_k.cuda(), B, H, H, **kw)[0]
+    red(1)
+    o2 = ops.conv3x3(a1, w_k.cuda(), B, H, H, **kw)[0]
+    assert torch.equal(o1, o2) and torch.equal(o2, ops.conv3x3(a1, w_k.cuda(), B, H, H, **kw)[0]), '128-row fold != ping-pong fold'
     red(0)
     o0 = ops.conv3x3(a1, w_k.cuda(), B, H, H, **kw)[0]
     old = tune(-1)
@@ -124,7 +131,7 @@ def test_conv_slices_folded_in_the_launch(lib, red, dtype, B, H, C1, C2, Cout):
     xin = torch.cat([x1, x2], 1) if C2 else x1
     ref = conv_ref(xin, wt, bias) + temb.cpu()[:, :, None, None]
     check('conv', o1, to_nhwc(ref), dtype, f'B={B} H={H} C={C1}+{C2}->{Cout}')
-    red(1)
+    red(3)
     alone = ops.conv3x3(a1[:H * H], w_k.cuda(), 1, H, H, x2=(a2[:H * H] if C2 else None), bias=bias.cuda(), rowvec=temb[:1], flags=wflag)[0]
     assert torch.equal(alone, o1[:H * H]), 'batch invariance'
 
@@ -141,7 +148,7 @@ def test_upsample_phases_and_pair_outputs_through_the_fold(lib, red, B, H, C):
     r32 = torch.randn(B * H * H, C, generator=torch.Generator().manual_seed(9)) * 2
     rh, rl = _split_pair(r32, dtype)
     outs = []
-    for on in (1, 0):
+    for on in (3, 1, 0):
         red(on)
         (hi, lo), _, _ = ops.conv3x3(x, w_k.cuda(), B, H, H, bias=bias, residual=rh.cuda(), residual_lo=rl.cuda(), flags=wflag, pair_out=True)
         row = [hi, lo]
@@ -150,7 +157,51 @@ def test_upsample_phases_and_pair_outputs_through_the_fold(lib, red, B, H, C):
             ph, pl = ops.upsample_conv_phases(x, w4, B, H, H, bias=bias, pair_out=True)
             row += [ph, pl]
         outs.append(row)
-    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(*outs))
     hi, lo = outs[0][:2]
     ref = to_nhwc(conv_ref(rnd((B, C, H, H), dtype, 1), wt, bias.cpu())).double() + (rh.double() + _lo(rl))
     assert float(((hi.double().cpu() + _lo(lo)) - ref).abs().max() / ref.abs().max()) < _pair_tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_four_stage_ring_of_the_128_row_kernel_is_bit_identical(lib, red, dtype):
+    """k_gemm_deep (csrc/gemm.hip): the 128-row kernel with three K tiles in flight for launches of a block or two per CU -- same tile, same MFMA
+    order, same epilogue as the two-stage loop, so every bit must agree; dense, conv (slab-major and tap-major weights, concat, stride 2, fused
+    shortcut), K slices that start inside a slab, K tails (K % 64 != 0), one-tile problems."""
+    from mvedit_amd import ops, _lib
+    deep, tune = _lib.raw('mve_gemm_deep_tune'), _lib.raw('mve_gemm_tune')
+    old_d, old_t = deep(-1), tune(-1)
+    red(0)
+    try:
+        tune(0)                                     # the 128-row kernel everywhere
+        def both(fn):
+            deep(0); a = fn(); deep(4096); b = fn()
+            return a, b
+        for (M, N, K, rpi, fl) in [(512, 1280, 1280, 64, 0), (512, 1280, 5120, 64, 0), (2048, 1280, 1280, 256, 0), (8, 1280, 1280, 0, 0), (77 * 8, 1280, 768, 0, 0),
+                                   (300, 640, 328, 0, 0), (512, 2560, 320, 0, ops.GEGLU), (130, 128, 200, 0, 0), (64, 320, 64, 0, 0)]:
+            a, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
+            bias = rnd((N,), torch.float32, 3).cuda()
+            res = None if fl else rnd((M, N), dtype, 4).cuda()
+            x, y = both(lambda: ops.gemm(a, w, bias=bias, residual=res, flags=fl, rows_per_image=rpi))
+            assert torch.equal(x, y), (M, N, K)
+            ref = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+            if fl:
+                ref = ref[:, 0::2] * F.gelu(ref[:, 1::2])
+            else:
+                ref = ref + res.float().cpu()
+            check('deep gemm', y, ref, dtype, f'M={M} N={N} K={K}')
+        for (B, H, C1, C2, Cout, stride, chunk) in [(8, 8, 1280, 0, 1280, 1, True), (2, 16, 640, 320, 640, 1, True), (2, 16, 320, 0, 320, 2, True), (3, 9, 72, 0, 320, 1, False),
+                                                    (1, 16, 320, 0, 128, 1, True)]:
+            x1 = to_nhwc(rnd((B, C1, H, H), dtype, 1)).cuda()
+            x2 = to_nhwc(rnd((B, C2, H, H), dtype, 2)).cuda() if C2 else None
+            wt = rnd((Cout, C1 + C2, 3, 3), dtype, 3, (9 * (C1 + C2)) ** -0.5)
+            w_k, wflag = ops.pack_conv_weight(wt, chunk)
+            x, y = both(lambda: ops.conv3x3(x1, w_k.cuda(), B, H, H, x2=x2, stride=stride, flags=wflag)[0])
+            assert torch.equal(x, y), (B, H, C1, C2, Cout, stride)
+        B, H, C1, C3 = 2, 8, 1280, 1280
+        x1, x3 = to_nhwc(rnd((B, C1, H, H), dtype, 1)).cuda(), to_nhwc(rnd((B, C3, H, H), dtype, 2)).cuda()
+        w2 = torch.cat([ops.pack_conv_weight(rnd((C1, C1, 3, 3), dtype, 3, (9 * C1) ** -0.5), True)[0].reshape(C1, -1), rnd((C1, C3), dtype, 4, C3 ** -0.5)], 1).contiguous().cuda()
+        x, y = both(lambda: ops.conv3x3_shortcut(x1, w2, B, H, H, x3))
+        assert torch.equal(x, y)
+    finally:
+        deep(old_d); tune(old_t)
