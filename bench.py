@@ -227,7 +227,13 @@ def main():
             break
     if sampler is not None:
         sampler.__exit__()
+    per_rank_ms = None
     if use_dist:
+        # every rank's own clock over the K timed steps (barrier to barrier), so that the first real SCALE file explains itself: the line's value is the MAX
+        tr = torch.zeros(world, device=dev, dtype=torch.float64)
+        tr[rank] = elapsed / args.steps * 1e3
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(v), 3) for v in tr.tolist()]
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -333,6 +339,10 @@ def main():
         }
         if collectives is not None:
             line['collectives'] = collectives
+        if per_rank_ms is not None:
+            line['per_rank'] = dict(ms_per_step=per_rank_ms, views=[list(partition_views(V, world, r)) for r in range(world)] if shards else None,
+                                    note='each rank\'s own wall clock per timed step (barrier to barrier; the step ends with the all-gather, so ranks agree to '
+                                         'the skew of its completion); `ms_per_step` of the line is the max')
         if sampler is not None and sampler.summary() is not None:
             line['power'] = sampler.summary()
             # energy per unit of algorithmic work over the sampled (untimed) steps: what a kernel change has to lower when the package sits at its

@@ -125,3 +125,79 @@ def test_sync_scene_gloo():
     from mvedit_amd.parallel import sync_scene
     t = [torch.ones(3)]
     assert sync_scene(t) is t                                                          # no process group: a no-op
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# One whole sharded OUTER step on a stand-in engine: partition -> per-rank noise prediction -> the one all-gather ->
+# replicated 3D update -> scene re-sync -> camera pruning 32 -> 16 -> 9 -> repartition, for three outer steps, against the 1-rank run.
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+def _stub_noise_pred(latents, t):
+    """Per-view function of the view's own latent and the timestep (like get_noise_pred: views are independent, adapter3d_mixin.py:77-129)."""
+    return torch.tanh(latents * 0.7 + 0.01 * t) - 0.1 * latents.mean(dim=(1, 2, 3), keepdim=True)
+
+
+def _stub_render(scene, view_ids):
+    """Per-view 'rendered maps' from the replicated scene (8 channels, as the design's RGBD + normal payload)."""
+    base = scene['table'][:64].reshape(8, 4, 4)
+    return torch.stack([base * (1.0 + 0.01 * int(v)) + scene['mlp'].sum() for v in view_ids])
+
+
+def _outer_loop(world, rank, use_dist):
+    from mvedit_amd.parallel import sync_scene
+    g = torch.Generator().manual_seed(0)
+    V = 32
+    latents_all = torch.randn(V, 4, 8, 8, generator=g)
+    scene = dict(table=torch.randn(256, 2, generator=g), mlp=torch.randn(8, 8, generator=g))
+    view_ids = list(range(V))
+    lo, hi = partition_views(V, world, rank)
+    mine = latents_all[lo:hi].clone()
+    log = []
+    for step, (t, keep_n) in enumerate([(981, 16), (741, 9), (499, 9)]):
+        Vc = len(view_ids)
+        lo, hi = partition_views(Vc, world, rank)
+        assert mine.shape[0] == hi - lo
+        noise = _stub_noise_pred(mine, t)                                   # sharded: this rank's views only
+        mine = mine - 0.1 * noise                                           # scheduler state stays local
+        maps = _stub_render(scene, view_ids[lo:hi])                         # sharded render of the replicated scene
+        maps_all = all_gather_views(maps, Vc) if use_dist else maps         # THE collective of the step
+        assert maps_all.shape[0] == Vc
+        # replicated 3D update: every rank the same seeded arithmetic over all views' maps; a rank-dependent perturbation stands for the float-atomic
+        # scatter order of the real backward kernels (ranks agree to rounding, not bitwise) ...
+        upd = maps_all.mean(dim=(0, 2, 3))
+        scene['table'] = scene['table'] + 0.01 * upd.sum() + (1e-7 * rank if use_dist else 0.0)
+        scene['mlp'] = scene['mlp'] * 0.99 + 0.001 * upd[:8].reshape(8, 1)
+        # ... which the one broadcast per outer step removes (DESIGN.md section 6: the second, stated collective)
+        if use_dist:
+            sync_scene([scene['table'], scene['mlp']], src=0)
+        # camera pruning (mvedit_3d_pipeline.py:1180-1215): keep the keep_n views with the largest map energy, view 0 always
+        if keep_n < Vc:
+            score = maps_all.flatten(1).norm(dim=1)
+            score[0] = float('inf')
+            keep = sorted(score.topk(keep_n).indices.tolist())
+            mine = repartition(mine, Vc, keep) if use_dist else mine[keep]
+            view_ids = [view_ids[k] for k in keep]
+        log.append((list(view_ids), scene['table'].clone(), scene['mlp'].clone()))
+    lo, hi = partition_views(len(view_ids), world, rank)
+    return log, mine, (lo, hi)
+
+
+def _outer_worker(rank, world, port, ref_path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ref_log, ref_latents = torch.load(ref_path)
+        log, mine, (lo, hi) = _outer_loop(world, rank, True)
+        for (ids, table, mlp), (rids, rtable, rmlp) in zip(log, ref_log):
+            assert ids == rids, (rank, ids, rids)                            # the same cameras survive on every rank
+            assert torch.equal(table, rtable) and torch.equal(mlp, rmlp), rank  # rank 0's scene everywhere == the 1-rank run's scene
+        assert torch.equal(mine, ref_latents[lo:hi]), rank                   # this rank's latents == its block of the 1-rank run's
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_sharded_outer_steps_equal_the_one_rank_run(world, tmp_path):
+    ref_log, ref_latents, _ = _outer_loop(1, 0, False)
+    path = str(tmp_path / 'ref.pt')
+    torch.save((ref_log, ref_latents), path)
+    mp.spawn(_outer_worker, args=(world, _free_port(), path), nprocs=world, join=True)
