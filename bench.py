@@ -65,7 +65,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, dtype=torch.float16, latent_hw=(LATENT, LATENT), B=1, n_img=1, repeats=3, x=None, ctx=None, t=499):
+def cpu_baseline(cfg, dtype=torch.float16, latent_hw=(LATENT, LATENT), B=1, n_img=1, repeats=3, x=None, ctx=None, t=499, zero123pp_passes=None):
     """Oracle (kind "port") on the host cores: a forward of B images, fp32 arithmetic over the engine's (16-bit rounded) weights.
     Returns the baseline record and (x, ctx, out) so that the same forward can be compared with the HIP engine (the oracle as checker).
     The ONLY function of this file that touches oracle/ (tests/test_abi.py).  x / ctx given: those rows (the headline passes rows of the TIMED
@@ -76,6 +76,16 @@ def cpu_baseline(cfg, dtype=torch.float16, latent_hw=(LATENT, LATENT), B=1, n_im
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     sd = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=1234).items()}
+    if zero123pp_passes is not None:
+        # checker leg of BASELINE config 2: the two passes of a Zero123++ denoise step exactly as tools/bench_parts.make_passes builds them -- the condition
+        # latent writes the reference keys / values, the tiled views read them, the CFG-first item exempt (zero123plus.py:43-77, :107-150)
+        (cond, t2, cctx, _, _), (xx, _, _, _, _) = zero123pp_passes
+        f = lambda a: a.detach().float().cpu()
+        d = {}
+        with torch.no_grad():
+            U.unet_forward(sd, cfg, f(cond), f(t2), f(cctx), attn_opts=dict(mode='w', ref_dict=d, ref_skip=1))
+            out = U.unet_forward(sd, cfg, f(xx), f(t2), f(cctx), attn_opts=dict(mode='r', ref_dict=d, ref_skip=1))
+        return None, ('zero123pp', None, out)
     if x is None:
         g = torch.Generator().manual_seed(0)
         x = torch.randn(B, 4, *latent_hw, generator=g).to(dtype).float()
@@ -427,6 +437,9 @@ def main():
                             ref = cpu_baseline(dict(SD15_CONFIG), dt2, (LATENT, LATENT), repeats=1)[1] + (1,)
                         elif wl2 == 'use_reference':
                             ref = cpu_baseline(dict(SD15_CONFIG), dt2, (LATENT, LATENT), B=2, n_img=2, repeats=1)[1] + (2,)
+                        elif wl2 == 'zero123pp':
+                            zp = make_passes('zero123pp', dict(SD21_CONFIG), 6, 0, 6, 6, 1, dev, dt2)[0]
+                            ref = cpu_baseline(dict(SD21_CONFIG), dt2, zero123pp_passes=zp)[1] + (1,)
                     extras.append(measure_workload(dev, wl2, dt2, pair2, parity_ref=ref))
                 except Exception as e:
                     extras.append({'workload': wl2, 'error': repr(e)[:300]})

@@ -643,7 +643,11 @@ int launch_red(int dtype, int mode, const GemmParams& p, hipStream_t s) {
 // MVE_OK after a launch, 1 when neither loop takes the problem (the caller falls back to the 128-row kernel), < 0 on error
 int launch_tile256(int dtype, int mode, const GemmParams* q, hipStream_t s) {
     const int pp2 = gemm_pp2_mode();
-    if (gemm_pp_on() && mode == 0 && q->splitk <= 1 && q->splitk_seq <= 1 && ((pp2 == 1 && q->tile_n == 0) || (pp2 == 2 && q->tile_n == 160))) {
+    // (round 6) in the default mode also the chip-filling launches WITHOUT a GEGLU epilogue: attn1.qkv / attn2.to_q at every level run 8-16 % faster on
+    // two 256 x 160 blocks per CU than on one 256 x 320 block (the epilogue of one block under the K loop of the other; K = C is 10-40 steps), the
+    // GEGLU launches 6-7 % slower at the 32 x 32 level (profiles/r06_oplist64_pp2_ab.txt) -- residual / pair launches are not eligible for this tile
+    if (gemm_pp_on() && mode == 0 && q->splitk <= 1 && q->splitk_seq <= 1 &&
+        ((pp2 == 1 && q->tile_n == 0) || (pp2 == 2 && (q->tile_n == 160 || (q->tile_n == 0 && !q->geglu))))) {
         GemmParams r = *q;
         r.tile_n = 161;
         const int rc = mve_gemm_pp_launch(dtype, mode, &r, s);

@@ -357,7 +357,18 @@ def measure_workload(dev, wl, dtype, residual_pair, steps=3, warmup=1, parity_re
                roofline=dict(bound='mfma', kernel='k_gemm_pp (conv3x3 + linear)' if dom == 'gemm' else 'k_attention3 / k_attention2', achieved=round(ach, 1),
                              peak=PEAK_TFLOPS_F16, unit='TFLOP/s', frac=round(ach / PEAK_TFLOPS_F16, 4),
                              per_class_ms={k: round(v, 3) for k, v in cls_ms.items()}))
-    if parity_ref is not None:
+    if parity_ref is not None and isinstance(parity_ref[0], str) and parity_ref[0] == 'zero123pp':
+        try:            # the step's own two passes (condition pass writes the reference keys / values, the tiled-view pass reads them) against the oracle's
+            out = None
+            for (x_, t_, c_, n_, kw_) in passes:
+                eng._set_attention(kw_, x_.shape[0], x_.shape[2], x_.shape[3])
+                out = eng._run(0, x_, t_, c_, n_, None, None, None)
+            got, bout = out.float().cpu(), parity_ref[2]
+            rec['parity'] = dict(rel_l2_vs_fp32_oracle=round(float((got - bout).norm() / bout.norm()), 6), shape=list(got.shape), north_star_bar=1e-3,
+                                 note='the tiled-view pass of the timed step (reference-only attention over the condition pass\'s keys / values) vs fp32 oracle arithmetic')
+        except Exception as e:
+            rec['parity'] = {'error': repr(e)[:200]}
+    elif parity_ref is not None:
         try:
             bx, bctx, bout, n_img = parity_ref
             eng._set_attention(dict(num_cross_attn_imgs=n_img) if n_img > 1 else None, bx.shape[0], bx.shape[2], bx.shape[3])
