@@ -103,9 +103,25 @@ struct BF16Tag {
 // 16-bit low half, 1.23e-3 without one) at half the low half's HBM traffic.  The scale keeps the remainder of any |v| >= 2^-11 out of E5M2's
 // subnormals.  Four elements per dword, element e in byte e.
 // ---------------------------------------------------------------------------
+// Range: E5M2's largest finite value is 57344.  fp16 streams cannot reach it (the scaled remainder of the largest fp16 step is
+// 2^12); a bf16 stream value of magnitude >= 2^16 has a remainder of up to 2^(e-8) and would overflow -- the scaled remainder is clamped to the
+// format's range (the pair then reconstructs hi plus a saturated correction: never worse than hi alone), and a NaN remainder (hi non-finite)
+// becomes 0 so that the pair reconstructs hi.
+__device__ __forceinline__ float mve_lo8_scaled(float r) {
+    const float s = __builtin_amdgcn_fmed3f(r * 256.f, -57344.f, 57344.f);
+    return s == s ? s : 0.f;
+}
+// CLAMP = false (fp16 streams): the plain scale -- the instruction stream of round 5, bit for bit
+template <bool CLAMP = false>
 __device__ __forceinline__ unsigned mve_lo8_pack4(float a, float b, float c, float d) {
-    int p = __builtin_amdgcn_cvt_pk_bf8_f32(a * 256.f, b * 256.f, 0, false);
-    p = __builtin_amdgcn_cvt_pk_bf8_f32(c * 256.f, d * 256.f, p, true);
+    int p;
+    if constexpr (CLAMP) {
+        p = __builtin_amdgcn_cvt_pk_bf8_f32(mve_lo8_scaled(a), mve_lo8_scaled(b), 0, false);
+        p = __builtin_amdgcn_cvt_pk_bf8_f32(mve_lo8_scaled(c), mve_lo8_scaled(d), p, true);
+    } else {
+        p = __builtin_amdgcn_cvt_pk_bf8_f32(a * 256.f, b * 256.f, 0, false);
+        p = __builtin_amdgcn_cvt_pk_bf8_f32(c * 256.f, d * 256.f, p, true);
+    }
     return (unsigned)p;
 }
 __device__ __forceinline__ void mve_lo8_unpack4(unsigned p, float (&o)[4]) {
@@ -128,7 +144,8 @@ __device__ __forceinline__ u32x2 mve_pair_split8(const float (&v)[8], typename T
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { hi[e] = Tag::from_f32(v[e]); r[e] = v[e] - Tag::to_f32(hi[e]); }
-    return u32x2{mve_lo8_pack4(r[0], r[1], r[2], r[3]), mve_lo8_pack4(r[4], r[5], r[6], r[7])};
+    constexpr bool CL = Tag::dtype == MVE_BF16;      // only a bf16 remainder can leave E5M2's range
+    return u32x2{mve_lo8_pack4<CL>(r[0], r[1], r[2], r[3]), mve_lo8_pack4<CL>(r[4], r[5], r[6], r[7])};
 }
 
 // dispatch a templated launcher on the runtime dtype code

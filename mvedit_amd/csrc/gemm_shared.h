@@ -169,7 +169,8 @@ __device__ __forceinline__ void gemm_epilogue_tail(const GemmParams& p, int m, i
             float r[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) r[e] = v[e] - Tag::to_f32(pk[e]);
-            const u32x2 pl = {mve_lo8_pack4(r[0], r[1], r[2], r[3]), mve_lo8_pack4(r[4], r[5], r[6], r[7])};
+            constexpr bool CL = Tag::dtype == MVE_BF16;
+            const u32x2 pl = {mve_lo8_pack4<CL>(r[0], r[1], r[2], r[3]), mve_lo8_pack4<CL>(r[4], r[5], r[6], r[7])};
             if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.out_lo) + orow + n) = pl;
         }
     }

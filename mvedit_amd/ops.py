@@ -41,7 +41,10 @@ def split_pair(x32, dtype):
     """fp32 tensor -> (hi, lo8): hi = x rounded to `dtype`, lo8 = E5M2(2^8 (x - hi)) as uint8 -- the stream-pair format of the *_pair entry
     points (include/mvedit_amd.h); torch.float8_e5m2 rounds to nearest even like v_cvt_pk_bf8_f32."""
     hi = x32.to(dtype)
-    lo = ((x32.float() - hi.float()) * 256.0).to(torch.float8_e5m2).view(torch.uint8)
+    # clamped to E5M2's finite range and NaN -> 0 like the device packer (common.h: mve_lo8_scaled); gfx950's bf8 is the OCP E5M2 torch.float8_e5m2
+    # holds -- on gfx942 the hardware format is FNUZ and these host helpers would not match the device
+    r = torch.nan_to_num(((x32.float() - hi.float()) * 256.0), nan=0.0).clamp(-57344.0, 57344.0)
+    lo = r.to(torch.float8_e5m2).view(torch.uint8)
     return hi, lo
 
 

@@ -121,7 +121,7 @@ class Adapter3DMixin:
         nets = getattr(cn, 'nets', [cn] if cn is not None else [])
         return len(nets) > 0 and all(getattr(n, 'shares_cond', False) for n in nets)
 
-    detect_repeated_cond = True      # one device comparison + host read per fused call (see _cat_shared_cond); False: object identity only
+    detect_repeated_cond = True      # one device comparison + host read per distinct control tensor (cached, see _cat_shared_cond); False: object identity only
 
     @staticmethod
     def _as_one_tensor(bs):
@@ -136,7 +136,14 @@ class Adapter3DMixin:
                 return None
             off += b.numel()
             total += b.shape[0]
-        return torch.as_strided(b0, (total,) + tuple(b0.shape[1:]), b0.stride(), b0.storage_offset())
+        # canonical contiguous strides from the shape, NOT b0.stride(): torch calls a tensor contiguous whatever the stride of a size-1 leading
+        # dimension, so a one-item chunk may carry any stride(0)
+        strides, acc = [], 1
+        for d in reversed(b0.shape[1:]):
+            strides.append(acc)
+            acc *= int(d)
+        strides = (acc,) + tuple(reversed(strides))
+        return torch.as_strided(b0, (total,) + tuple(b0.shape[1:]), strides, b0.storage_offset())
 
     def _cat_shared_cond(self, bs):
         """Fused conditioning batch of the ControlNets.  The reference builds the CFG halves of the control images from the same data, in two forms:
@@ -157,9 +164,16 @@ class Adapter3DMixin:
             full = self._as_one_tensor(bs)
             if full is not None and full.shape[0] >= 2 and full.shape[0] % 2 == 0:
                 h = full.shape[0] // 2
-                if torch.equal(full[:h], full[h:]):
-                    return full[:h]
-                return full
+                # the verdict is cached per (storage, version, geometry): control images are constant over a denoise loop, so the device
+                # comparison and its host read happen once per loop, not once per step (the read stalled launch-ahead)
+                key = (full.untyped_storage().data_ptr(), full._version, full.storage_offset(), tuple(full.shape), full.dtype)
+                cache = self.__dict__.setdefault('_repeated_cond_cache', {})
+                same = cache.get(key)
+                if same is None:
+                    if len(cache) > 64:
+                        cache.clear()
+                    same = cache[key] = bool(torch.equal(full[:h], full[h:]))
+                return full[:h] if same else full
         return torch.cat(bs, dim=0)
 
     def _sub_controlnet(self, nets):

@@ -99,7 +99,7 @@ class TriPlaneDecoder:
             if name in self._NAMES:
                 key, transpose = self._NAMES[name]
                 t = t.detach()
-                self.w[key] = t.t().contiguous() if transpose else t.clone()
+                self.w[key] = t.t().clone(memory_format=torch.contiguous_format) if transpose else t.clone()      # (.t().contiguous() aliases a [1, N] weight)
             elif name == 'encoder.params':
                 self.w['table'] = t.detach().reshape(-1, 2).clone()
 

@@ -81,11 +81,12 @@ class UNet2DConditionEngine:
             self._h = None
 
     def set_residual_pair(self, flag=True):
-        """Carry the residual stream (x + f(x) of ResnetBlock2D / BasicTransformerBlock / Transformer2DModel) as an unrounded (hi, lo) pair of 16-bit
-        tensors instead of rounding it after every block as the reference's half modules do (mve_unet_set_residual_mode): the end-to-end error
-        against fp32 arithmetic falls below north_star's 1e-3 (1.23e-3 without) for 4 more bytes per stream element and pass.  ON by default for
-        the UNet since round 5 (the native handle is created in this mode; MVE_RESIDUAL_PAIR=0 in the environment or set_residual_pair(False)
-        give the reference's rounding points); a ControlNetEngine keeps the 16-bit stream unless asked.  Returns the previous setting."""
+        """Carry the residual stream (x + f(x) of ResnetBlock2D / BasicTransformerBlock / Transformer2DModel) as an unrounded pair -- the 16-bit tensor
+        every matrix-core operand read sees plus an 8-bit E5M2 remainder (lo8, csrc/common.h) -- instead of rounding it after every block as the
+        reference's half modules do (mve_unet_set_residual_mode): the end-to-end error against fp32 arithmetic falls below north_star's 1e-3
+        (1.23e-3 without) for 1 more byte per stream element written and read.  ON by default for the UNet since round 5 (the native handle is
+        created in this mode; MVE_RESIDUAL_PAIR=0 in the environment -- read by UNet handles only -- or set_residual_pair(False) give the reference's
+        rounding points); a ControlNetEngine keeps the 16-bit stream unless its own set_residual_pair(True) is called.  Returns the previous setting."""
         return bool(_lib.raw('mve_unet_set_residual_mode')(self._h, int(bool(flag))))
 
     @property

@@ -627,3 +627,28 @@ def test_oracle_blocks_against_torch_modules():
         ref = nn.functional.conv2d(hcl.reshape(2, 8, 8, C).permute(0, 3, 1, 2), sd[p + '.proj_out.weight'], sd[p + '.proj_out.bias']) + x
         got = U._transformer(c, p, x, ctx, heads, 1, 1)
         assert (got - ref).abs().max() < 2e-4 * ref.abs().max()
+
+
+@pytest.mark.gpu
+def test_plain_stream_mode_is_the_reference_parity_anchor(lib):
+    """the engine's default mode departs from the reference's half-precision rounding points on purpose (the residual stream is not
+    rounded after every block); `set_residual_pair(False)` / MVE_RESIDUAL_PAIR=0 is the mode that reproduces them.  One test keeps that mode pinned to
+    the oracle that emulates PyTorch's half modules op by op (q = quantizer): it must sit closer to that emulation than the default mode does, and
+    within the bound the per-kernel tests allow."""
+    from mvedit_amd.unet import UNet2DConditionEngine
+    cfg, dtype, B, S = U.SMALL if hasattr(U, 'SMALL') else U.TINY, torch.float16, 2, 16
+    sd_q = {k: v.to(dtype).float() for k, v in U.make_state_dict(cfg, seed=1234).items()}
+    x, ctx = inputs(cfg, B, S, seed=4)
+    x, ctx = x.to(dtype).float(), ctx.to(dtype).float()
+    with torch.no_grad():
+        ref16 = U.unet_forward(sd_q, cfg, x, 499, ctx, q=U.quantizer(dtype))
+        ref32 = U.unet_forward(sd_q, cfg, x, 499, ctx)
+    eng = UNet2DConditionEngine.from_state_dict(sd_q, cfg, dtype)
+    assert eng.residual_pair
+    pair = eng(x.to(dtype).cuda(), 499, ctx.to(dtype).cuda())[0]
+    eng.set_residual_pair(False)
+    plain = eng(x.to(dtype).cuda(), 499, ctx.to(dtype).cuda())[0]
+    d_plain, d_pair = _rel(plain, ref16)[0], _rel(pair, ref16)[0]
+    print(f'vs the half-emulating oracle: plain stream {d_plain:.2e}, default (pair) mode {d_pair:.2e};  vs fp32: plain {_rel(plain, ref32)[0]:.2e}, pair {_rel(pair, ref32)[0]:.2e}')
+    assert d_plain <= 3e-3
+    assert _rel(pair, ref32)[0] <= _rel(plain, ref32)[0] * 1.02 + 1e-5       # what the default mode buys: closer to fp32

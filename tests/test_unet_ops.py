@@ -996,3 +996,24 @@ def test_norms_read_the_residual_pair(lib, dtype):
     e_pair, e_plain = float((ln(lo) - ref).norm() / ref.norm()), float((plain - ref).norm() / ref.norm())
     print(f'{dtype}: LayerNorm rel-L2 vs fp64 of the unrounded input: pair {e_pair:.2e}, hi alone {e_plain:.2e}')
     assert e_pair <= e_plain * 1.02
+
+
+@pytest.mark.gpu
+def test_lo8_saturates_instead_of_overflowing_on_large_bf16_values(lib):
+    """a bf16 stream value of magnitude >= 2^16 has a rounding remainder above E5M2's 57344 / 2^8; the packer clamps the scaled
+    remainder (and zeroes a NaN one), so hi + lo8 stays finite and never lands further from the value than hi alone.  fp16 cannot reach the range."""
+    from mvedit_amd import ops
+    dtype = torch.bfloat16
+    M, N, K = 256, 320, 64
+    a = rnd((M, K), dtype, 1)
+    w = rnd((N, K), dtype, 2, 3.0e5)                  # outputs of magnitude ~2e6 >> 2^16
+    ref = a.double() @ w.double().t()
+    hi, lo = ops.gemm(a.cuda(), w.cuda(), pair_out=True)
+    got = hi.double().cpu() + _lo(lo)
+    assert torch.isfinite(got).all() and float(ref.abs().max()) > 2.0 ** 18
+    e_pair, e_hi = (got - ref).abs(), (hi.double().cpu() - ref).abs()
+    assert bool((e_pair <= e_hi * (1 + 1e-6) + 1e-3).all()), 'the pair is never worse than its high half'
+    assert float(e_pair.mean()) < float(e_hi.mean())
+    # host-side converter: same clamp
+    h2, l2 = ops.split_pair(ref.float(), dtype)
+    assert torch.isfinite(ops.lo8_to_float(l2)).all()
