@@ -283,6 +283,20 @@ MVE_API int mve_gemm_pair(int dtype, const void* d_A, int lda, const void* d_W, 
                           int M, int N, int K, const float* d_bias, const float* d_rowvec, int ldrv, int rows_per_vec,
                           const void* d_residual, int ldr, int flags, float out_scale, void* d_workspace,
                           size_t workspace_bytes, int rows_per_image, const void* d_residual_lo, void* d_out_lo, void* stream);
+
+/* mve_gemm_pair (no per-image row vector, no GEGLU, unit scale) followed by LayerNorm of the output rows over the N columns:
+ *   d_ln_out[m][:] = LayerNorm(row m of the output as a consumer reads it back: hi + lo8 when d_out_lo is given) * gamma + beta   (eps inside the sqrt).
+ * Where the launch runs on the 320-wide pair tile (N = 320, M a multiple of 256, bias, no K slices: the residual-stream GEMMs of the 64 x 64 level
+ * from 16 images up) the tile that produces a row normalises it in its epilogue -- the row never returns from HBM for its LayerNorm; every other
+ * launch is followed by the LayerNorm kernel.  One row arithmetic for both (csrc/ln_core.h): bit-identical results, so the choice may follow the
+ * launch geometry.  BasicTransformerBlock norm1 / norm2 / norm3 behind Transformer2DModel.proj_in / attn1.to_out / attn2.to_out (diffusers 0.27.2 as
+ * driven from lib/models/architecture/diffusers.py:69-97).  MVE_GEMM_LN_FUSE=0 / mve_gemm_ln_fuse_tune(0): always the separate kernel. */
+MVE_API int mve_gemm_pair_ln(int dtype, const void* d_A, int lda, const void* d_W, int ldw, void* d_out, int ldc, int M, int N, int K,
+                             const float* d_bias, const void* d_residual, int ldr, void* d_workspace, size_t workspace_bytes, int rows_per_image,
+                             const void* d_residual_lo, void* d_out_lo, void* d_ln_out, int ld_ln, const float* d_ln_gamma, const float* d_ln_beta,
+                             float ln_eps, void* stream);
+MVE_API int mve_gemm_ln_fuse_tune(int on);
+
 MVE_API int mve_conv3x3_pair(int dtype, const void* x1, int C1, const void* x2, int C2, int B, int Hs, int Ws, int stride,
                              int upsample, const void* W, int Cout, void* out, int ldc, const float* bias, const float* rowvec,
                              int ldrv, const void* residual, int ldr, int flags, float out_scale, void* d_workspace,

@@ -13,6 +13,8 @@ int mve_gemm(int, const void*, int, const void*, int, void*, int, int, int, int,
              const void*, int, int, float, void*, size_t, int, void*);
 int mve_gemm_pair(int, const void*, int, const void*, int, void*, int, int, int, int, const float*, const float*, int, int,
                   const void*, int, int, float, void*, size_t, int, const void*, void*, void*);
+int mve_gemm_pair_ln(int, const void*, int, const void*, int, void*, int, int, int, int, const float*, const void*, int, void*, size_t, int,
+                     const void*, void*, void*, int, const float*, const float*, float, void*);
 int mve_conv3x3_pair(int, const void*, int, const void*, int, int, int, int, int, int, const void*, int, void*, int,
                      const float*, const float*, int, const void*, int, int, float, void*, size_t, const void*, void*, void*);
 int mve_conv3x3_shortcut_pair(int, const void*, int, const void*, int, const void*, int, int, int, int, const void*, int, void*, int,

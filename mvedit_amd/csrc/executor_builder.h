@@ -80,6 +80,23 @@ struct Builder {
         });
         rel(sk);
     }
+    // GEMM whose output rows go straight into a LayerNorm (BasicTransformerBlock norm1 / norm2 / norm3 behind proj_in / attn1.to_out / attn2.to_out):
+    // mve_gemm_pair_ln normalises the rows in the producing tile's epilogue where the launch allows (N = 320 on the pair tile) and runs the LayerNorm
+    // kernel behind the GEMM otherwise -- bit-identical either way, so the op list does not depend on the batch.  Counted as one linear op.
+    void gemm_ln(Ref A, int lda, Ref W, int ldw, Ref out, int ldc, int M, int N, int K, Ref bias, Ref res, int ldr, Ref ln_out, Ref ln_g, Ref ln_b,
+                 const char* what) {
+        const int rimg = rows_img;
+        const int d = dt;
+        live(A, what); live(out, what); live(res, what); live(ln_out, what);
+        const size_t skb = mve_gemm_workspace_bytes(M, N, K, rimg);
+        Ref sk = skb ? ws(skb) : Ref();
+        const Ref res_lo = lo(res), out_lo = lo(out);
+        op(OC_LINEAR, 2.0 * M * N * K, what, [=](const Run& r) {
+            return mve_gemm_pair_ln(d, r.p(A), lda, r.p(W), ldw, r.p(out), ldc, M, N, K, (const float*)r.p(bias), r.p(res), ldr, r.p(sk), skb, rimg,
+                                    r.p(res_lo), r.p(out_lo), r.p(ln_out), N, (const float*)r.p(ln_g), (const float*)r.p(ln_b), 1e-5f, r.stream);
+        });
+        rel(sk);
+    }
     void conv(Ref x, int C1, int Bn, int H, int W, int stride, int ups, Ref Wt, int Cout, Ref out, Ref bias, Ref rowvec,
               int ldrv, Ref res, int flags, const char* what) {
         const int d = dt;
@@ -248,13 +265,27 @@ struct Builder {
         Ref n0 = ws((size_t)M * C * e);
         gn(x, C, Ref(), 0, B, H * W, 1e-6f, wt(name + ".norm.g"), wt(name + ".norm.b"), 0, n0, "transformer.norm");
         Ref h = ws_stream((size_t)M * C * e);
-        gemm(n0, C, wt(name + ".proj_in.w"), C, h, C, M, C, C, wt(name + ".proj_in.b"), Ref(), 0, 0, Ref(), 0, 0, "transformer.proj_in");
+        // (round 6) a GEMM that writes the residual stream also writes the LayerNorm of its rows (gemm_ln): the row's next reader never fetches it back
+        const bool fuse_ln = layers >= 1;      // (either stream mode: the op list does not depend on it; without a pair the LayerNorm kernel runs behind the GEMM)
+        Ref n1_first;
+        if (fuse_ln) {
+            const std::string b0 = name + ".transformer_blocks.0";
+            n1_first = ws((size_t)M * C * e);
+            gemm_ln(n0, C, wt(name + ".proj_in.w"), C, h, C, M, C, C, wt(name + ".proj_in.b"), Ref(), 0, n1_first, wt(b0 + ".norm1.g"), wt(b0 + ".norm1.b"),
+                    "transformer.proj_in+norm1");
+        } else {
+            gemm(n0, C, wt(name + ".proj_in.w"), C, h, C, M, C, C, wt(name + ".proj_in.b"), Ref(), 0, 0, Ref(), 0, 0, "transformer.proj_in");
+        }
         rel(n0);
         for (int k = 0; k < layers; ++k) {
             const std::string b = name + ".transformer_blocks." + std::to_string(k);
             // self attention
-            Ref n1 = ws((size_t)M * C * e);
-            ln(h, n1, M, C, wt(b + ".norm1.g"), wt(b + ".norm1.b"));
+            Ref n1;
+            if (fuse_ln && k == 0) n1 = n1_first;
+            else {
+                n1 = ws((size_t)M * C * e);
+                ln(h, n1, M, C, wt(b + ".norm1.g"), wt(b + ".norm1.b"));
+            }
             Ref qkv = ws((size_t)M * 3 * C * e);
             gemm(n1, C, wt(b + ".qkv.w"), C, qkv, 3 * C, M, 3 * C, C, Ref(), Ref(), 0, 0, Ref(), 0, 0, "attn1.qkv");
             rel(n1);
@@ -285,11 +316,16 @@ struct Builder {
             }
             rel(qkv);
             Ref h2 = ws_stream((size_t)M * C * e);
-            gemm(a, C, wt(b + ".o1.w"), C, h2, C, M, C, C, wt(b + ".o1.b"), Ref(), 0, 0, h, C, 0, "attn1.to_out+residual");
-            rel(a); rel(h); h = h2;
-            // cross attention (K/V hoisted)
             Ref n2 = ws((size_t)M * C * e);
-            ln(h, n2, M, C, wt(b + ".norm2.g"), wt(b + ".norm2.b"));
+            if (fuse_ln) {
+                gemm_ln(a, C, wt(b + ".o1.w"), C, h2, C, M, C, C, wt(b + ".o1.b"), h, C, n2, wt(b + ".norm2.g"), wt(b + ".norm2.b"), "attn1.to_out+residual+norm2");
+                rel(a); rel(h); h = h2;
+            } else {
+                gemm(a, C, wt(b + ".o1.w"), C, h2, C, M, C, C, wt(b + ".o1.b"), Ref(), 0, 0, h, C, 0, "attn1.to_out+residual");
+                rel(a); rel(h); h = h2;
+                // cross attention (K/V hoisted)
+                ln(h, n2, M, C, wt(b + ".norm2.g"), wt(b + ".norm2.b"));
+            }
             Ref q = ws((size_t)M * C * e);
             gemm(n2, C, wt(b + ".q2.w"), C, q, C, M, C, C, Ref(), Ref(), 0, 0, Ref(), 0, 0, "attn2.to_q");
             rel(n2);
@@ -308,11 +344,16 @@ struct Builder {
             }
             rel(q);
             Ref h3 = ws_stream((size_t)M * C * e);
-            gemm(a2, C, wt(b + ".o2.w"), C, h3, C, M, C, C, wt(b + ".o2.b"), Ref(), 0, 0, h, C, 0, "attn2.to_out+residual");
-            rel(a2); rel(h); h = h3;
-            // feed forward (GEGLU fused in the first GEMM's epilogue)
             Ref n3 = ws((size_t)M * C * e);
-            ln(h, n3, M, C, wt(b + ".norm3.g"), wt(b + ".norm3.b"));
+            if (fuse_ln) {
+                gemm_ln(a2, C, wt(b + ".o2.w"), C, h3, C, M, C, C, wt(b + ".o2.b"), h, C, n3, wt(b + ".norm3.g"), wt(b + ".norm3.b"), "attn2.to_out+residual+norm3");
+                rel(a2); rel(h); h = h3;
+            } else {
+                gemm(a2, C, wt(b + ".o2.w"), C, h3, C, M, C, C, wt(b + ".o2.b"), Ref(), 0, 0, h, C, 0, "attn2.to_out+residual");
+                rel(a2); rel(h); h = h3;
+                // feed forward (GEGLU fused in the first GEMM's epilogue)
+                ln(h, n3, M, C, wt(b + ".norm3.g"), wt(b + ".norm3.b"));
+            }
             Ref f = ws((size_t)M * 4 * C * e);
             gemm(n3, C, wt(b + ".ff1.w"), C, f, 4 * C, M, 8 * C, C, wt(b + ".ff1.b"), Ref(), 0, 0, Ref(), 0, MVE_GEMM_GEGLU, "ff.geglu");
             rel(n3);

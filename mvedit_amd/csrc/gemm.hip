@@ -49,6 +49,9 @@ long long mve_gemm_big_blocks(int M, int N, int splitk);
 int mve_gemm_big_launch(int dtype, int mode, const void* params, void* stream);
 int mve_gemm_pp_launch(int dtype, int mode, const void* params, void* stream);      // gemm_pp.hip; 1 = not eligible
 void mve_gemm_pp_old_swizzle(int on);
+bool mve_gemm_pp_ln_fused();
+void mve_gemm_pp_ln_fuse_tune(int on);
+extern "C" int mve_layernorm_pair(int, const void*, int, void*, int, int, int, const float*, const float*, float, const void*, void*);
 namespace {
 
 // NST: stages of the LDS ring.  2: the two-stage loop of rounds 1-5 (72 KiB at BN = 160: two blocks per CU; tile k + 1 in flight under the MFMAs of
@@ -870,12 +873,52 @@ int mve_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* ou
                          workspace_bytes, rows_per_image, nullptr, nullptr, stream);
 }
 
+static int gemm_pair_impl(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
+                          const float* bias, const float* rowvec, int ldrv, int rows_per_vec, const void* residual, int ldr, int flags,
+                          float out_scale, void* workspace, size_t workspace_bytes, int rows_per_image, const void* residual_lo, void* out_lo,
+                          void* stream, void* ln_out, int ld_ln, const float* ln_gamma, const float* ln_beta, float ln_eps);
+
 int mve_gemm_pair(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
                   const float* bias, const float* rowvec, int ldrv, int rows_per_vec, const void* residual, int ldr, int flags,
                   float out_scale, void* workspace, size_t workspace_bytes, int rows_per_image, const void* residual_lo, void* out_lo,
                   void* stream) {
+    return gemm_pair_impl(dtype, A, lda, W, ldw, out, ldc, M, N, K, bias, rowvec, ldrv, rows_per_vec, residual, ldr, flags, out_scale, workspace,
+                          workspace_bytes, rows_per_image, residual_lo, out_lo, stream, nullptr, 0, nullptr, nullptr, 0.f);
+}
+
+/* mve_gemm_pair followed by LayerNorm of the output rows: d_ln_out[m] = LayerNorm(out[m]) * gamma + beta over the N columns, where out[m] is the row
+ * as a consumer reads it back (hi + lo8 when d_out_lo is given, the 16-bit row otherwise).  Where the launch runs on the 320-wide pair tile
+ * (N = 320, whole 256-row tiles, bias, no K slices: the residual-stream GEMMs of the 64 x 64 level from 16 images up) the tile that produces a row
+ * normalises it in its epilogue -- the row never comes back from HBM for its LayerNorm; every other launch is followed by the LayerNorm kernel.
+ * Same row arithmetic either way (csrc/ln_core.h): bit-identical.  (BasicTransformerBlock: norm1 / norm2 / norm3 behind proj_in / attn1.to_out /
+ * attn2.to_out, diffusers 0.27.2 as driven from lib/models/architecture/diffusers.py:69-97.) */
+int mve_gemm_pair_ln(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
+                     const float* bias, const void* residual, int ldr, void* workspace, size_t workspace_bytes, int rows_per_image,
+                     const void* residual_lo, void* out_lo, void* ln_out, int ld_ln, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                     void* stream) {
+    MVE_CHECK(ln_out && ln_gamma && ln_beta && ld_ln >= N && ld_ln % 8 == 0, MVE_ERR_ARG, "gemm_pair_ln: LayerNorm output / parameters missing or ld_ln (%d) bad", ld_ln);
+    (void)mve_gemm_pp_ln_fused();                 // clear a stale flag
+    const int rc = gemm_pair_impl(dtype, A, lda, W, ldw, out, ldc, M, N, K, bias, nullptr, 0, 0, residual, ldr, 0, 1.0f, workspace, workspace_bytes,
+                                  rows_per_image, residual_lo, out_lo, stream, ln_out, ld_ln, ln_gamma, ln_beta, ln_eps);
+    if (rc != MVE_OK || M == 0) return rc;
+    if (mve_gemm_pp_ln_fused()) return MVE_OK;
+    return mve_layernorm_pair(dtype, out, ldc, ln_out, ld_ln, M, N, ln_gamma, ln_beta, ln_eps, out_lo, stream);
+}
+
+int mve_gemm_ln_fuse_tune(int on) {
+    static int cur = 1;
+    const int old = cur;
+    if (on >= 0) { cur = on ? 1 : 0; mve_gemm_pp_ln_fuse_tune(cur); }
+    return old;
+}
+
+static int gemm_pair_impl(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
+                          const float* bias, const float* rowvec, int ldrv, int rows_per_vec, const void* residual, int ldr, int flags,
+                          float out_scale, void* workspace, size_t workspace_bytes, int rows_per_image, const void* residual_lo, void* out_lo,
+                          void* stream, void* ln_out, int ld_ln, const float* ln_gamma, const float* ln_beta, float ln_eps) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
+    p.ln_out = ln_out; p.ld_ln = ld_ln; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps;
     p.A = A; p.W = W; p.out = out; p.bias = bias; p.rowvec = rowvec; p.residual = residual;
     p.residual_lo = residual_lo; p.out_lo = out_lo;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldrv = ldrv;

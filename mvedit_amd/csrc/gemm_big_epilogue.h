@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "gemm_shared.h"
+#include "ln_core.h"
 
 namespace {
 
@@ -29,7 +30,8 @@ __device__ __forceinline__ void big_lds_fence() {
 // WAVES_N: waves along N (4: 2 x 4 arrangement, wave tile 128 x BN2/4;  2: 4 x 2 arrangement, wave tile 64 x BN2/2)
 // PAIR: the kernel instantiation that serves the executor's residual_pair mode (GemmParams::residual_lo / out_lo).  A separate instantiation, not a
 // run-time branch: with both fast paths in one function hipcc's register allocation of the ordinary one degrades from 1 to ~90 spilled registers.
-template <class Tag, int BN2, int WAVES_N = 4, bool PAIR = false>
+// LNF (PAIR, BN2 = 320, N = 320 only): the fast path also writes LayerNorm(row) to GemmParams::ln_out -- see the LN phase below.
+template <class Tag, int BN2, int WAVES_N = 4, bool PAIR = false, bool LNF = false>
 __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&acc)[BN2 / WAVES_N / 16][256 / (8 / WAVES_N) / 16], unsigned char* smem,
                                                   int m0, int n0, int kslice, int tid, int lane, int wm, int wn) {
     typedef typename Tag::V8 V8;
@@ -190,10 +192,56 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmParams& p, f32x4 (&a
                             *reinterpret_cast<V8*>(outb + (size_t)(pass * 64 + rr_) * p.ldc) = pk;
                             *reinterpret_cast<u32x2*>(outl + (size_t)(pass * 64 + rr_) * p.ldc) = pl;
                         }
+                        if constexpr (LNF) {
+                            // the value the LayerNorm kernel would read back: hi + lo8 (exact in fp32) -- parked where this lane found its accumulators
+                            float x8[8];
+                            mve_pair_load8<Tag>(pk, pl, x8);
+                            if (ok) {
+                                float* xs = Cs + (r0c + rr_) * CS_LD + ch * 8;
+                                *reinterpret_cast<f32x4*>(xs) = f32x4{x8[0], x8[1], x8[2], x8[3]};
+                                *reinterpret_cast<f32x4*>(xs + 4) = f32x4{x8[4], x8[5], x8[6], x8[7]};
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) pk[e] = Tag::from_f32(v[e]);
                         if (ok) *reinterpret_cast<V8*>(outb + (size_t)(pass * 64 + rr_) * p.ldc) = pk;
+                    }
+                }
+                if constexpr (LNF) {
+                    // LN phase of the pass: 64 rows of 320 channels sit in the staging tile as the LayerNorm kernel would load them; wave w normalises
+                    // rows 8 w .. 8 w + 7 with that kernel's row arithmetic (ln_core.h: lane l < 40 holds chunk l) and writes them to ln_out
+                    big_lds_barrier();
+                    const int wv = tid >> 6;
+                    const bool has = lane < BN2 / 8;
+                    const int lc = has ? lane : 0;
+                    T* lnb = reinterpret_cast<T*>(p.ln_out) + (size_t)(m0 + pass * 64 + wv * 8) * p.ld_ln + lc * 8;
+                    constexpr int LNR = 1;
+                    // LNR rows at a time: their reduction trees are independent, so one row's shuffle latency (ds_bpermute) hides behind the others'
+                    // (one row at a time this phase cost as much as the LayerNorm kernel it replaces: profiles/r06_ln_epilogue_ab.log)
+                    const float* g8 = p.ln_gamma + lc * 8;      // (read per row from L1: sixteen more live registers next to the accumulators of the later passes spill)
+                    const float* b8 = p.ln_beta + lc * 8;
+#pragma unroll
+                    for (int r4 = 0; r4 < 8; r4 += LNR) {
+                        float x[LNR][8], sm[LNR], q[LNR];
+#pragma unroll
+                        for (int r = 0; r < LNR; ++r) {
+                            const float* xs = Cs + (wv * 8 + r4 + r) * CS_LD + lc * 8;
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(xs), b = *reinterpret_cast<const f32x4*>(xs + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { x[r][e] = a[e]; x[r][4 + e] = b[e]; }
+                            sm[r] = has ? mve_ln_sum8(x[r], 0.f) : 0.f;
+                        }
+                        mve_ln_wave_sum_n<LNR>(sm);
+#pragma unroll
+                        for (int r = 0; r < LNR; ++r) { sm[r] = sm[r] / (float)BN2; q[r] = has ? mve_ln_sq8(x[r], sm[r], 0.f) : 0.f; }
+                        mve_ln_wave_sum_n<LNR>(q);
+#pragma unroll
+                        for (int r = 0; r < LNR; ++r) {
+                            const float rstd = rsqrtf(q[r] / (float)BN2 + p.ln_eps);
+                            const V8 y = mve_ln_out8<Tag>(x[r], sm[r], rstd, g8, b8);
+                            if (has) *reinterpret_cast<V8*>(lnb + (size_t)(r4 + r) * p.ld_ln) = y;
+                        }
                     }
                 }
                 big_lds_barrier();

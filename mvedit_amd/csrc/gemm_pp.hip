@@ -219,7 +219,7 @@ template <int V> struct PInt { static constexpr int value = V; };
 // NSL: LDS ring slots (prefetch distance NSL - 1).  NSL = 3 (BN2 = 160, dense GEMM only): the tile that lets TWO blocks share a CU -- 128
 // registers, 79 KiB -- so that one block's epilogue (memory-latency bound: residual reads, stores; no MFMA) runs under the other block's
 // K loop and the fragment reads of either hide behind the other's MFMAs; its epilogue is per wave (pp2_epilogue), without block barriers.
-template <class Tag, int MODE, bool SEQ, int BN2, bool PROF = false, int NSL = PNSLOT, bool PAIR = false, bool RED = false>        // MODE 1: slab-major (chunk64) conv only; PAIR: residual_pair epilogue; RED: in-kernel slice reduction (pp_reduce_slices)
+template <class Tag, int MODE, bool SEQ, int BN2, bool PROF = false, int NSL = PNSLOT, bool PAIR = false, bool RED = false, bool LNF = false>        // MODE 1: slab-major (chunk64) conv only; PAIR: residual_pair epilogue; RED: in-kernel slice reduction (gemm_reduce_slices); LNF: LayerNorm of the output rows in the epilogue (big_tile_epilogue)
 __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmParams p) {
     typedef typename Tag::V8 V8;
     // BN2 = 320 | 256: waves 2 (M) x 4 (N), wave tile 128 x {80, 64};  BN2 = 128 (the 128-channel convolutions of the VAE at image
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(PNTH, NSL == 3 ? 4 : 2) void k_gemm_pp(const GemmPa
     pp_barrier();
     pp_mfma_settle();
     if constexpr (NSL == 3) pp2_epilogue<Tag>(p, acc, smem, m0, n0, wid, lane, wm, wn);
-    else big_tile_epilogue<Tag, BN2, WAVES_N, PAIR>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
+    else big_tile_epilogue<Tag, BN2, WAVES_N, PAIR, LNF>(p, acc, smem, m0, n0, kslice, tid, lane, wm, wn);
     if constexpr (RED) gemm_reduce_slices<Tag, BN2, PBM, PNTH>(p, tile, kslice, S, m0, n0, tid);
     if constexpr (PROF) {
         if (g_pp_prof && lane == 0) {
@@ -601,6 +601,15 @@ int pp_bn(const GemmParams& p) { return (p.tile_n == 160 && p.N % 160 == 0) ? 16
 
 unsigned long long* g_pp_prof_host = nullptr;
 
+// set by a launch that normalised its output rows itself (GemmParams::ln_out); read and cleared by mve_gemm_pp_ln_fused()
+thread_local bool g_pp_ln_fused = false;
+int g_pp_ln_fuse = -1;      // MVE_GEMM_LN_FUSE (default 1); 0: never (A/B, tests)
+bool pp_ln_fusable(const GemmParams& p) {
+    if (g_pp_ln_fuse < 0) { const char* e = getenv("MVE_GEMM_LN_FUSE"); g_pp_ln_fuse = e ? atoi(e) : 1; }
+    return g_pp_ln_fuse != 0 && p.N == 320 && p.M % PBM == 0 && p.out_lo && p.bias && p.out_scale == 1.0f && !p.res_after_scale && !p.out_f32 && !p.geglu &&
+           !p.rowvec && p.splitk <= 1 && p.splitk_seq <= 1 && p.orow_extra == 0 && p.tile_n == 0 && !(p.dbg & 2) && p.ln_gamma && p.ln_beta && p.ld_ln % 8 == 0;
+}
+
 template <class Tag, int MODE, bool SEQ, int BN2>
 int launch_pp3(const GemmParams& p, hipStream_t s) {
     if (p.sk_sync && p.splitk > 1) {          // K slices folded inside the launch (the partial tiles leave raw: the plain instantiation's generic epilogue path)
@@ -618,6 +627,23 @@ int launch_pp3(const GemmParams& p, hipStream_t s) {
             return MVE_OK;
         } else {
             return 1;
+        }
+    }
+    if constexpr (!SEQ && BN2 == 320 && MODE == 0) {
+        // LayerNorm of the output rows inside the launch: exactly the configuration big_tile_epilogue's pair fast path takes on EVERY tile of the launch
+        if (p.ln_out && pp_ln_fusable(p)) {
+            static bool configured_ln[64] = {};
+            int dev = 0;
+            MVE_HIP(hipGetDevice(&dev));
+            if (dev >= 0 && dev < 64 && !configured_ln[dev]) {
+                MVE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pp<Tag, 0, false, 320, false, PNSLOT, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pp_smem(320)));
+                configured_ln[dev] = true;
+            }
+            const unsigned grid = (unsigned)(p.M / PBM);
+            k_gemm_pp<Tag, 0, false, 320, false, PNSLOT, true, false, true><<<grid, PNTH, pp_smem(320), s>>>(p);
+            MVE_LAUNCH_CHECK();
+            g_pp_ln_fused = true;
+            return MVE_OK;
         }
     }
     if (p.residual_lo || p.out_lo) {          // residual_pair mode: the 320-wide and (round 5: small batches) 160-wide tiles without the slice fold
@@ -734,6 +760,14 @@ extern "C" MVE_API int mve_gemm_pp_profile(void* buf) {
     MVE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_prof), &g_pp_prof_host, sizeof(g_pp_prof_host)));
     return MVE_OK;
 }
+
+// did the last launch of this thread normalise its output rows itself?  (read once: the flag is cleared)
+bool mve_gemm_pp_ln_fused() {
+    const bool f = g_pp_ln_fused;
+    g_pp_ln_fused = false;
+    return f;
+}
+void mve_gemm_pp_ln_fuse_tune(int on) { g_pp_ln_fuse = on ? 1 : 0; }
 
 // A/B aid: 1 = the ring swizzle of round 2 ((row >> 2) & 3: every fragment read 2-way bank conflicted); results are identical either way
 void mve_gemm_pp_old_swizzle(int on) { g_pp_old_swizzle = on ? 1 : 0; }

@@ -83,6 +83,15 @@ struct GemmParams {
     // the smaller operand (few rows: the deep UNet levels, small batches), where re-fetching all of W into eight L2s over the fabric is what
     // bounds the launch (profiles/r06_ab_deep_ring_null.log: 118-236 MB of weight re-reads per 8-image conv).  Pure index remap: identical bits.
     int w_major;
+    // LayerNorm of the produced rows inside the launch (round 6; mve_gemm_pair_ln): ln_out [M][ld_ln] receives LayerNorm(out row) * gamma + beta in the
+    // storage type, computed from the value the stand-alone kernel would read back (hi + lo8 of the row just written) with the shared row arithmetic
+    // of ln_core.h -- bit-identical to mve_layernorm_pair on the output.  Only the 320-wide pair fast path of the ping-pong tile does it (N = 320:
+    // a tile holds whole rows); every other launch leaves ln_out untouched and the caller runs the kernel (gemm.hip: mve_gemm_pair_ln).
+    void* ln_out;
+    const float* ln_gamma;
+    const float* ln_beta;
+    float ln_eps;
+    int ld_ln;
     ConvGeom g;
 };
 

@@ -13,6 +13,7 @@
 // They replace GroupNorm + SiLU inside diffusers' ResnetBlock2D / Transformer2DModel as driven by
 // lib/models/architecture/diffusers.py:86-97,139-156 of the reference.
 #include "common.h"
+#include "ln_core.h"
 
 namespace {
 
@@ -433,38 +434,25 @@ __global__ __launch_bounds__(256) void k_layernorm(const void* __restrict__ x, i
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[i][e] += a[e]; v[i][4 + e] += b[e]; }
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s += v[i][e];
+                s = mve_ln_sum8(v[i], s);
             }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        // (the row arithmetic lives in ln_core.h: the GEMM epilogue that normalises its own output rows shares it, bit for bit)
+        s = mve_ln_wave_sum(s);
         const float mean = s / (float)C;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXC8; ++i) {
             const int c = lane + i * 64;
-            if (c < nchunk) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
-            }
+            if (c < nchunk) q = mve_ln_sq8(v[i], mean, q);
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        q = mve_ln_wave_sum(q);
         const float rstd = rsqrtf(q / (float)C + eps);
         T* yr = reinterpret_cast<T*>(y) + (size_t)row * ldy;
 #pragma unroll
         for (int i = 0; i < MAXC8; ++i) {
             const int c = lane + i * 64;
-            if (c < nchunk) {
-                V8 pk;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ch = c * 8 + e;
-                    pk[e] = Tag::from_f32((v[i][e] - mean) * rstd * gamma[ch] + beta[ch]);
-                }
-                *reinterpret_cast<V8*>(yr + c * 8) = pk;
-            }
+            if (c < nchunk) *reinterpret_cast<V8*>(yr + c * 8) = mve_ln_out8<Tag>(v[i], mean, rstd, gamma + c * 8, beta + c * 8);
         }
     }
 }

@@ -93,6 +93,24 @@ def gemm(a, w, bias=None, rowvec=None, rows_per_vec=0, residual=None, flags=0, o
     return out
 
 
+def gemm_ln(a, w, bias, gamma, beta, residual=None, residual_lo=None, pair_out=True, eps=1e-5, rows_per_image=0):
+    """mve_gemm_pair_ln: a [M,K], w [N,K] -> ((out, out_lo) or out, LayerNorm(out rows) * gamma + beta).  The LayerNorm reads the row as a consumer
+    reads it back (hi + lo8 with pair_out); on the 320-wide pair tile it runs in the producing tile's epilogue, else as the kernel behind the GEMM."""
+    _chk16(a, w, residual)
+    _chk_lo8(residual_lo)
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    out_lo = torch.empty(M, N, dtype=torch.uint8, device=a.device) if pair_out else None
+    ln_out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    ws, ws_bytes = _splitk_ws(M, N, K, a.device, rows_per_image)
+    with torch.cuda.device(a.device):
+        _lib.call('mve_gemm_pair_ln', dt(a), _lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(out), out.stride(0), M, N, K, _lib.ptr(bias),
+                  _lib.ptr(residual), residual.stride(0) if residual is not None else 0, _lib.ptr(ws), ws_bytes, int(rows_per_image),
+                  _lib.ptr(residual_lo), _lib.ptr(out_lo), _lib.ptr(ln_out), ln_out.stride(0), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _s(a))
+    return ((out, out_lo) if pair_out else out), ln_out
+
+
 def conv3x3(x1, w, B, H, W, x2=None, stride=1, upsample=False, bias=None, rowvec=None, residual=None, flags=0,
             out_scale=1.0, splitk=True, residual_lo=None, pair_out=False):
     """x1 [B*H*W, C1] (+ x2 [B*H*W, C2]) NHWC, w [Cout,3,3,C1+C2] -> ([B*Ho*Wo, Cout], Ho, Wo).

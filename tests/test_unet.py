@@ -68,7 +68,7 @@ def test_plan_flops_match_oracle_and_survey(lib):
     # oracle count for the same topology (run once on a 64x64 latent in test_oracle_* is slow; closed form here)
     assert abs(total / 1e12 - 0.8033) < 2e-3, total             # 0.803 TFLOP / image
     assert abs(fl['attention'] / 1e12 - 0.12605) < 1e-4
-    assert info['n_ops'] > 300 and info['workspace_bytes'] < 1 << 30
+    assert info['n_ops'] > 270 and info['workspace_bytes'] < 1 << 30          # (round 6: 48 LayerNorms ride with the GEMMs in front of them: 330 -> 282 ops)
     # cross-image pairing doubles self-attention sequence length: 0.926 TFLOP per image (section 8(d))
     info2 = eng.plan(2, 64, 64, 77, num_cross_attn_imgs=2)
     t2 = sum(info2['flops'][k] for k in ('conv3x3', 'linear', 'attention'))
