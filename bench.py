@@ -327,6 +327,9 @@ def main():
                                        '4/9 of that (four 2x2 phase convs over the source, MVE_UPSAMPLE_PHASES=0 restores the 3x3 form): this is the '
                                        'rate on the multiply-adds actually issued'),
                     avg_launch_ms=round(b['ms'] / b['launches'], 4),
+                    note=('since round 6 the durations of the linear launches include the LayerNorm of their output rows (48 per forward: inside the epilogue of the '
+                          '320-wide pair tile at the 64x64 level, as the LayerNorm kernel behind the GEMM elsewhere -- mve_gemm_pair_ln); their flops are not counted: '
+                          '`frac` is the GEMM / conv flops over a duration that now also normalises (round 5 carried those 2.7 ms in the norm class)') if dom == 'gemm' else None,
                     per_class_ms={k: round(v['ms'], 3) for k, v in breakdown.items()},
                     per_class_tflops={k: round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) for k, v in breakdown.items() if v['flops'] > 0})
 
