@@ -50,7 +50,7 @@ int mve_gemm_big_launch(int dtype, int mode, const void* params, void* stream);
 int mve_gemm_pp_launch(int dtype, int mode, const void* params, void* stream);      // gemm_pp.hip; 1 = not eligible
 void mve_gemm_pp_old_swizzle(int on);
 bool mve_gemm_pp_ln_fused();
-void mve_gemm_pp_ln_fuse_tune(int on);
+int mve_gemm_pp_ln_fuse_tune(int on);
 extern "C" int mve_layernorm_pair(int, const void*, int, void*, int, int, int, const float*, const float*, float, const void*, void*);
 namespace {
 
@@ -905,12 +905,7 @@ int mve_gemm_pair_ln(int dtype, const void* A, int lda, const void* W, int ldw, 
     return mve_layernorm_pair(dtype, out, ldc, ln_out, ld_ln, M, N, ln_gamma, ln_beta, ln_eps, out_lo, stream);
 }
 
-int mve_gemm_ln_fuse_tune(int on) {
-    static int cur = 1;
-    const int old = cur;
-    if (on >= 0) { cur = on ? 1 : 0; mve_gemm_pp_ln_fuse_tune(cur); }
-    return old;
-}
+int mve_gemm_ln_fuse_tune(int on) { return mve_gemm_pp_ln_fuse_tune(on); }
 
 static int gemm_pair_impl(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int ldc, int M, int N, int K,
                           const float* bias, const float* rowvec, int ldrv, int rows_per_vec, const void* residual, int ldr, int flags,

@@ -767,7 +767,12 @@ bool mve_gemm_pp_ln_fused() {
     g_pp_ln_fused = false;
     return f;
 }
-void mve_gemm_pp_ln_fuse_tune(int on) { g_pp_ln_fuse = on ? 1 : 0; }
+int mve_gemm_pp_ln_fuse_tune(int on) {       // -> previous setting (the environment default resolved); negative only queries
+    if (g_pp_ln_fuse < 0) { const char* e = getenv("MVE_GEMM_LN_FUSE"); g_pp_ln_fuse = e ? atoi(e) : 1; }
+    const int old = g_pp_ln_fuse != 0;
+    if (on >= 0) g_pp_ln_fuse = on ? 1 : 0;
+    return old;
+}
 
 // A/B aid: 1 = the ring swizzle of round 2 ((row >> 2) & 3: every fragment read 2-way bank conflicted); results are identical either way
 void mve_gemm_pp_old_swizzle(int on) { g_pp_old_swizzle = on ? 1 : 0; }
