@@ -459,7 +459,10 @@ int choose_splitk(int rows_per_image, int N, int K) {
     const int bn = (N % 160 == 0) ? 160 : (N % 128 == 0 ? 128 : (N <= 64 ? 64 : 128));
     const long long t1 = (long long)mve_cdiv(rows_per_image, BM) * mve_cdiv(N, bn);      // tiles of ONE image
     const int nk = (K + BK - 1) / BK;
-    long long s = 64 / t1;
+    // ceil (round 6): an image of 40 tiles (the 30 x 20 level of Zero123++'s 120 x 80 latent: 80 blocks for a CFG pair, each walking K = 11 520 alone --
+    // 271 us per conv, profiles/r06_trace_zero123pp.txt) gets 2 slices instead of 1.  Power-of-two tile counts (every level of a 64 x 64 latent: 64 / 32 /
+    // 16 / 8 tiles) divide 64: their slice counts, and with them every bit of those results, are unchanged.
+    long long s = (64 + t1 - 1) / t1;
     if (s > nk / 8) s = nk / 8;        // at least 8 K tiles (512 k) per slice
     if (s > 16) s = 16;
     return s < 2 ? 1 : (int)s;
@@ -477,6 +480,16 @@ bool gemm_w_major_on() {
         g_w_major = e ? atoi(e) : 1;
     }
     return g_w_major != 0;
+}
+
+// K columns per block from which a launch that fills neither 256-row rule takes the ping-pong 256 x 160 tile anyway; 0 = never.  MVE_GEMM_PP160_MINK.
+int g_pp160_min_k = -1;
+int gemm_pp160_min_k() {
+    if (g_pp160_min_k < 0) {
+        const char* e = getenv("MVE_GEMM_PP160_MINK");
+        g_pp160_min_k = e ? atoi(e) : 1440;      // same-box sweep, profiles/r06_ab_pp160_min_k.log: Zero123++ 22.9 -> 21.4 ms, 8-image forward 12.44 -> 12.18 ms; 640 and below lose again
+    }
+    return g_pp160_min_k;
 }
 
 // The four-stage ring of the 128-row kernel (k_gemm_deep) for launches of at most this many blocks; 0 turns it off.  MVE_GEMM_DEEP / mve_gemm_deep_tune.
@@ -736,6 +749,17 @@ int launch_gemm_split(const GemmParams& p, hipStream_t s) {
             }
             return MVE_OK;
         }
+    }
+    // (round 6) launches too small for either rule above but with a LONG K loop per block: the ping-pong 256 x 160 tile with half the blocks of the
+    // 128-row kernel still wins -- its K step costs ~0.45 us per 32 columns against ~1.6 us per 64 for a 128-row block that runs alone on its CU
+    // (profiles/r06_gemm_lab_ablation.txt), and the fixed costs of a launch stop mattering.  Zero123++'s CFG pair on a 120 x 80 latent lives here
+    // (75-300 blocks of 128 x 160 per conv, K = 2 880 .. 11 520 unsplit or in 2 slices).  Bit-identical like every tile choice.
+    if (gemm_pp_on() && gemm_pp160_min_k() > 0 && p.N % 160 == 0 && p.M >= 128 && p.K / (p.splitk > 1 ? p.splitk : 1) >= gemm_pp160_min_k()) {
+        GemmParams q = p;
+        q.tile_n = 160;
+        const int rc = mve_gemm_pp_launch(Tag::dtype, MODE, &q, s);
+        if (rc < 0) return rc;
+        if (rc == 0) return splitk_reduce_launch<Tag>(p, s);
     }
     return launch_v<Tag, MODE>(p, s);
 }
