@@ -205,3 +205,31 @@ def test_four_stage_ring_of_the_128_row_kernel_is_bit_identical(lib, red, dtype)
         assert torch.equal(x, y)
     finally:
         deep(old_d); tune(old_t)
+
+
+def test_weight_strip_major_block_order_is_a_pure_remap(lib, red):
+    """GemmParams::w_major (launches whose activations are the smaller operand walk the row panels inside a weight strip): same tiles, same slices,
+    another block order -- every bit must agree with the row-panel-major order (mve_gemm_deep_tune bit 30 turns it off), on the 128-row kernel, on
+    the ping-pong tiles, K-sliced and not, with ragged tile counts."""
+    from mvedit_amd import ops, _lib
+    deep, tune = _lib.raw('mve_gemm_deep_tune'), _lib.raw('mve_gemm_tune')
+    old_d, old_t = deep(-1), tune(-1)
+    OFF = 1 << 30
+    dtype = torch.float16
+    try:
+        for word in (old_t, 0):                                   # default dispatch / 128-row kernel only
+            tune(word)
+            for (M, N, K, rpi, fl) in [(512, 1280, 5120, 64, 0), (300, 1280, 1280, 150, 0), (512, 10240, 1280, 0, ops.GEGLU), (1000, 3840, 1280, 0, 0), (64, 1280, 1280, 64, 0)]:
+                a, w = rnd((M, K), dtype, 1).cuda(), rnd((N, K), dtype, 2, K ** -0.5).cuda()
+                bias = rnd((N,), torch.float32, 3).cuda()
+                deep(0); x = ops.gemm(a, w, bias=bias, flags=fl, rows_per_image=rpi)
+                deep(OFF); y = ops.gemm(a, w, bias=bias, flags=fl, rows_per_image=rpi)
+                assert torch.equal(x, y), (word, M, N, K)
+            for (B, H, C1, Cout) in [(8, 8, 1280, 1280), (3, 10, 640, 1280), (2, 16, 1280, 640)]:
+                x1 = to_nhwc(rnd((B, C1, H, H), dtype, 1)).cuda()
+                w_k, wflag = ops.pack_conv_weight(rnd((Cout, C1, 3, 3), dtype, 3, (9 * C1) ** -0.5), True)
+                deep(0); x = ops.conv3x3(x1, w_k.cuda(), B, H, H, flags=wflag)[0]
+                deep(OFF); y = ops.conv3x3(x1, w_k.cuda(), B, H, H, flags=wflag)[0]
+                assert torch.equal(x, y), (word, B, H, C1, Cout)
+    finally:
+        deep(old_d); tune(old_t)
