@@ -482,6 +482,24 @@ bool gemm_w_major_on() {
     return g_w_major != 0;
 }
 
+// Narrower tile for launches of at most gemm_small_bn_max_blocks() 128 x 160 blocks (see launch_v).  MVE_GEMM_SMALL_BN = 0 | 64 | 128, MVE_GEMM_SMALL_BN_MAX.
+int g_small_bn = -1, g_small_bn_max = -1;
+int gemm_small_bn() {
+    if (g_small_bn < 0) {
+        const char* e = getenv("MVE_GEMM_SMALL_BN");
+        g_small_bn = e ? atoi(e) : 64;      // same-box sweep, profiles/r06_ab_small_bn.log: Zero123++ 21.55 -> 20.4 ms, 8-image forward -1 %; 128 is neutral
+        if (g_small_bn != 64 && g_small_bn != 128) g_small_bn = 0;
+    }
+    return g_small_bn;
+}
+int gemm_small_bn_max_blocks() {
+    if (g_small_bn_max < 0) {
+        const char* e = getenv("MVE_GEMM_SMALL_BN_MAX");
+        g_small_bn_max = e ? atoi(e) : 384;
+    }
+    return g_small_bn_max;
+}
+
 // K columns per block from which a launch that fills neither 256-row rule takes the ping-pong 256 x 160 tile anyway; 0 = never.  MVE_GEMM_PP160_MINK.
 int g_pp160_min_k = -1;
 int gemm_pp160_min_k() {
@@ -528,6 +546,12 @@ int launch_v(const GemmParams& p, hipStream_t s) {
     if (p.N % 160 == 0) bn = 160;
     else if (p.N % 128 == 0) bn = 128;
     else if (p.N <= 64) bn = 64;
+    // (round 6) a launch of at most one 128 x 160 block per CU runs its phases back to back (one wave per SIMD: LDS-DMA, fragment reads + MFMAs and
+    // the epilogue add up, profiles/r06_gemm_lab_ablation.txt); narrower tiles put two or more blocks on a CU, whose phases overlap.  gemm_small_bn():
+    // the tile width such launches take when it divides N (0 = keep 160).  Bit-identical like every tile choice.
+    if (bn == 160 && gemm_small_bn() > 0 && p.N % gemm_small_bn() == 0 &&
+        mve_cdiv(p.M, BM) * mve_cdiv(p.N, 160) * (p.splitk > 1 ? p.splitk : 1) <= (unsigned)gemm_small_bn_max_blocks())
+        bn = gemm_small_bn();
     const unsigned tiles_m = mve_cdiv(p.M, BM), tiles_n = mve_cdiv(p.N, bn);
     const unsigned grid = tiles_m * tiles_n * (p.splitk > 1 ? p.splitk : 1);
 #ifdef MVE_GEMM_LAB
