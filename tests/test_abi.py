@@ -189,6 +189,20 @@ def test_effective_splitk_by_batch(lib):
     assert esk(64 * 256, 1280, 9 * 1280, 256) == 1
 
 
+def test_slice_rule_rounds_up_and_keeps_power_of_two_tile_counts(lib):
+    """Round 6: the slice rule is ceil(64 / tiles of one image) (capped by 8 K tiles per slice and 16).  Tile counts that divide 64 -- every level of
+    a 64 x 64 latent, the shapes every pinned result of rounds 1-5 was produced with -- keep their counts; the 30 x 20 level of Zero123++'s 120 x 80
+    latent (600 rows = 5 row tiles x 8 column tiles = 40 tiles) gets 2 slices instead of 1 (a CFG pair ran 80 blocks through K = 11 520 alone)."""
+    ws = lib.raw('mve_gemm_workspace_bytes')
+    slices = lambda rows, N, K: max(1, ws(rows, N, K, rows) // (rows * N * 4))          # workspace = slices x M x N fp32 (0 = unsliced)
+    # 64 x 64 latent: 4096 / 1024 / 256 / 64 rows per image
+    assert [slices(r, n, 9 * n) for r, n in ((4096, 320), (1024, 640), (256, 1280), (64, 1280))] == [1, 2, 4, 8]
+    assert [slices(r, 1280, 1280) for r in (256, 64)] == [2, 2]                         # (K = 1280: at least 8 K tiles per slice)
+    # 120 x 80 latent (Zero123++): 9600 / 2400 / 600 / 150 rows per image
+    assert [slices(r, n, 9 * n) for r, n in ((9600, 320), (2400, 640), (600, 1280), (150, 1280))] == [1, 1, 2, 4]
+    assert ws(2 * 600, 1280, 9 * 1280, 600) == 2 * ws(600, 1280, 9 * 1280, 600)          # a function of the rows PER IMAGE: batch invariant
+
+
 def test_residual_pair_is_a_plan_option(lib):
     """mve_unet_set_residual_mode (plan-time only, no GPU): the pair mode -- the UNet's DEFAULT since round 5 -- doubles the residual-stream tensors
     of the workspace, keeps the op list, round-trips, and is refused by the non-UNet executors; ControlNet handles start with the 16-bit stream."""
