@@ -60,11 +60,15 @@ namespace {
 // ~0.3 us of MFMA work: time_embedding.linear_2, 20 tiles, 26.6 us; the 8 x 8 conv at 8 images, 22 tiles per slice, 40 us).  The ring keeps THREE tiles in
 // flight and never drains: LDS-DMA pieces issued from inline asm (M0 owned by the loop), one `s_waitcnt vmcnt(2 x pieces)` + `s_barrier` per tile.
 // Same tile, MFMA order and epilogue: bit-identical results.
-template <class Tag, int BN, int MODE, int NST>   // MODE 0: dense A, 1: conv3x3 gather
+// BM (round 6): rows of the tile, 128 or 64.  64 x 64 tiles serve launches so small that even 128 x 64 tiles leave CUs with a single block (launch_v):
+// the waves stay 2 x 2, a wave owns 32 rows, the epilogue is ONE 64-row pass written by both wave rows.  Same K order and epilogue arithmetic: same bits.
+template <class Tag, int BN, int MODE, int NST, int BM = 128>   // MODE 0: dense A, 1: conv3x3 gather
 __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned char* smem) {
+    static_assert(BM == 128 || BM == 64, "tile rows");
     constexpr int WN = BN / 2;          // wave sub-tile width
     constexpr int NF = WN / 16;         // W fragments per wave (4 / 5 / 2)
-    constexpr int MF = 4;               // activation fragments per wave (64 rows)
+    constexpr int WM = BM / 2;          // rows of a wave's sub-tile (64 / 32)
+    constexpr int MF = WM / 16;         // activation fragments per wave (4 / 2)
     constexpr int ROWS_PER_PASS = NT / 8;               // 32 rows per load pass
     constexpr int A_PASSES = BM / ROWS_PER_PASS;        // 4
     constexpr int B_PASSES = BN / ROWS_PER_PASS;        // 4 / 5 / 2
@@ -265,7 +269,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned char* sm
         const unsigned char* rl = reinterpret_cast<const unsigned char*>(p.residual_lo);      // lo8: one byte per element (common.h)
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            int m = m0 + wm * WM + i * 16 + (lane & 15);
             m = m < p.M ? m : p.M - 1;
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
@@ -293,7 +297,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned char* sm
             V8 xf[MF], wf[NF];
 #pragma unroll
             for (int i = 0; i < MF; ++i)
-                xf[i] = *reinterpret_cast<const V8*>(As + swz(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+                xf[i] = *reinterpret_cast<const V8*>(As + swz(wm * WM + i * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
             for (int j = 0; j < NF; ++j)
                 wf[j] = *reinterpret_cast<const V8*>(Bs + swz(wn * WN + j * 16 + frow, ks * 4 + fchunk));
@@ -355,13 +359,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned char* sm
         constexpr int CHUNKS = BN / 8;                 // 8-column chunks per row
         constexpr int TASKS = 64 * CHUNKS;
 #pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            if (wm == pass) {
+        for (int pass = 0; pass < BM / 64; ++pass) {
+            if (BM == 64 || wm == pass) {          // (64-row tiles: one pass, both wave rows write their 32 rows)
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
 #pragma unroll
                     for (int i = 0; i < MF; ++i) {
-                        const int r = i * 16 + (lane & 15);
+                        const int r = (BM == 64 ? wm * WM : 0) + i * 16 + (lane & 15);
                         const int c = wn * WN + j * 16 + (lane >> 4) * 4;
                         *reinterpret_cast<f32x4*>(Cs + r * CS_LD + c) = acc[j][i];
                     }
@@ -397,15 +401,21 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned char* sm
     if (p.splitk > 1 && p.sk_sync) gemm_reduce_slices<Tag, BN, BM, NT>(p, (unsigned)(tm * tiles_n + tn), kslice, S, m0, n0, tid);      // (uniform branch)
 }
 
-template <int BN, int NST>
+template <int BN, int NST, int BMT = BM>
 constexpr int gemm_smem_bytes() {
-    return (NST * (BM + BN) * ROW_BYTES > 64 * (BN + 4) * 4) ? NST * (BM + BN) * ROW_BYTES : 64 * (BN + 4) * 4;
+    return (NST * (BMT + BN) * ROW_BYTES > 64 * (BN + 4) * 4) ? NST * (BMT + BN) * ROW_BYTES : 64 * (BN + 4) * 4;
 }
 
 template <class Tag, int BN, int MODE>
 __global__ __launch_bounds__(NT, 2) void k_gemm(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_smem_bytes<BN, 2>()];
     gemm_body<Tag, BN, MODE, 2>(p, smem);
+}
+
+template <class Tag, int BN, int MODE>
+__global__ __launch_bounds__(NT, 2) void k_gemm64(const GemmParams p) {      // 64-row tiles (gemm_body's BM)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_smem_bytes<BN, 2, 64>()];
+    gemm_body<Tag, BN, MODE, 2, 64>(p, smem);
 }
 
 constexpr int DEEP_NST = 4;
@@ -500,6 +510,23 @@ int gemm_small_bn_max_blocks() {
     return g_small_bn_max;
 }
 
+int g_small_bm = -1, g_small_bm_max = -1;
+int gemm_small_bm() {
+    if (g_small_bm < 0) {
+        const char* e = getenv("MVE_GEMM_SMALL_BM");
+        g_small_bm = e ? atoi(e) : 0;
+        if (g_small_bm != 64) g_small_bm = 0;
+    }
+    return g_small_bm;
+}
+int gemm_small_bm_max_blocks() {
+    if (g_small_bm_max < 0) {
+        const char* e = getenv("MVE_GEMM_SMALL_BM_MAX");
+        g_small_bm_max = e ? atoi(e) : 512;
+    }
+    return g_small_bm_max;
+}
+
 // K columns per block from which a launch that fills neither 256-row rule takes the ping-pong 256 x 160 tile anyway; 0 = never.  MVE_GEMM_PP160_MINK.
 int g_pp160_min_k = -1;
 int gemm_pp160_min_k() {
@@ -573,6 +600,13 @@ int launch_v(const GemmParams& p, hipStream_t s) {
     if ((int)grid <= gemm_deep_max_blocks() && nk_slice > 2 && bn >= 128) {
         if (bn == 160) return launch_deep<Tag, 160, MODE>(p, grid, s);
         return launch_deep<Tag, 128, MODE>(p, grid, s);
+    }
+    // ... and 64 x 64 tiles where even the 128 x 64 tiling is at most gemm_small_bm_max_blocks() blocks (MVE_GEMM_SMALL_BM = 64 | 0)
+    if (bn == 64 && gemm_small_bm() == 64 && p.N % 64 == 0 && p.M > 64 && (int)grid <= gemm_small_bm_max_blocks()) {
+        const unsigned grid64 = mve_cdiv(p.M, 64) * tiles_n * (p.splitk > 1 ? p.splitk : 1);
+        k_gemm64<Tag, 64, MODE><<<grid64, NT, 0, s>>>(p);
+        MVE_LAUNCH_CHECK();
+        return splitk_reduce_launch<Tag>(p, s);
     }
     if (bn == 160) k_gemm<Tag, 160, MODE><<<grid, NT, 0, s>>>(p);
     else if (bn == 128) k_gemm<Tag, 128, MODE><<<grid, NT, 0, s>>>(p);
